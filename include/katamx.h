@@ -1,0 +1,206 @@
+/*
+ * katamx.h — C ABI of the MI355X-native KataGo neural-net evaluation backend.
+ *
+ * This is the drop-in boundary for ONE hot path of lightvector/KataGo: the
+ * NNEvaluator batch path. Every entry point replaces (is bound by) one function of
+ * the reference's compile-time backend interface `namespace NeuralNet`
+ * (reference: cpp/neuralnet/nninterface.h:32-182). The reference-side binding
+ * (a backend TU implementing NeuralNet:: on top of this ABI) is
+ * integration/katamxbackend.cpp; INTEGRATION.md shows how it is wired in.
+ *
+ * Conventions
+ *   - plain C, opaque handles, plain pointers and sizes; no C++/torch types.
+ *   - every function that can fail returns KMX_OK (0) or a negative kmx_status;
+ *     kmx_last_error() returns a thread-local human-readable message. The reference
+ *     reports errors by throwing StringError (cpp/core/global.h:151); the shim rethrows.
+ *   - all tensors crossing the boundary are fp32, little endian, "NHWC" where spatial:
+ *     index = (y*nnXLen + x)*C + c. "All outputs are logits" (nninterface.h:116):
+ *     no softmax / tanh / scaling is applied by the backend.
+ *   - a kmx_handle is used by exactly one host thread at a time (nninterface.h:19-21).
+ *   - the implementation is HIP-only (gfx950). There is no CPU fallback: without a
+ *     usable GPU kmx_handle_create fails with KMX_ERR_DEVICE.
+ */
+#ifndef KATAMX_H_
+#define KATAMX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMX_ABI_VERSION 1
+
+typedef enum kmx_status {
+  KMX_OK = 0,
+  KMX_ERR_INVALID_ARG = -1,
+  KMX_ERR_IO = -2,          /* model file unreadable / truncated */
+  KMX_ERR_MODEL = -3,       /* model parse error or unsupported architecture */
+  KMX_ERR_DEVICE = -4,      /* HIP runtime error / no device */
+  KMX_ERR_UNSUPPORTED = -5, /* valid request this backend does not implement */
+  KMX_ERR_INTERNAL = -6
+} kmx_status;
+
+/* Activation kinds — numeric values equal the reference's (cpp/neuralnet/activations.h:4-17). */
+enum { KMX_ACT_IDENTITY = 0, KMX_ACT_RELU = 1, KMX_ACT_MISH = 2, KMX_ACT_SILU = 3 };
+
+/* Arithmetic of the device path. The reference's tri-state useFP16Mode
+ * (cpp/core/commontypes.h:4-30) maps as: False -> KMX_PREC_FP32, True/Auto -> KMX_PREC_AUTO. */
+enum {
+  KMX_PREC_AUTO = 0, /* backend default 16-bit storage (bf16), fp32 accumulate */
+  KMX_PREC_FP32 = 1, /* fp32 storage and arithmetic (slow verification mode) */
+  KMX_PREC_FP16 = 2, /* fp16 storage, fp32 accumulate */
+  KMX_PREC_BF16 = 3  /* bf16 storage, fp32 accumulate */
+};
+
+typedef struct kmx_model kmx_model;     /* replaces LoadedModel   (nninterface.h:27) */
+typedef struct kmx_context kmx_context; /* replaces ComputeContext (nninterface.h:17) */
+typedef struct kmx_handle kmx_handle;   /* replaces ComputeHandle + InputBuffers (nninterface.h:21,24) */
+
+/* What NNEvaluator reads from ModelDesc (cpp/neuralnet/nneval.cpp:138-143,292,306,327;
+ * fields of cpp/neuralnet/desc.h ModelDesc / ModelPostProcessParams). */
+typedef struct kmx_model_info {
+  char name[128];
+  int32_t model_version;
+  int32_t num_input_channels;        /* 22 for inputs v7 */
+  int32_t num_input_global_channels; /* 19 for inputs v7 */
+  int32_t num_input_meta_channels;   /* 0 (sgf-metadata nets are rejected at load) */
+  int32_t num_policy_channels;       /* 1, 2 or 4 */
+  int32_t num_value_channels;        /* 3 */
+  int32_t num_score_value_channels;  /* 4 (v8) or 6 (v>=9) */
+  int32_t num_ownership_channels;    /* 1 */
+  int32_t trunk_num_channels;
+  int32_t mid_num_channels;
+  int32_t num_blocks;
+  int32_t reserved0;
+  /* ModelPostProcessParams (desc.cpp:2477-2513); defaults for v<13 as in desc.h */
+  float td_score_multiplier;
+  float score_mean_multiplier;
+  float score_stdev_multiplier;
+  float lead_multiplier;
+  float variance_time_multiplier;
+  float shortterm_value_error_multiplier;
+  float shortterm_score_error_multiplier;
+  float output_scale_multiplier; /* always 1: this backend never applies scale-8 */
+  int64_t num_parameters;
+  double flops_per_position; /* 2*MAC per board point, direct-convolution count */
+} kmx_model_info;
+
+/* ---- process-wide ----------------------------------------------------------------- */
+/* NeuralNet::globalInitialize / globalCleanup / printDevices  (nninterface.h:34-39) */
+int kmx_abi_version(void);
+int kmx_global_init(void);
+void kmx_global_cleanup(void);
+int kmx_device_count(void); /* <0 on error */
+int kmx_device_name(int device, char* buf, size_t buflen);
+const char* kmx_last_error(void);
+
+/* ---- model ------------------------------------------------------------------------- */
+/* NeuralNet::loadModelFile / freeLoadedModel / getModelDesc  (nninterface.h:43-46).
+ * Reads KataGo .bin / .txt model files, optionally gzipped (format: desc.cpp:40-90,2441-2615).
+ * expected_sha256 may be NULL or "" (no check). */
+int kmx_model_load(const char* path, const char* expected_sha256, kmx_model** out);
+void kmx_model_free(kmx_model* model);
+int kmx_model_info_get(const kmx_model* model, kmx_model_info* out);
+
+/* ---- context / handle -------------------------------------------------------------- */
+/* NeuralNet::createComputeContext / freeComputeContext  (nninterface.h:50-65). */
+int kmx_context_create(const int* gpu_idxs, int num_gpu_idxs, int nn_x_len, int nn_y_len,
+                       int precision_mode, kmx_context** out);
+void kmx_context_free(kmx_context* ctx);
+
+/* NeuralNet::createComputeHandle (+createInputBuffers) / freeComputeHandle / isUsingFP16
+ * (nninterface.h:76-99). Must be called on the thread that will use the handle;
+ * gpu_idx < 0 means "default device 0". Uploads a private copy of the weights. */
+int kmx_handle_create(kmx_context* ctx, const kmx_model* model, int max_batch_size,
+                      int require_exact_nn_len, int gpu_idx, kmx_handle** out);
+void kmx_handle_free(kmx_handle* handle);
+int kmx_handle_precision(const kmx_handle* handle); /* KMX_PREC_FP32/FP16/BF16 actually in use */
+
+/* ---- the hot path ------------------------------------------------------------------ */
+/* NeuralNet::getOutput (nninterface.h:117-123; semantics: eigenbackend.cpp:2445-2628).
+ *   row_spatial[i]  -> float[nnY*nnX*num_input_channels], NHWC, NOT yet symmetrised
+ *                      (NNResultBuf::rowSpatialBuf, nneval.h:55)
+ *   row_global[i]   -> float[num_input_global_channels]    (rowGlobalBuf)
+ *   symmetry[i]     0..7: bit0 flipY, bit1 flipX, bit2 transpose (nninputs.cpp:529-597)
+ *   policy_optimism[i]  blend weight p + (pOpt-p)*w (eigenbackend.cpp:2553-2562)
+ * Outputs (all logits, inverse-symmetrised where spatial):
+ *   out_policy[i]   -> float[nnX*nnY + 1], last element = pass logit
+ *   out_value       -> float[n_rows*3]  win, loss, noResult (side to move)
+ *   out_score       -> float[n_rows*6]  scoreMean, scoreStdev(pre-softplus), lead,
+ *                      varTimeLeft, shorttermWinlossError, shorttermScoreError
+ *                      (v8 nets: last two are 0)            (eigenbackend.cpp:2583-2606)
+ *   out_ownership[i]-> float[nnX*nnY] or NULL to skip that row
+ * Synchronous: on return all outputs are filled. */
+int kmx_eval(kmx_handle* handle, int n_rows,
+             const float* const* row_spatial, const float* const* row_global,
+             const int* symmetry, const float* policy_optimism,
+             float* const* out_policy, float* out_value, float* out_score,
+             float* const* out_ownership);
+
+/* Device-resident variant used by bench.py and the persistent batcher: inputs already
+ * staged in HBM in the packed batch layout (see DESIGN.md "Input staging").
+ *   d_spatial: float[n_rows][nnY*nnX*Cin], d_global: float[n_rows][G] (device pointers)
+ *   symmetry/policy_optimism: host arrays. Outputs written to DEVICE buffers:
+ *   d_policy float[n_rows][nnX*nnY+1], d_value float[n_rows][3], d_score float[n_rows][6],
+ *   d_ownership float[n_rows][nnX*nnY]. Asynchronous on the handle's stream unless sync!=0. */
+int kmx_eval_device(kmx_handle* handle, int n_rows, const float* d_spatial, const float* d_global,
+                    const int* symmetry, const float* policy_optimism,
+                    float* d_policy, float* d_value, float* d_score, float* d_ownership, int sync);
+void* kmx_handle_stream(kmx_handle* handle); /* hipStream_t the handle launches on */
+int kmx_handle_sync(kmx_handle* handle);
+
+/* NNEvaluator counters (nneval.cpp:330-347, incremented :712-713): rows = evaluated
+ * positions, batches = kmx_eval calls. */
+int kmx_handle_stats(const kmx_handle* handle, uint64_t* rows, uint64_t* batches);
+
+/* ---- layer test hooks -------------------------------------------------------------- */
+/* NeuralNet::testEvaluateConv / BatchNorm / ResidualBlock / GlobalPoolingResidualBlock
+ * (nninterface.h:134-180). Raw fp32 NHWC buffers in host memory; weights in the
+ * reference's in-memory layouts (conv: [oc][ic][ky][kx] desc.cpp:131-152; matmul:
+ * [ic][oc] desc.cpp:461-476; BN: merged scale/bias desc.cpp:272-279). */
+typedef struct kmx_conv_desc {
+  int32_t conv_y_size, conv_x_size, in_channels, out_channels;
+  const float* weights; /* [oc][ic][ky][kx] */
+} kmx_conv_desc;
+typedef struct kmx_bnact_desc {
+  int32_t num_channels;
+  int32_t activation; /* KMX_ACT_* */
+  const float* merged_scale;
+  const float* merged_bias;
+} kmx_bnact_desc;
+typedef struct kmx_matmul_desc {
+  int32_t in_channels, out_channels;
+  const float* weights; /* [ic][oc] */
+} kmx_matmul_desc;
+typedef struct kmx_resblock_desc { /* ResidualBlockDesc, desc.h */
+  kmx_bnact_desc pre_bn;
+  kmx_conv_desc regular_conv;
+  kmx_bnact_desc mid_bn;
+  kmx_conv_desc final_conv;
+} kmx_resblock_desc;
+typedef struct kmx_gpoolblock_desc { /* GlobalPoolingResidualBlockDesc, desc.h */
+  kmx_bnact_desc pre_bn;
+  kmx_conv_desc regular_conv;
+  kmx_conv_desc gpool_conv;
+  kmx_bnact_desc gpool_bn;
+  kmx_matmul_desc gpool_to_bias_mul;
+  kmx_bnact_desc mid_bn;
+  kmx_conv_desc final_conv;
+} kmx_gpoolblock_desc;
+
+/* precision_mode: KMX_PREC_*; returns KMX_ERR_UNSUPPORTED if that mode is not available. */
+int kmx_test_conv(const kmx_conv_desc* desc, int batch, int nn_x_len, int nn_y_len,
+                  int precision_mode, const float* in_nhwc, float* out_nhwc);
+int kmx_test_bnact(const kmx_bnact_desc* desc, int batch, int nn_x_len, int nn_y_len,
+                   int precision_mode, const float* in_nhwc, const float* mask_nhw, float* out_nhwc);
+int kmx_test_resblock(const kmx_resblock_desc* desc, int batch, int nn_x_len, int nn_y_len,
+                      int precision_mode, const float* in_nhwc, const float* mask_nhw, float* out_nhwc);
+int kmx_test_gpoolblock(const kmx_gpoolblock_desc* desc, int batch, int nn_x_len, int nn_y_len,
+                        int precision_mode, const float* in_nhwc, const float* mask_nhw, float* out_nhwc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KATAMX_H_ */

@@ -1,0 +1,510 @@
+// katamxbackend.cpp — the reference-side binding of the katamx C ABI.
+//
+// This is the backend translation unit a KataGo maintainer adds next to
+// cpp/neuralnet/{cuda,opencl,eigen,...}backend.cpp: it defines the 13 functions of
+// `namespace NeuralNet` (cpp/neuralnet/nninterface.h:32-182) and the four opaque structs
+// (nninterface.h:15-28) on top of include/katamx.h, so that the UNMODIFIED reference host code
+// (nneval.cpp, search/, command/benchmark.cpp, gputest.cpp, tests/*) runs on the MI355X backend.
+// It is compiled against the reference headers with -I<reference>/cpp (see INTEGRATION.md and
+// oracle/Makefile); it contains no arithmetic.
+//
+// With -DKMX_USE_ORACLE the same TU binds the CPU oracle (oracle/kmx_oracle.h) instead. That build
+// (oracle/_ref/katago_oracle) is test infrastructure: it lets the reference's own known-answer
+// tests pin the oracle, and plays the role of the reference's Eigen build in `testgpuerror`.
+
+#include "neuralnet/nninterface.h"
+#include "neuralnet/nneval.h"
+#include "neuralnet/nninputs.h"
+#include "neuralnet/modelversion.h"
+#include "neuralnet/desc.h"
+
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "katamx.h"
+#ifdef KMX_USE_ORACLE
+#include "kmx_oracle.h"
+#endif
+
+using namespace std;
+
+#ifdef KMX_USE_ORACLE
+static string lastError() { return string(okmx_last_error()); }
+#else
+static string lastError() { return string(kmx_last_error()); }
+#endif
+static void check(int status, const char* what) {
+  if(status != KMX_OK)
+    throw StringError(string("katamx backend: ") + what + ": " + lastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+struct LoadedModel {
+  ModelDesc modelDesc;  // parsed by the reference loader: NNEvaluator reads name/version/postprocess
+#ifdef KMX_USE_ORACLE
+  okmx_model* model = NULL;
+#else
+  kmx_model* model = NULL;
+#endif
+  LoadedModel(const string& file, const string& expectedSha256) {
+    ModelDesc::loadFromFileMaybeGZipped(file, modelDesc, expectedSha256);
+    // The backend re-parses the file itself; it does not depend on the host's ModelDesc layout.
+#ifdef KMX_USE_ORACLE
+    check(okmx_model_load(file.c_str(), expectedSha256.c_str(), &model), "loading model");
+#else
+    check(kmx_model_load(file.c_str(), expectedSha256.c_str(), &model), "loading model");
+#endif
+    // This backend never applies the scale-8 transform (desc.cpp:2718-2736): outputScaleMultiplier stays 1.
+    modelDesc.releaseWeights();
+  }
+  ~LoadedModel() {
+#ifdef KMX_USE_ORACLE
+    okmx_model_free(model);
+#else
+    kmx_model_free(model);
+#endif
+  }
+  LoadedModel() = delete;
+  LoadedModel(const LoadedModel&) = delete;
+  LoadedModel& operator=(const LoadedModel&) = delete;
+};
+
+struct ComputeContext {
+  int nnXLen;
+  int nnYLen;
+  int precisionMode;
+#ifndef KMX_USE_ORACLE
+  kmx_context* ctx = NULL;
+#endif
+};
+
+struct ComputeHandle {
+  const ComputeContext* context;
+  const LoadedModel* loadedModel;
+  bool inputsUseNHWC;
+  int modelVersion;
+  int numInputChannels;
+  int numInputGlobalChannels;
+#ifndef KMX_USE_ORACLE
+  kmx_handle* handle = NULL;
+#endif
+};
+
+struct InputBuffers {
+  int maxBatchSize;
+  size_t singleInputElts;
+  size_t singlePolicyElts;
+  size_t singleOwnershipElts;
+  // Per-call pointer tables and output staging, reused across calls.
+  vector<const float*> rowSpatial;
+  vector<const float*> rowGlobal;
+  vector<int> symmetry;
+  vector<float> policyOptimism;
+  vector<float*> outPolicy;
+  vector<float*> outOwnership;
+  vector<float> value;
+  vector<float> score;
+  vector<float> ownershipScratch;
+  vector<float> nhwcScratch;  // only used when the host hands over NCHW rows
+};
+
+// ---------------------------------------------------------------------------------------------
+void NeuralNet::globalInitialize() {
+#ifndef KMX_USE_ORACLE
+  check(kmx_global_init(), "global init");
+#endif
+}
+void NeuralNet::globalCleanup() {
+#ifndef KMX_USE_ORACLE
+  kmx_global_cleanup();
+#endif
+}
+void NeuralNet::printDevices() {
+#ifdef KMX_USE_ORACLE
+  cout << "katamx CPU oracle (no devices)" << endl;
+#else
+  int n = kmx_device_count();
+  for(int i = 0; i < n; i++) {
+    char name[256];
+    if(kmx_device_name(i, name, sizeof(name)) == KMX_OK)
+      cout << "Found HIP device " << i << ": " << name << endl;
+  }
+#endif
+}
+
+LoadedModel* NeuralNet::loadModelFile(const string& file, const string& expectedSha256) {
+  return new LoadedModel(file, expectedSha256);
+}
+void NeuralNet::freeLoadedModel(LoadedModel* loadedModel) {
+  delete loadedModel;
+}
+const ModelDesc& NeuralNet::getModelDesc(const LoadedModel* loadedModel) {
+  return loadedModel->modelDesc;
+}
+
+ComputeContext* NeuralNet::createComputeContext(
+  const vector<int>& gpuIdxs,
+  Logger* logger,
+  int nnXLen,
+  int nnYLen,
+  const string& homeDataDirOverride,
+  enabled_t useFP16Mode,
+  const LoadedModel* loadedModel,
+  ConfigParser& cfg
+) {
+  (void)logger;
+  (void)homeDataDirOverride;
+  (void)loadedModel;
+  ComputeContext* context = new ComputeContext();
+  context->nnXLen = nnXLen;
+  context->nnYLen = nnYLen;
+  // useFP16 = false asks for fp32; true/auto picks the backend's 16-bit default. The private key
+  // katamxPrecision = fp16|bf16|fp32 overrides (read off cfg as nninterface.h:60-62 allows).
+  int precisionMode = (useFP16Mode == enabled_t::False) ? KMX_PREC_FP32 : KMX_PREC_AUTO;
+  if(cfg.contains("katamxPrecision")) {
+    string p = cfg.getString("katamxPrecision");
+    if(p == "fp16") precisionMode = KMX_PREC_FP16;
+    else if(p == "bf16") precisionMode = KMX_PREC_BF16;
+    else if(p == "fp32") precisionMode = KMX_PREC_FP32;
+    else if(p == "auto") precisionMode = KMX_PREC_AUTO;
+    else throw StringError("katamxPrecision must be one of fp16, bf16, fp32, auto");
+  }
+  context->precisionMode = precisionMode;
+#ifndef KMX_USE_ORACLE
+  check(
+    kmx_context_create(gpuIdxs.data(), (int)gpuIdxs.size(), nnXLen, nnYLen, precisionMode, &context->ctx),
+    "creating compute context");
+#else
+  (void)gpuIdxs;
+#endif
+  return context;
+}
+void NeuralNet::freeComputeContext(ComputeContext* computeContext) {
+  if(computeContext == NULL)
+    return;
+#ifndef KMX_USE_ORACLE
+  kmx_context_free(computeContext->ctx);
+#endif
+  delete computeContext;
+}
+
+ComputeHandle* NeuralNet::createComputeHandle(
+  ComputeContext* context,
+  const LoadedModel* loadedModel,
+  Logger* logger,
+  int maxBatchSize,
+  bool requireExactNNLen,
+  bool inputsUseNHWC,
+  int gpuIdxForThisThread,
+  int serverThreadIdx
+) {
+  ComputeHandle* handle = new ComputeHandle();
+  handle->context = context;
+  handle->loadedModel = loadedModel;
+  handle->inputsUseNHWC = inputsUseNHWC;
+  handle->modelVersion = loadedModel->modelDesc.modelVersion;
+  handle->numInputChannels = loadedModel->modelDesc.numInputChannels;
+  handle->numInputGlobalChannels = loadedModel->modelDesc.numInputGlobalChannels;
+#ifndef KMX_USE_ORACLE
+  check(
+    kmx_handle_create(
+      context->ctx, loadedModel->model, maxBatchSize, requireExactNNLen ? 1 : 0, gpuIdxForThisThread, &handle->handle),
+    "creating compute handle");
+  if(logger != NULL) {
+    int prec = kmx_handle_precision(handle->handle);
+    logger->write(
+      "katamx (HIP/gfx950) backend thread " + Global::intToString(serverThreadIdx) + ": device " +
+      Global::intToString(gpuIdxForThisThread) + " precision " +
+      (prec == KMX_PREC_FP32 ? "fp32" : prec == KMX_PREC_FP16 ? "fp16" : "bf16") + " model " +
+      loadedModel->modelDesc.name);
+  }
+#else
+  (void)maxBatchSize;
+  (void)requireExactNNLen;
+  (void)gpuIdxForThisThread;
+  if(logger != NULL)
+    logger->write("katamx CPU ORACLE backend thread " + Global::intToString(serverThreadIdx) + " model " + loadedModel->modelDesc.name);
+#endif
+  return handle;
+}
+void NeuralNet::freeComputeHandle(ComputeHandle* handle) {
+  if(handle == NULL)
+    return;
+#ifndef KMX_USE_ORACLE
+  kmx_handle_free(handle->handle);
+#endif
+  delete handle;
+}
+
+bool NeuralNet::isUsingFP16(const ComputeHandle* handle) {
+#ifdef KMX_USE_ORACLE
+  (void)handle;
+  return false;
+#else
+  return kmx_handle_precision(handle->handle) != KMX_PREC_FP32;
+#endif
+}
+bool NeuralNet::setIsWarmup(const ComputeHandle* handle, bool isWarmup) {
+  (void)handle;
+  (void)isWarmup;
+  return false;
+}
+
+InputBuffers* NeuralNet::createInputBuffers(const LoadedModel* loadedModel, int maxBatchSize, int nnXLen, int nnYLen) {
+  const ModelDesc& m = loadedModel->modelDesc;
+  InputBuffers* buffers = new InputBuffers();
+  buffers->maxBatchSize = maxBatchSize;
+  buffers->singleInputElts = (size_t)m.numInputChannels * nnXLen * nnYLen;
+  buffers->singlePolicyElts = (size_t)nnXLen * nnYLen + 1;
+  buffers->singleOwnershipElts = (size_t)nnXLen * nnYLen;
+  buffers->rowSpatial.resize(maxBatchSize);
+  buffers->rowGlobal.resize(maxBatchSize);
+  buffers->symmetry.resize(maxBatchSize);
+  buffers->policyOptimism.resize(maxBatchSize);
+  buffers->outPolicy.resize(maxBatchSize);
+  buffers->outOwnership.resize(maxBatchSize);
+  buffers->value.resize((size_t)maxBatchSize * 3);
+  buffers->score.resize((size_t)maxBatchSize * 6);
+  return buffers;
+}
+void NeuralNet::freeInputBuffers(InputBuffers* buffers) {
+  delete buffers;
+}
+
+void NeuralNet::getOutput(
+  ComputeHandle* handle,
+  InputBuffers* buffers,
+  int numBatchEltsFilled,
+  NNResultBuf** inputBufs,
+  vector<NNOutput*>& outputs
+) {
+  const int batchSize = numBatchEltsFilled;
+  testAssert(batchSize > 0 && batchSize <= buffers->maxBatchSize);
+  testAssert((int)outputs.size() == batchSize);
+  const int nnXLen = handle->context->nnXLen;
+  const int nnYLen = handle->context->nnYLen;
+  const int cIn = handle->numInputChannels;
+  const int area = nnXLen * nnYLen;
+
+  if(!handle->inputsUseNHWC)
+    buffers->nhwcScratch.resize((size_t)batchSize * buffers->singleInputElts);
+
+  for(int row = 0; row < batchSize; row++) {
+    const NNResultBuf* in = inputBufs[row];
+    testAssert(!in->hasRowMeta);  // sgf-metadata nets are rejected at load
+    NNOutput* out = outputs[row];
+    testAssert(out->nnXLen == nnXLen && out->nnYLen == nnYLen);
+    if(handle->inputsUseNHWC)
+      buffers->rowSpatial[row] = in->rowSpatialBuf.data();
+    else {
+      // NCHW hand-over (only if a config forces inputsUseNHWC=false): transpose on the host.
+      float* dst = buffers->nhwcScratch.data() + (size_t)row * buffers->singleInputElts;
+      const float* src = in->rowSpatialBuf.data();
+      for(int c = 0; c < cIn; c++)
+        for(int p = 0; p < area; p++)
+          dst[(size_t)p * cIn + c] = src[(size_t)c * area + p];
+      buffers->rowSpatial[row] = dst;
+    }
+    buffers->rowGlobal[row] = in->rowGlobalBuf.data();
+    buffers->symmetry[row] = in->symmetry;
+    buffers->policyOptimism[row] = (float)in->policyOptimism;
+    buffers->outPolicy[row] = out->policyProbs;
+    buffers->outOwnership[row] = out->whiteOwnerMap;  // NULL => skipped
+  }
+
+#ifdef KMX_USE_ORACLE
+  check(
+    okmx_eval(
+      handle->loadedModel->model, nnXLen, nnYLen, batchSize, buffers->rowSpatial.data(), buffers->rowGlobal.data(),
+      buffers->symmetry.data(), buffers->policyOptimism.data(), buffers->outPolicy.data(), buffers->value.data(),
+      buffers->score.data(), buffers->outOwnership.data(), 1),
+    "evaluating batch");
+#else
+  check(
+    kmx_eval(
+      handle->handle, batchSize, buffers->rowSpatial.data(), buffers->rowGlobal.data(), buffers->symmetry.data(),
+      buffers->policyOptimism.data(), buffers->outPolicy.data(), buffers->value.data(), buffers->score.data(),
+      buffers->outOwnership.data()),
+    "evaluating batch");
+#endif
+
+  // Scalars -> NNOutput, exactly the field mapping of eigenbackend.cpp:2569-2626.
+  const int modelVersion = handle->modelVersion;
+  for(int row = 0; row < batchSize; row++) {
+    NNOutput* out = outputs[row];
+    const float* v = buffers->value.data() + (size_t)row * 3;
+    const float* s = buffers->score.data() + (size_t)row * 6;
+    out->whiteWinProb = v[0];
+    out->whiteLossProb = v[1];
+    out->whiteNoResultProb = v[2];
+    out->whiteScoreMean = s[0];
+    out->whiteScoreMeanSq = s[1];
+    out->whiteLead = s[2];
+    out->varTimeLeft = s[3];
+    if(modelVersion >= 9) {
+      out->shorttermWinlossError = s[4];
+      out->shorttermScoreError = s[5];
+    }
+    else {
+      out->shorttermWinlossError = 0;
+      out->shorttermScoreError = 0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Test hooks. The reference hands over NCHW or NHWC fp32 vectors; the ABI is NHWC only.
+
+static vector<float> toNHWC(const vector<float>& v, int n, int c, int h, int w, bool isNHWC) {
+  if(isNHWC)
+    return v;
+  vector<float> r(v.size());
+  for(int b = 0; b < n; b++)
+    for(int ch = 0; ch < c; ch++)
+      for(int p = 0; p < h * w; p++)
+        r[((size_t)b * h * w + p) * c + ch] = v[((size_t)b * c + ch) * h * w + p];
+  return r;
+}
+static vector<float> fromNHWC(const vector<float>& v, int n, int c, int h, int w, bool wantNHWC) {
+  if(wantNHWC)
+    return v;
+  vector<float> r(v.size());
+  for(int b = 0; b < n; b++)
+    for(int ch = 0; ch < c; ch++)
+      for(int p = 0; p < h * w; p++)
+        r[((size_t)b * c + ch) * h * w + p] = v[((size_t)b * h * w + p) * c + ch];
+  return r;
+}
+static kmx_conv_desc convDesc(const ConvLayerDesc& d) {
+  kmx_conv_desc c;
+  c.conv_y_size = d.convYSize;
+  c.conv_x_size = d.convXSize;
+  c.in_channels = d.inChannels;
+  c.out_channels = d.outChannels;
+  c.weights = d.weights.data();
+  return c;
+}
+static kmx_bnact_desc bnDesc(const BatchNormLayerDesc& d, int activation) {
+  kmx_bnact_desc b;
+  b.num_channels = d.numChannels;
+  b.activation = activation;
+  b.merged_scale = d.mergedScale.data();
+  b.merged_bias = d.mergedBias.data();
+  return b;
+}
+static kmx_matmul_desc matmulDesc(const MatMulLayerDesc& d) {
+  kmx_matmul_desc m;
+  m.in_channels = d.inChannels;
+  m.out_channels = d.outChannels;
+  m.weights = d.weights.data();
+  return m;
+}
+#ifdef KMX_USE_ORACLE
+static bool precisionSupported(bool useFP16, int& mode) { mode = KMX_PREC_FP32; return !useFP16; }
+#else
+static bool precisionSupported(bool useFP16, int& mode) { mode = useFP16 ? KMX_PREC_AUTO : KMX_PREC_FP32; return true; }
+#endif
+static bool hookResult(int status, const char* what) {
+  if(status == KMX_ERR_UNSUPPORTED)
+    return false;
+  check(status, what);
+  return true;
+}
+
+bool NeuralNet::testEvaluateConv(
+  const ConvLayerDesc* desc, int batchSize, int nnXLen, int nnYLen, bool useFP16, bool useNHWC,
+  const vector<float>& inputBuffer, vector<float>& outputBuffer
+) {
+  int mode;
+  if(!precisionSupported(useFP16, mode))
+    return false;
+  kmx_conv_desc c = convDesc(*desc);
+  vector<float> in = toNHWC(inputBuffer, batchSize, desc->inChannels, nnYLen, nnXLen, useNHWC);
+  vector<float> out((size_t)batchSize * nnXLen * nnYLen * desc->outChannels);
+#ifdef KMX_USE_ORACLE
+  int status = okmx_test_conv(&c, batchSize, nnXLen, nnYLen, in.data(), out.data());
+#else
+  int status = kmx_test_conv(&c, batchSize, nnXLen, nnYLen, mode, in.data(), out.data());
+#endif
+  if(!hookResult(status, "testEvaluateConv"))
+    return false;
+  outputBuffer = fromNHWC(out, batchSize, desc->outChannels, nnYLen, nnXLen, useNHWC);
+  return true;
+}
+
+bool NeuralNet::testEvaluateBatchNorm(
+  const BatchNormLayerDesc* desc, int batchSize, int nnXLen, int nnYLen, bool useFP16, bool useNHWC,
+  const vector<float>& inputBuffer, const vector<float>& maskBuffer, vector<float>& outputBuffer
+) {
+  int mode;
+  if(!precisionSupported(useFP16, mode))
+    return false;
+  kmx_bnact_desc b = bnDesc(*desc, ACTIVATION_IDENTITY);
+  vector<float> in = toNHWC(inputBuffer, batchSize, desc->numChannels, nnYLen, nnXLen, useNHWC);
+  vector<float> out(in.size());
+#ifdef KMX_USE_ORACLE
+  int status = okmx_test_bnact(&b, batchSize, nnXLen, nnYLen, in.data(), maskBuffer.data(), out.data());
+#else
+  int status = kmx_test_bnact(&b, batchSize, nnXLen, nnYLen, mode, in.data(), maskBuffer.data(), out.data());
+#endif
+  if(!hookResult(status, "testEvaluateBatchNorm"))
+    return false;
+  outputBuffer = fromNHWC(out, batchSize, desc->numChannels, nnYLen, nnXLen, useNHWC);
+  return true;
+}
+
+bool NeuralNet::testEvaluateResidualBlock(
+  const ResidualBlockDesc* desc, int batchSize, int nnXLen, int nnYLen, bool useFP16, bool useNHWC,
+  const vector<float>& inputBuffer, const vector<float>& maskBuffer, vector<float>& outputBuffer
+) {
+  int mode;
+  if(!precisionSupported(useFP16, mode))
+    return false;
+  kmx_resblock_desc r;
+  r.pre_bn = bnDesc(desc->preBN, desc->preActivation.activation);
+  r.regular_conv = convDesc(desc->regularConv);
+  r.mid_bn = bnDesc(desc->midBN, desc->midActivation.activation);
+  r.final_conv = convDesc(desc->finalConv);
+  const int c = desc->preBN.numChannels;
+  vector<float> in = toNHWC(inputBuffer, batchSize, c, nnYLen, nnXLen, useNHWC);
+  vector<float> out(in.size());
+#ifdef KMX_USE_ORACLE
+  int status = okmx_test_resblock(&r, batchSize, nnXLen, nnYLen, in.data(), maskBuffer.data(), out.data());
+#else
+  int status = kmx_test_resblock(&r, batchSize, nnXLen, nnYLen, mode, in.data(), maskBuffer.data(), out.data());
+#endif
+  if(!hookResult(status, "testEvaluateResidualBlock"))
+    return false;
+  outputBuffer = fromNHWC(out, batchSize, c, nnYLen, nnXLen, useNHWC);
+  return true;
+}
+
+bool NeuralNet::testEvaluateGlobalPoolingResidualBlock(
+  const GlobalPoolingResidualBlockDesc* desc, int batchSize, int nnXLen, int nnYLen, bool useFP16, bool useNHWC,
+  const vector<float>& inputBuffer, const vector<float>& maskBuffer, vector<float>& outputBuffer
+) {
+  int mode;
+  if(!precisionSupported(useFP16, mode))
+    return false;
+  kmx_gpoolblock_desc g;
+  g.pre_bn = bnDesc(desc->preBN, desc->preActivation.activation);
+  g.regular_conv = convDesc(desc->regularConv);
+  g.gpool_conv = convDesc(desc->gpoolConv);
+  g.gpool_bn = bnDesc(desc->gpoolBN, desc->gpoolActivation.activation);
+  g.gpool_to_bias_mul = matmulDesc(desc->gpoolToBiasMul);
+  g.mid_bn = bnDesc(desc->midBN, desc->midActivation.activation);
+  g.final_conv = convDesc(desc->finalConv);
+  const int c = desc->preBN.numChannels;
+  vector<float> in = toNHWC(inputBuffer, batchSize, c, nnYLen, nnXLen, useNHWC);
+  vector<float> out(in.size());
+#ifdef KMX_USE_ORACLE
+  int status = okmx_test_gpoolblock(&g, batchSize, nnXLen, nnYLen, in.data(), maskBuffer.data(), out.data());
+#else
+  int status = kmx_test_gpoolblock(&g, batchSize, nnXLen, nnYLen, mode, in.data(), maskBuffer.data(), out.data());
+#endif
+  if(!hookResult(status, "testEvaluateGlobalPoolingResidualBlock"))
+    return false;
+  outputBuffer = fromNHWC(out, batchSize, c, nnYLen, nnXLen, useNHWC);
+  return true;
+}
