@@ -1,0 +1,64 @@
+"""Build libkatamx.so (HIP kernels + C ABI) in-tree with hipcc for gfx950.
+
+    python -m katago_amd.build            # incremental
+    python -m katago_amd.build --force
+
+The shared library lands next to this file (katago_amd/libkatamx.so): it is git-ignored but travels
+with the tree to the GPU box. hipcc cross-compiles gfx950 without a GPU present.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJDIR = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "libkatamx.so")
+
+SOURCES = ["conv_mfma.hip", "misc_kernels.hip", "engine.cpp", "model_desc.cpp", "kmx_api.cpp"]
+HEADERS = ["kernels.h", "device_common.h", "engine.h", "model_desc.h", os.path.join("..", "..", "include", "katamx.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-x", "hip"]
+
+
+def _mtime(p):
+    return os.path.getmtime(p) if os.path.exists(p) else 0.0
+
+
+def _compile(src):
+    obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+    cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    return obj
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJDIR, exist_ok=True)
+    newest_header = max(_mtime(os.path.join(CSRC, h)) for h in HEADERS)
+    todo = []
+    objs = []
+    for s in SOURCES:
+        obj = os.path.join(OBJDIR, os.path.splitext(s)[0] + ".o")
+        objs.append(obj)
+        if force or _mtime(obj) < max(_mtime(os.path.join(CSRC, s)), newest_header):
+            todo.append(s)
+    if todo:
+        if verbose:
+            print("[katago_amd.build] hipcc gfx950:", " ".join(todo), flush=True)
+        with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4)) as ex:
+            list(ex.map(_compile, todo))
+    if todo or not os.path.exists(LIB) or force:
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        if verbose:
+            print("[katago_amd.build] linked", LIB, flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

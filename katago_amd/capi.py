@@ -1,0 +1,132 @@
+"""ctypes binding of libkatamx.so (include/katamx.h). No torch types cross this boundary.
+
+The library is HIP-only. Importing this module does not need a GPU (model parsing works anywhere);
+creating a compute handle without a usable MI355X raises KatamxError — there is no CPU fallback.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkatamx.so")
+
+KMX_OK = 0
+KMX_ERR_INVALID_ARG, KMX_ERR_IO, KMX_ERR_MODEL, KMX_ERR_DEVICE, KMX_ERR_UNSUPPORTED, KMX_ERR_INTERNAL = -1, -2, -3, -4, -5, -6
+PREC_AUTO, PREC_FP32, PREC_FP16, PREC_BF16 = 0, 1, 2, 3
+PREC_NAMES = {PREC_AUTO: "auto", PREC_FP32: "fp32", PREC_FP16: "fp16", PREC_BF16: "bf16"}
+ACT_IDENTITY, ACT_RELU, ACT_MISH, ACT_SILU = 0, 1, 2, 3
+
+
+class KatamxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("katamx error %d: %s" % (code, msg))
+        self.code = code
+
+
+class ModelInfo(ctypes.Structure):
+    _fields_ = [
+        ("name", ctypes.c_char * 128),
+        ("model_version", ctypes.c_int32),
+        ("num_input_channels", ctypes.c_int32),
+        ("num_input_global_channels", ctypes.c_int32),
+        ("num_input_meta_channels", ctypes.c_int32),
+        ("num_policy_channels", ctypes.c_int32),
+        ("num_value_channels", ctypes.c_int32),
+        ("num_score_value_channels", ctypes.c_int32),
+        ("num_ownership_channels", ctypes.c_int32),
+        ("trunk_num_channels", ctypes.c_int32),
+        ("mid_num_channels", ctypes.c_int32),
+        ("num_blocks", ctypes.c_int32),
+        ("reserved0", ctypes.c_int32),
+        ("td_score_multiplier", ctypes.c_float),
+        ("score_mean_multiplier", ctypes.c_float),
+        ("score_stdev_multiplier", ctypes.c_float),
+        ("lead_multiplier", ctypes.c_float),
+        ("variance_time_multiplier", ctypes.c_float),
+        ("shortterm_value_error_multiplier", ctypes.c_float),
+        ("shortterm_score_error_multiplier", ctypes.c_float),
+        ("output_scale_multiplier", ctypes.c_float),
+        ("num_parameters", ctypes.c_int64),
+        ("flops_per_position", ctypes.c_double),
+    ]
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [("conv_y_size", ctypes.c_int32), ("conv_x_size", ctypes.c_int32), ("in_channels", ctypes.c_int32),
+                ("out_channels", ctypes.c_int32), ("weights", ctypes.POINTER(ctypes.c_float))]
+
+
+class BnActDesc(ctypes.Structure):
+    _fields_ = [("num_channels", ctypes.c_int32), ("activation", ctypes.c_int32),
+                ("merged_scale", ctypes.POINTER(ctypes.c_float)), ("merged_bias", ctypes.POINTER(ctypes.c_float))]
+
+
+class MatMulDesc(ctypes.Structure):
+    _fields_ = [("in_channels", ctypes.c_int32), ("out_channels", ctypes.c_int32), ("weights", ctypes.POINTER(ctypes.c_float))]
+
+
+class ResBlockDesc(ctypes.Structure):
+    _fields_ = [("pre_bn", BnActDesc), ("regular_conv", ConvDesc), ("mid_bn", BnActDesc), ("final_conv", ConvDesc)]
+
+
+class GPoolBlockDesc(ctypes.Structure):
+    _fields_ = [("pre_bn", BnActDesc), ("regular_conv", ConvDesc), ("gpool_conv", ConvDesc), ("gpool_bn", BnActDesc),
+                ("gpool_to_bias_mul", MatMulDesc), ("mid_bn", BnActDesc), ("final_conv", ConvDesc)]
+
+
+_FP = ctypes.POINTER(ctypes.c_float)
+_FPP = ctypes.POINTER(_FP)
+_IP = ctypes.POINTER(ctypes.c_int)
+
+# every symbol include/katamx.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "kmx_abi_version": (ctypes.c_int, []),
+    "kmx_global_init": (ctypes.c_int, []),
+    "kmx_global_cleanup": (None, []),
+    "kmx_device_count": (ctypes.c_int, []),
+    "kmx_device_name": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]),
+    "kmx_last_error": (ctypes.c_char_p, []),
+    "kmx_model_load": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]),
+    "kmx_model_free": (None, [ctypes.c_void_p]),
+    "kmx_model_info_get": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ModelInfo)]),
+    "kmx_context_create": (ctypes.c_int, [_IP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "kmx_context_free": (None, [ctypes.c_void_p]),
+    "kmx_handle_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "kmx_handle_free": (None, [ctypes.c_void_p]),
+    "kmx_handle_precision": (ctypes.c_int, [ctypes.c_void_p]),
+    "kmx_eval": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _FPP, _FPP, _IP, _FP, _FPP, _FP, _FP, _FPP]),
+    "kmx_eval_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, _IP, _FP,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    "kmx_handle_stream": (ctypes.c_void_p, [ctypes.c_void_p]),
+    "kmx_handle_sync": (ctypes.c_int, [ctypes.c_void_p]),
+    "kmx_handle_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
+    "kmx_test_conv": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP]),
+    "kmx_test_bnact": (ctypes.c_int, [ctypes.POINTER(BnActDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP, _FP]),
+    "kmx_test_resblock": (ctypes.c_int, [ctypes.POINTER(ResBlockDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP, _FP]),
+    "kmx_test_gpoolblock": (ctypes.c_int, [ctypes.POINTER(GPoolBlockDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP, _FP]),
+}
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load libkatamx.so (built by katago_amd.build). Fails loudly if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise KatamxError(KMX_ERR_INTERNAL, "%s not found: run `python -m katago_amd.build` (the HIP extension is mandatory)" % p)
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(status, lib=None):
+    if status != KMX_OK:
+        lib = lib or load_library()
+        raise KatamxError(status, (lib.kmx_last_error() or b"").decode("utf-8", "replace"))

@@ -1,0 +1,669 @@
+// engine.cpp — see engine.h. Compiled with hipcc (host code only; kernels live in the .hip files).
+#include "engine.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace kmx {
+
+void hipCheck(hipError_t e, const char* what) {
+  if(e != hipSuccess) throw Error(KMX_ERR_DEVICE, std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
+}
+
+DevBuf::DevBuf(size_t bytes, bool zero) : p_(nullptr), bytes_(bytes) {
+  if(bytes == 0) return;
+  hipCheck(hipMalloc(&p_, bytes), "hipMalloc");
+  if(zero) hipCheck(hipMemset(p_, 0, bytes), "hipMemset");
+}
+DevBuf::~DevBuf() {
+  if(p_) (void)hipFree(p_);
+}
+DevBuf& DevBuf::operator=(DevBuf&& o) noexcept {
+  if(this != &o) {
+    if(p_) (void)hipFree(p_);
+    p_ = o.p_;
+    bytes_ = o.bytes_;
+    o.p_ = nullptr;
+    o.bytes_ = 0;
+  }
+  return *this;
+}
+void DevBuf::upload(const void* src, size_t bytes) {
+  if(bytes > bytes_) throw Error(KMX_ERR_INTERNAL, "DevBuf::upload overflow");
+  if(bytes) hipCheck(hipMemcpy(p_, src, bytes, hipMemcpyHostToDevice), "hipMemcpy H2D");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight re-tiling. Reference layouts: conv weights in the file are [ky][kx][ic][oc] (desc.cpp:130);
+// the kernel wants, per (chunk of 32 ic, tap), rows of one output channel: T[chunk][tap][oc][40].
+FusedConv buildFusedConv(int dtype, const std::vector<ConvSegment>& segs, std::vector<int>* segOffsets) {
+  if(segs.empty()) throw Error(KMX_ERR_INTERNAL, "buildFusedConv: no segments");
+  FusedConv fc;
+  const ConvDesc& first = *segs[0].conv;
+  fc.ks = first.ky;
+  fc.cin = first.inC;
+  if(first.ky != first.kx) throw Error(KMX_ERR_UNSUPPORTED, first.name + ": non-square convolution kernels are not supported");
+  if(fc.ks != 1 && fc.ks != 3 && fc.ks != 5)
+    throw Error(KMX_ERR_UNSUPPORTED, first.name + ": only 1x1, 3x3 and 5x5 convolutions are supported");
+  std::vector<int> offs;
+  int cout = 0;
+  for(const ConvSegment& s : segs) {
+    if(s.conv->ky != fc.ks || s.conv->kx != fc.ks || s.conv->inC != fc.cin)
+      throw Error(KMX_ERR_INTERNAL, "buildFusedConv: segments disagree on kernel size / input channels");
+    offs.push_back(cout);
+    cout += roundUp(s.conv->outC, 4);
+  }
+  fc.cout = cout;
+  fc.coutPad = roundUp(cout, 64);
+  fc.nChunks = (fc.cin + KCHUNK - 1) / KCHUNK;
+  const int nt = fc.ks * fc.ks;
+  std::vector<uint16_t> w((size_t)fc.nChunks * nt * fc.coutPad * WROW_HALFS, 0);
+  std::vector<float> scale(fc.coutPad, 0.0f), bias(fc.coutPad, 0.0f);
+  for(size_t si = 0; si < segs.size(); si++) {
+    const ConvDesc& c = *segs[si].conv;
+    fc.macPerCell += (double)c.ky * c.kx * c.inC * c.outC;
+    for(int chunk = 0; chunk < fc.nChunks; chunk++)
+      for(int t = 0; t < nt; t++) {
+        const int ky = t / fc.ks, kx = t % fc.ks;
+        for(int oc = 0; oc < c.outC; oc++) {
+          uint16_t* row = &w[(((size_t)chunk * nt + t) * fc.coutPad + offs[si] + oc) * WROW_HALFS];
+          for(int k = 0; k < KCHUNK; k++) {
+            const int ic = chunk * KCHUNK + k;
+            if(ic < c.inC) row[k] = floatToTBits(dtype, c.at(ky, kx, ic, oc));
+          }
+        }
+      }
+    if(segs[si].bn != nullptr) {
+      const BnDesc& bn = *segs[si].bn;
+      if(bn.c != c.outC) throw Error(KMX_ERR_INTERNAL, "buildFusedConv: bn/conv channel mismatch");
+      for(int oc = 0; oc < c.outC; oc++) {
+        scale[offs[si] + oc] = bn.scale[oc];
+        bias[offs[si] + oc] = bn.bias[oc];
+      }
+    }
+  }
+  fc.w = DevBuf(w.size() * sizeof(uint16_t), false);
+  fc.w.upload(w.data(), w.size() * sizeof(uint16_t));
+  fc.scale = DevBuf(scale.size() * sizeof(float), false);
+  fc.scale.upload(scale.data(), scale.size() * sizeof(float));
+  fc.bias = DevBuf(bias.size() * sizeof(float), false);
+  fc.bias.upload(bias.data(), bias.size() * sizeof(float));
+  if(segOffsets) *segOffsets = offs;
+  return fc;
+}
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+void scanStack(const std::vector<BlockDesc>& blocks, int depth, std::vector<int>& levelStride, int& tmpStride, int& gStride) {
+  for(const BlockDesc& b : blocks) {
+    if(b.kind == BlockKind::Ordinary) tmpStride = std::max(tmpStride, roundUp(b.regularConv.outC, 32));
+    else if(b.kind == BlockKind::GPool) {
+      tmpStride = std::max(tmpStride, roundUp(b.regularConv.outC, 32));
+      gStride = std::max(gStride, roundUp(b.gpoolConv.outC, 32));
+    }
+    else {
+      if((int)levelStride.size() <= depth + 1) levelStride.resize(depth + 2, 0);
+      levelStride[depth + 1] = std::max(levelStride[depth + 1], roundUp(b.regularConv.outC, 32));
+      scanStack(b.inner, depth + 1, levelStride, tmpStride, gStride);
+    }
+  }
+}
+
+}  // namespace
+
+Engine::Engine(const ModelDesc& model, int nnXLen, int nnYLen, int maxBatch, int dtype, int device)
+  : dtype_(dtype), device_(device), X_(nnXLen), Y_(nnYLen), S_(nnXLen * nnYLen), maxBatch_(maxBatch), stream_(nullptr) {
+  if(nnXLen < 2 || nnYLen < 2 || nnXLen > 19 || nnYLen > 19)
+    throw Error(KMX_ERR_INVALID_ARG, "nnXLen/nnYLen must be in 2..19");
+  if(maxBatch < 1 || maxBatch > 65535) throw Error(KMX_ERR_INVALID_ARG, "maxBatchSize must be in 1..65535");
+  if(dtype != DT_F16 && dtype != DT_BF16) throw Error(KMX_ERR_UNSUPPORTED, "unsupported device precision");
+  hipCheck(hipSetDevice(device_), "hipSetDevice");
+  hipCheck(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+  cin_ = model.numInputChannels;
+  gin_ = model.numInputGlobalChannels;
+  const size_t NS = (size_t)maxBatch_ * S_;
+  zeroPage_ = DevBuf(4096);
+  inputT_ = DevBuf(NS * KCHUNK * 2);
+  mask_ = DevBuf(NS * sizeof(float));
+  maskSum_ = DevBuf((size_t)maxBatch_ * sizeof(float));
+  ncBias_ = DevBuf((size_t)maxBatch_ * roundUp(model.trunkC, 64) * sizeof(float));
+  dSymmetry_ = DevBuf((size_t)maxBatch_ * sizeof(int));
+  dOptimism_ = DevBuf((size_t)maxBatch_ * sizeof(float));
+  dSpatialIn_ = DevBuf(NS * cin_ * sizeof(float));
+  dGlobalIn_ = DevBuf((size_t)maxBatch_ * gin_ * sizeof(float));
+  dPolicy_ = DevBuf((size_t)maxBatch_ * (S_ + 1) * sizeof(float));
+  dValue_ = DevBuf((size_t)maxBatch_ * 3 * sizeof(float));
+  dScore_ = DevBuf((size_t)maxBatch_ * 6 * sizeof(float));
+  dOwnership_ = DevBuf(NS * sizeof(float));
+  hipCheck(hipHostMalloc((void**)&hSpatial_, NS * cin_ * sizeof(float)), "hipHostMalloc");
+  hipCheck(hipHostMalloc((void**)&hGlobal_, (size_t)maxBatch_ * gin_ * sizeof(float)), "hipHostMalloc");
+  hipCheck(hipHostMalloc((void**)&hPolicy_, (size_t)maxBatch_ * (S_ + 1) * sizeof(float)), "hipHostMalloc");
+  hipCheck(hipHostMalloc((void**)&hValue_, (size_t)maxBatch_ * 3 * sizeof(float)), "hipHostMalloc");
+  hipCheck(hipHostMalloc((void**)&hScore_, (size_t)maxBatch_ * 6 * sizeof(float)), "hipHostMalloc");
+  hipCheck(hipHostMalloc((void**)&hOwnership_, NS * sizeof(float)), "hipHostMalloc");
+  hipCheck(hipHostMalloc((void**)&hSymmetry_, (size_t)maxBatch_ * sizeof(int)), "hipHostMalloc");
+  hipCheck(hipHostMalloc((void**)&hOptimism_, (size_t)maxBatch_ * sizeof(float)), "hipHostMalloc");
+  buildSchedule(model);
+  hipCheck(hipStreamSynchronize(stream_), "sync after build");
+}
+
+Engine::~Engine() {
+  if(stream_) (void)hipStreamSynchronize(stream_);
+  (void)hipHostFree(hSpatial_);
+  (void)hipHostFree(hGlobal_);
+  (void)hipHostFree(hPolicy_);
+  (void)hipHostFree(hValue_);
+  (void)hipHostFree(hScore_);
+  (void)hipHostFree(hOwnership_);
+  (void)hipHostFree(hSymmetry_);
+  (void)hipHostFree(hOptimism_);
+  if(stream_) (void)hipStreamDestroy(stream_);
+}
+
+float* Engine::uploadFloats(const std::vector<float>& v) {
+  std::unique_ptr<DevBuf> b(new DevBuf(std::max<size_t>(v.size(), 1) * sizeof(float), true));
+  b->upload(v.data(), v.size() * sizeof(float));
+  float* p = b->as<float>();
+  params_.push_back(std::move(b));
+  return p;
+}
+const FusedConv* Engine::newConv(const std::vector<ConvSegment>& segs, std::vector<int>* offs) {
+  convs_.emplace_back(new FusedConv(buildFusedConv(dtype_, segs, offs)));
+  return convs_.back().get();
+}
+
+void Engine::addConv(const FusedConv* fc, const void* in, int inStride, const float* ncBias, int ncBiasStride,
+                     const void* resid, int residStride, void* rawOut, int rawStride, int rawBegin, int rawEnd,
+                     void* actOut, int actStride, int actBegin, int actEnd, int actKind) {
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = in;
+  a.w = fc->w.get();
+  a.zeroPage = zeroPage_.get();
+  a.inC = inStride;
+  a.nChunks = fc->nChunks;
+  a.coutPad = fc->coutPad;
+  a.X = X_;
+  a.Y = Y_;
+  a.ncBias = ncBias;
+  a.ncBiasStride = ncBiasStride;
+  a.resid = resid;
+  a.residC = residStride;
+  a.rawOut = rawOut;
+  a.rawC = rawStride;
+  a.rawBegin = rawBegin;
+  a.rawEnd = std::min(rawEnd, rawBegin + rawStride);  // never write past the channel stride of the destination
+  a.actOut = actOut;
+  a.actC = actStride;
+  a.actBegin = actBegin;
+  a.actEnd = std::min(actEnd, actBegin + actStride);
+  a.scale = fc->scale.as<float>();
+  a.bias = fc->bias.as<float>();
+  a.actKind = actKind;
+  a.mask = mask_.as<float>();
+  if(inStride < fc->nChunks * KCHUNK) throw Error(KMX_ERR_INTERNAL, "addConv: input stride smaller than the padded channel count");
+  const int dtype = dtype_, ks = fc->ks, coutPad = fc->coutPad;
+  ops_.push_back([=](int n, hipStream_t st) {
+    ConvArgs b = a;
+    b.N = n;
+    hipCheck(launchConv(dtype, ks, chooseConvWN(ks, coutPad, n), b, st), "convolution launch");
+  });
+}
+
+void Engine::buildStack(const std::vector<BlockDesc>& blocks, const Stream& s, const BnDesc* bnAfter, int depth) {
+  for(size_t i = 0; i < blocks.size(); i++) {
+    const BlockDesc& b = blocks[i];
+    const BnDesc* nextBN = i + 1 < blocks.size() ? &blocks[i + 1].preBN : bnAfter;
+      if(b.kind == BlockKind::Ordinary) {
+      // mid = act(midBN(conv1(s.act)));  s.raw += conv2(mid);  s.act = act(nextBN(s.raw))   (eigenbackend.cpp:1139-1145)
+      const FusedConv* c1 = newConv({{&b.regularConv, &b.midBN}});
+      const FusedConv* c2 = newConv({{&b.finalConv, nextBN}});
+      void* tmp = acts_[0]->get();
+      const int tmpStride = roundUp(b.regularConv.outC, 32);
+      addConv(c1, s.act, s.stride, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, tmp, tmpStride, 0, c1->coutPad, b.midBN.act);
+      addConv(c2, tmp, tmpStride, nullptr, 0, s.raw, s.stride, s.raw, s.stride, 0, c2->coutPad, s.act, s.stride, 0,
+              c2->coutPad, nextBN->act);
+    }
+    else if(b.kind == BlockKind::GPool) {
+      // r = convR(s.act); g = act(gpoolBN(convG(s.act))); r += W*pool(g); s.raw += conv2(act(midBN(r)))  (eigenbackend.cpp:1204-1220)
+      std::vector<int> offs;
+      const FusedConv* c1 = newConv({{&b.regularConv, nullptr}, {&b.gpoolConv, &b.gpoolBN}}, &offs);
+      const FusedConv* c2 = newConv({{&b.finalConv, nextBN}});
+      const int R = b.regularConv.outC, G = b.gpoolConv.outC;
+      const int rStride = roundUp(R, 32), gStride = roundUp(G, 32);
+      void* tmpR = acts_[0]->get();
+      void* tmpG = acts_[1]->get();
+      addConv(c1, s.act, s.stride, nullptr, 0, nullptr, 0, tmpR, rStride, 0, offs[1], tmpG, gStride, offs[1], c1->coutPad,
+              b.gpoolBN.act);
+      GPoolArgs ga;
+      memset(&ga, 0, sizeof(ga));
+      ga.g = tmpG; ga.gStride = gStride; ga.gOffset = 0; ga.G = G;
+      ga.r = tmpR; ga.rStride = rStride; ga.rOffset = 0; ga.R = R;
+      ga.w = uploadFloats(b.gpoolToBiasMul.w);
+      ga.scale = uploadFloats(b.midBN.scale);
+      ga.bias = uploadFloats(b.midBN.bias);
+      ga.actKind = b.midBN.act;
+      ga.mask = mask_.as<float>();
+      ga.maskSum = maskSum_.as<float>();
+      ga.featOut = nullptr;
+      ga.S = S_;
+      const int dtype = dtype_;
+      ops_.push_back([=](int n, hipStream_t st) {
+        GPoolArgs x = ga;
+        x.N = n;
+        hipCheck(launchGPoolApply(dtype, x, st), "gpool launch");
+      });
+      addConv(c2, tmpR, rStride, nullptr, 0, s.raw, s.stride, s.raw, s.stride, 0, c2->coutPad, s.act, s.stride, 0,
+              c2->coutPad, nextBN->act);
+    }
+    else {
+      // mid = conv1x1(s.act); inner stack on mid; s.raw += conv1x1(act(postBN(mid)))   (eigenbackend.cpp:1308-1314)
+      const int M = b.regularConv.outC;
+      Stream mid;
+      mid.raw = acts_[2 + 2 * (depth + 1)]->get();
+      mid.act = acts_[3 + 2 * (depth + 1)]->get();
+      mid.stride = roundUp(M, 32);
+      const BnDesc* firstInnerBN = &b.inner[0].preBN;
+      const FusedConv* pre = newConv({{&b.regularConv, firstInnerBN}});
+      addConv(pre, s.act, s.stride, nullptr, 0, nullptr, 0, mid.raw, mid.stride, 0, pre->coutPad, mid.act, mid.stride, 0,
+              pre->coutPad, firstInnerBN->act);
+      buildStack(b.inner, mid, &b.midBN, depth + 1);
+      const FusedConv* post = newConv({{&b.finalConv, nextBN}});
+      addConv(post, mid.act, mid.stride, nullptr, 0, s.raw, s.stride, s.raw, s.stride, 0, post->coutPad, s.act, s.stride, 0,
+              post->coutPad, nextBN->act);
+    }
+  }
+}
+
+void Engine::buildSchedule(const ModelDesc& m) {
+  const size_t NS = (size_t)maxBatch_ * S_;
+  // ---- activation buffers: [0] tmp, [1] gpool tmp, then (raw, act) per nesting depth ----
+  std::vector<int> levelStride(1, roundUp(m.trunkC, 32));
+  int tmpStride = 32, gStride = 32;
+  scanStack(m.blocks, 0, levelStride, tmpStride, gStride);
+  acts_.emplace_back(new DevBuf(NS * tmpStride * 2));
+  acts_.emplace_back(new DevBuf(NS * gStride * 2));
+  for(size_t d = 0; d < levelStride.size(); d++) {
+    acts_.emplace_back(new DevBuf(NS * std::max(levelStride[d], 32) * 2));
+    acts_.emplace_back(new DevBuf(NS * std::max(levelStride[d], 32) * 2));
+  }
+  Stream trunk;
+  trunk.raw = acts_[2]->get();
+  trunk.act = acts_[3]->get();
+  trunk.stride = roundUp(m.trunkC, 32);
+
+  // ---- input staging ----
+  {
+    InputArgs ia;
+    memset(&ia, 0, sizeof(ia));
+    ia.cin = cin_;
+    ia.gin = gin_;
+    ia.X = X_;
+    ia.Y = Y_;
+    ia.out = inputT_.get();
+    ia.mask = mask_.as<float>();
+    ia.maskSum = maskSum_.as<float>();
+    ia.wGlobal = uploadFloats(m.initialMatMul.w);
+    ia.ncBias = ncBias_.as<float>();
+    ia.C = m.trunkC;
+    ia.ncStride = roundUp(m.trunkC, 64);
+    ia.symmetry = dSymmetry_.as<int>();
+    const int dtype = dtype_;
+    ops_.push_back([=](int n, hipStream_t st) {
+      InputArgs x = ia;
+      x.N = n;
+      x.spatial = curSpatial_;
+      x.global = curGlobal_;
+      hipCheck(launchInputExpand(dtype, x, st), "input staging launch");
+    });
+  }
+  // ---- trunk (Trunk::apply, eigenbackend.cpp:1909-1947) ----
+  const BnDesc* firstBN = &m.blocks[0].preBN;
+  const FusedConv* stem = newConv({{&m.initialConv, firstBN}});
+  addConv(stem, inputT_.get(), KCHUNK, ncBias_.as<float>(), roundUp(m.trunkC, 64), nullptr, 0, trunk.raw, trunk.stride, 0,
+          stem->coutPad, trunk.act, trunk.stride, 0, stem->coutPad, firstBN->act);
+  buildStack(m.blocks, trunk, &m.trunkTipBN, 0);
+
+  // ---- heads: one 1x1 conv for p1 (raw), g1 (BN+act), v1 (BN+act) ----
+  const bool fuseV = m.g1BN.act == m.v1BN.act;
+  std::vector<int> offs;
+  std::vector<ConvSegment> segs = {{&m.p1Conv, nullptr}, {&m.g1Conv, &m.g1BN}};
+  if(fuseV) segs.push_back({&m.v1Conv, &m.v1BN});
+  const FusedConv* heads = newConv(segs, &offs);
+  const int P1 = m.p1Conv.outC, G1 = m.g1Conv.outC, V1 = m.v1Conv.outC;
+  const int headRawStride = roundUp(P1, 32);
+  const int headActC = heads->cout - offs[1];
+  const int headActStride = roundUp(headActC, 32);
+  acts_.emplace_back(new DevBuf(NS * headRawStride * 2));
+  void* headRaw = acts_.back()->get();
+  acts_.emplace_back(new DevBuf(NS * headActStride * 2));
+  void* headAct = acts_.back()->get();
+  addConv(heads, trunk.act, trunk.stride, nullptr, 0, nullptr, 0, headRaw, headRawStride, 0, offs[1], headAct, headActStride,
+          offs[1], heads->cout, m.g1BN.act);
+  void* vAct = headAct;
+  int vStride = headActStride, vOffset = fuseV ? offs[2] - offs[1] : 0;
+  if(!fuseV) {
+    const FusedConv* vconv = newConv({{&m.v1Conv, &m.v1BN}});
+    vStride = roundUp(V1, 32);
+    acts_.emplace_back(new DevBuf(NS * vStride * 2));
+    vAct = acts_.back()->get();
+    addConv(vconv, trunk.act, trunk.stride, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, vAct, vStride, 0, vconv->coutPad, m.v1BN.act);
+  }
+  polFeat_ = DevBuf((size_t)maxBatch_ * 3 * G1 * sizeof(float));
+  {
+    GPoolArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.g = headAct; ga.gStride = headActStride; ga.gOffset = 0; ga.G = G1;
+    ga.r = headRaw; ga.rStride = headRawStride; ga.rOffset = 0; ga.R = P1;
+    ga.w = uploadFloats(m.gpoolToBiasMul.w);
+    ga.scale = uploadFloats(m.p1BN.scale);
+    ga.bias = uploadFloats(m.p1BN.bias);
+    ga.actKind = m.p1BN.act;
+    ga.mask = mask_.as<float>();
+    ga.maskSum = maskSum_.as<float>();
+    ga.featOut = polFeat_.as<float>();
+    ga.S = S_;
+    const int dtype = dtype_;
+    ops_.push_back([=](int n, hipStream_t st) {
+      GPoolArgs x = ga;
+      x.N = n;
+      hipCheck(launchGPoolApply(dtype, x, st), "policy gpool launch");
+    });
+  }
+  {
+    PolicyArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.p = headRaw; pa.pStride = headRawStride; pa.pOffset = 0; pa.P = P1;
+    pa.w2 = uploadFloats(m.p2Conv.w);
+    pa.NP = m.numPolicyChannels;
+    pa.feat = polFeat_.as<float>();
+    pa.G3 = 3 * G1;
+    pa.wPass = uploadFloats(m.gpoolToPassMul.w);
+    if(m.hasPassMLP) {
+      pa.bPass = uploadFloats(m.gpoolToPassBias.w);
+      pa.wPass2 = uploadFloats(m.gpoolToPassMul2.w);
+      pa.passHidden = m.gpoolToPassMul.outC;
+      pa.passAct = m.passAct;
+    }
+    pa.symmetry = dSymmetry_.as<int>();
+    pa.optimism = dOptimism_.as<float>();
+    pa.X = X_;
+    pa.Y = Y_;
+    const int dtype = dtype_;
+    ops_.push_back([=](int n, hipStream_t st) {
+      PolicyArgs x = pa;
+      x.N = n;
+      x.out = curPolicy_;
+      hipCheck(launchPolicyFinal(dtype, x, st), "policy tail launch");
+    });
+  }
+  {
+    ValueArgs va;
+    memset(&va, 0, sizeof(va));
+    va.v = vAct; va.vStride = vStride; va.vOffset = vOffset; va.V1 = V1;
+    va.w2 = uploadFloats(m.v2Mul.w);
+    va.b2 = uploadFloats(m.v2Bias.w);
+    va.V2 = m.v2Mul.outC;
+    va.v2Act = m.v2Act;
+    va.w3 = uploadFloats(m.v3Mul.w);
+    va.b3 = uploadFloats(m.v3Bias.w);
+    va.wsv = uploadFloats(m.sv3Mul.w);
+    va.bsv = uploadFloats(m.sv3Bias.w);
+    va.NSV = m.numScoreValueChannels;
+    va.wOwn = uploadFloats(m.vOwnershipConv.w);
+    va.maskSum = maskSum_.as<float>();
+    va.symmetry = dSymmetry_.as<int>();
+    va.X = X_;
+    va.Y = Y_;
+    const int dtype = dtype_;
+    ops_.push_back([=](int n, hipStream_t st) {
+      ValueArgs x = va;
+      x.N = n;
+      x.value = curValue_;
+      x.score = curScore_;
+      x.ownership = curOwnership_;
+      hipCheck(launchValueFinal(dtype, x, st), "value tail launch");
+    });
+  }
+}
+
+void Engine::runSchedule(int n, const float* dSpatial, const float* dGlobal, float* dPolicy, float* dValue, float* dScore,
+                         float* dOwnership) {
+  curSpatial_ = dSpatial;
+  curGlobal_ = dGlobal;
+  curPolicy_ = dPolicy;
+  curValue_ = dValue;
+  curScore_ = dScore;
+  curOwnership_ = dOwnership;
+  for(const Op& op : ops_) op(n, stream_);
+}
+
+void Engine::sync() { hipCheck(hipStreamSynchronize(stream_), "stream synchronize"); }
+
+void Engine::evalDevice(int n, const float* dSpatial, const float* dGlobal, const int* symmetry, const float* policyOptimism,
+                        float* dPolicy, float* dValue, float* dScore, float* dOwnership, bool doSync) {
+  if(n < 1 || n > maxBatch_) throw Error(KMX_ERR_INVALID_ARG, "batch size out of range for this handle");
+  hipCheck(hipSetDevice(device_), "hipSetDevice");
+  // the pinned staging of the previous call must have been consumed before it is overwritten
+  hipCheck(hipStreamSynchronize(stream_), "stream synchronize");
+  for(int i = 0; i < n; i++) {
+    hSymmetry_[i] = symmetry ? symmetry[i] : 0;
+    hOptimism_[i] = policyOptimism ? policyOptimism[i] : 0.0f;
+  }
+  hipCheck(hipMemcpyAsync(dSymmetry_.get(), hSymmetry_, n * sizeof(int), hipMemcpyHostToDevice, stream_), "H2D symmetry");
+  hipCheck(hipMemcpyAsync(dOptimism_.get(), hOptimism_, n * sizeof(float), hipMemcpyHostToDevice, stream_), "H2D optimism");
+  runSchedule(n, dSpatial, dGlobal, dPolicy, dValue, dScore, dOwnership);
+  rows_ += (uint64_t)n;
+  batches_ += 1;
+  if(doSync) sync();
+}
+
+void Engine::evalHost(int n, const float* const* rowSpatial, const float* const* rowGlobal, const int* symmetry,
+                      const float* policyOptimism, float* const* outPolicy, float* outValue, float* outScore,
+                      float* const* outOwnership) {
+  if(n < 1 || n > maxBatch_) throw Error(KMX_ERR_INVALID_ARG, "batch size out of range for this handle");
+  hipCheck(hipSetDevice(device_), "hipSetDevice");
+  hipCheck(hipStreamSynchronize(stream_), "stream synchronize");
+  const size_t rowElts = (size_t)S_ * cin_;
+  for(int i = 0; i < n; i++) {
+    memcpy(hSpatial_ + i * rowElts, rowSpatial[i], rowElts * sizeof(float));
+    memcpy(hGlobal_ + (size_t)i * gin_, rowGlobal[i], gin_ * sizeof(float));
+  }
+  hipCheck(hipMemcpyAsync(dSpatialIn_.get(), hSpatial_, n * rowElts * sizeof(float), hipMemcpyHostToDevice, stream_), "H2D spatial");
+  hipCheck(hipMemcpyAsync(dGlobalIn_.get(), hGlobal_, (size_t)n * gin_ * sizeof(float), hipMemcpyHostToDevice, stream_), "H2D global");
+  bool anyOwner = false;
+  if(outOwnership)
+    for(int i = 0; i < n; i++) anyOwner = anyOwner || outOwnership[i] != nullptr;
+  // evalDevice synchronises the stream first, which is harmless here (the copies above are already queued on it)
+  for(int i = 0; i < n; i++) {
+    hSymmetry_[i] = symmetry ? symmetry[i] : 0;
+    hOptimism_[i] = policyOptimism ? policyOptimism[i] : 0.0f;
+  }
+  hipCheck(hipMemcpyAsync(dSymmetry_.get(), hSymmetry_, n * sizeof(int), hipMemcpyHostToDevice, stream_), "H2D symmetry");
+  hipCheck(hipMemcpyAsync(dOptimism_.get(), hOptimism_, n * sizeof(float), hipMemcpyHostToDevice, stream_), "H2D optimism");
+  runSchedule(n, dSpatialIn_.as<float>(), dGlobalIn_.as<float>(), dPolicy_.as<float>(), dValue_.as<float>(),
+              dScore_.as<float>(), anyOwner ? dOwnership_.as<float>() : nullptr);
+  hipCheck(hipMemcpyAsync(hPolicy_, dPolicy_.get(), (size_t)n * (S_ + 1) * sizeof(float), hipMemcpyDeviceToHost, stream_), "D2H policy");
+  hipCheck(hipMemcpyAsync(hValue_, dValue_.get(), (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_), "D2H value");
+  hipCheck(hipMemcpyAsync(hScore_, dScore_.get(), (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost, stream_), "D2H score");
+  if(anyOwner)
+    hipCheck(hipMemcpyAsync(hOwnership_, dOwnership_.get(), (size_t)n * S_ * sizeof(float), hipMemcpyDeviceToHost, stream_), "D2H ownership");
+  sync();
+  for(int i = 0; i < n; i++) {
+    memcpy(outPolicy[i], hPolicy_ + (size_t)i * (S_ + 1), (S_ + 1) * sizeof(float));
+    if(anyOwner && outOwnership[i]) memcpy(outOwnership[i], hOwnership_ + (size_t)i * S_, S_ * sizeof(float));
+  }
+  memcpy(outValue, hValue_, (size_t)n * 3 * sizeof(float));
+  memcpy(outScore, hScore_, (size_t)n * 6 * sizeof(float));
+  rows_ += (uint64_t)n;
+  batches_ += 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Layer test hooks. Small one-shot runs on the default device with the production kernels.
+namespace {
+
+struct HookCtx {
+  int dtype, N, X, Y, S;
+  hipStream_t st;
+  DevBuf zero, mask;
+  HookCtx(int dt, int n, int x, int y, const float* hostMask) : dtype(dt), N(n), X(x), Y(y), S(x * y), st(nullptr) {
+    if(x < 2 || y < 2 || x > 19 || y > 19 || n < 1) throw Error(KMX_ERR_INVALID_ARG, "test hook: bad sizes");
+    zero = DevBuf(4096);
+    std::vector<float> ones((size_t)n * S, 1.0f);
+    mask = DevBuf((size_t)n * S * sizeof(float), false);
+    mask.upload(hostMask ? hostMask : ones.data(), (size_t)n * S * sizeof(float));
+  }
+  // fp32 host NHWC [N][S][C] -> device T [N][S][round32(C)]
+  DevBuf toDevice(const float* host, int C, int* stride) {
+    const size_t cells = (size_t)N * S;
+    DevBuf f(cells * C * sizeof(float), false);
+    f.upload(host, cells * C * sizeof(float));
+    *stride = roundUp(C, 32);
+    DevBuf t(cells * (*stride) * 2);
+    hipCheck(launchFloatToT(dtype, f.as<float>(), C, t.get(), *stride, cells, st), "floatToT");
+    hipCheck(hipStreamSynchronize(st), "sync");
+    return t;
+  }
+  void toHost(const DevBuf& t, int stride, int C, float* host) {
+    const size_t cells = (size_t)N * S;
+    DevBuf f(cells * C * sizeof(float), false);
+    hipCheck(launchTToFloat(dtype, t.get(), stride, 0, f.as<float>(), C, cells, st), "tToFloat");
+    hipCheck(hipStreamSynchronize(st), "sync");
+    hipCheck(hipMemcpy(host, f.get(), cells * C * sizeof(float), hipMemcpyDeviceToHost), "D2H");
+  }
+  void conv(const FusedConv& fc, const void* in, int inStride, const void* resid, int residStride, void* rawOut, int rawStride,
+            int rawBegin, int rawEnd, void* actOut, int actStride, int actBegin, int actEnd, int actKind) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.w = fc.w.get(); a.zeroPage = zero.get(); a.inC = inStride; a.nChunks = fc.nChunks; a.coutPad = fc.coutPad;
+    a.N = N; a.X = X; a.Y = Y;
+    a.resid = resid; a.residC = residStride;
+    a.rawOut = rawOut; a.rawC = rawStride; a.rawBegin = rawBegin; a.rawEnd = std::min(rawEnd, rawBegin + rawStride);
+    a.actOut = actOut; a.actC = actStride; a.actBegin = actBegin; a.actEnd = std::min(actEnd, actBegin + actStride);
+    a.scale = fc.scale.as<float>(); a.bias = fc.bias.as<float>(); a.actKind = actKind;
+    a.mask = mask.as<float>();
+    hipCheck(launchConv(dtype, fc.ks, chooseConvWN(fc.ks, fc.coutPad, N), a, st), "test conv launch");
+  }
+};
+
+ConvDesc convFromAbi(const kmx_conv_desc* d) {  // [oc][ic][ky][kx] -> file order [ky][kx][ic][oc]
+  if(!d || !d->weights) throw Error(KMX_ERR_INVALID_ARG, "null conv desc");
+  ConvDesc c;
+  c.name = "testconv";
+  c.ky = d->conv_y_size; c.kx = d->conv_x_size; c.inC = d->in_channels; c.outC = d->out_channels;
+  if(c.ky < 1 || c.kx < 1 || c.inC < 1 || c.outC < 1) throw Error(KMX_ERR_INVALID_ARG, "bad conv desc");
+  c.w.resize((size_t)c.ky * c.kx * c.inC * c.outC);
+  for(int o = 0; o < c.outC; o++)
+    for(int i = 0; i < c.inC; i++)
+      for(int y = 0; y < c.ky; y++)
+        for(int x = 0; x < c.kx; x++)
+          c.w[(((size_t)y * c.kx + x) * c.inC + i) * c.outC + o] = d->weights[(((size_t)o * c.inC + i) * c.ky + y) * c.kx + x];
+  return c;
+}
+BnDesc bnFromAbi(const kmx_bnact_desc* d) {
+  if(!d || !d->merged_scale || !d->merged_bias) throw Error(KMX_ERR_INVALID_ARG, "null bn desc");
+  BnDesc b;
+  b.name = "testbn";
+  b.c = d->num_channels;
+  b.act = d->activation;
+  b.scale.assign(d->merged_scale, d->merged_scale + b.c);
+  b.bias.assign(d->merged_bias, d->merged_bias + b.c);
+  return b;
+}
+DevBuf uploadVec(const std::vector<float>& v) {
+  DevBuf b(std::max<size_t>(v.size(), 1) * sizeof(float));
+  b.upload(v.data(), v.size() * sizeof(float));
+  return b;
+}
+void runBnAct(HookCtx& h, const BnDesc& bn, const DevBuf& in, DevBuf& out, int stride) {
+  DevBuf sc = uploadVec(bn.scale), bi = uploadVec(bn.bias);
+  BnActArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = in.get(); a.out = out.get(); a.stride = stride; a.C = bn.c;
+  a.scale = sc.as<float>(); a.bias = bi.as<float>(); a.actKind = bn.act; a.mask = h.mask.as<float>();
+  a.N = h.N; a.S = h.S;
+  hipCheck(launchBnAct(h.dtype, a, h.st), "bnact launch");
+  hipCheck(hipStreamSynchronize(h.st), "sync");
+}
+
+}  // namespace
+
+void testConv(int dtype, const kmx_conv_desc* d, int batch, int X, int Y, const float* in, float* out) {
+  HookCtx h(dtype, batch, X, Y, nullptr);
+  ConvDesc c = convFromAbi(d);
+  FusedConv fc = buildFusedConv(dtype, {{&c, nullptr}}, nullptr);
+  int inStride, outStride = roundUp(c.outC, 32);
+  DevBuf x = h.toDevice(in, c.inC, &inStride);
+  DevBuf y((size_t)batch * h.S * outStride * 2);
+  h.conv(fc, x.get(), inStride, nullptr, 0, y.get(), outStride, 0, roundUp(c.outC, 4), nullptr, 0, 0, 0, KMX_ACT_IDENTITY);
+  h.toHost(y, outStride, c.outC, out);
+}
+
+void testBnAct(int dtype, const kmx_bnact_desc* d, int batch, int X, int Y, const float* in, const float* mask, float* out) {
+  HookCtx h(dtype, batch, X, Y, mask);
+  BnDesc bn = bnFromAbi(d);
+  int stride;
+  DevBuf x = h.toDevice(in, bn.c, &stride);
+  runBnAct(h, bn, x, x, stride);
+  h.toHost(x, stride, bn.c, out);
+}
+
+void testResBlock(int dtype, const kmx_resblock_desc* d, int batch, int X, int Y, const float* in, const float* mask, float* out) {
+  if(!d) throw Error(KMX_ERR_INVALID_ARG, "null resblock desc");
+  HookCtx h(dtype, batch, X, Y, mask);
+  BnDesc preBN = bnFromAbi(&d->pre_bn), midBN = bnFromAbi(&d->mid_bn);
+  ConvDesc c1 = convFromAbi(&d->regular_conv), c2 = convFromAbi(&d->final_conv);
+  FusedConv f1 = buildFusedConv(dtype, {{&c1, &midBN}}, nullptr);
+  FusedConv f2 = buildFusedConv(dtype, {{&c2, nullptr}}, nullptr);
+  const int C = preBN.c;
+  int stride;
+  DevBuf raw = h.toDevice(in, C, &stride);
+  DevBuf act((size_t)batch * h.S * stride * 2);
+  runBnAct(h, preBN, raw, act, stride);
+  const int midStride = roundUp(c1.outC, 32);
+  DevBuf mid((size_t)batch * h.S * midStride * 2);
+  h.conv(f1, act.get(), stride, nullptr, 0, nullptr, 0, 0, 0, mid.get(), midStride, 0, f1.coutPad, midBN.act);
+  h.conv(f2, mid.get(), midStride, raw.get(), stride, raw.get(), stride, 0, roundUp(C, 4), nullptr, 0, 0, 0, KMX_ACT_IDENTITY);
+  h.toHost(raw, stride, C, out);
+}
+
+void testGPoolBlock(int dtype, const kmx_gpoolblock_desc* d, int batch, int X, int Y, const float* in, const float* mask,
+                    float* out) {
+  if(!d) throw Error(KMX_ERR_INVALID_ARG, "null gpoolblock desc");
+  if(!d->gpool_to_bias_mul.weights) throw Error(KMX_ERR_INVALID_ARG, "null matmul desc");
+  HookCtx h(dtype, batch, X, Y, mask);
+  BnDesc preBN = bnFromAbi(&d->pre_bn), gBN = bnFromAbi(&d->gpool_bn), midBN = bnFromAbi(&d->mid_bn);
+  ConvDesc cr = convFromAbi(&d->regular_conv), cg = convFromAbi(&d->gpool_conv), c2 = convFromAbi(&d->final_conv);
+  std::vector<int> offs;
+  FusedConv f1 = buildFusedConv(dtype, {{&cr, nullptr}, {&cg, &gBN}}, &offs);
+  FusedConv f2 = buildFusedConv(dtype, {{&c2, nullptr}}, nullptr);
+  const int C = preBN.c, R = cr.outC, G = cg.outC;
+  int stride;
+  DevBuf raw = h.toDevice(in, C, &stride);
+  DevBuf act((size_t)batch * h.S * stride * 2);
+  runBnAct(h, preBN, raw, act, stride);
+  const int rStride = roundUp(R, 32), gStride = roundUp(G, 32);
+  DevBuf r((size_t)batch * h.S * rStride * 2), g((size_t)batch * h.S * gStride * 2);
+  h.conv(f1, act.get(), stride, nullptr, 0, r.get(), rStride, 0, offs[1], g.get(), gStride, offs[1], f1.coutPad, gBN.act);
+  // mask sums on the host (computeMaskSum, eigenbackend.cpp:124-134)
+  std::vector<float> ms(batch, 0.0f);
+  for(int b = 0; b < batch; b++)
+    for(int p = 0; p < h.S; p++) ms[b] += mask ? mask[(size_t)b * h.S + p] : 1.0f;
+  DevBuf dms = uploadVec(ms);
+  std::vector<float> wv(d->gpool_to_bias_mul.weights,
+                        d->gpool_to_bias_mul.weights + (size_t)d->gpool_to_bias_mul.in_channels * d->gpool_to_bias_mul.out_channels);
+  DevBuf w = uploadVec(wv), sc = uploadVec(midBN.scale), bi = uploadVec(midBN.bias);
+  GPoolArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  ga.g = g.get(); ga.gStride = gStride; ga.G = G;
+  ga.r = r.get(); ga.rStride = rStride; ga.R = R;
+  ga.w = w.as<float>(); ga.scale = sc.as<float>(); ga.bias = bi.as<float>(); ga.actKind = midBN.act;
+  ga.mask = h.mask.as<float>(); ga.maskSum = dms.as<float>(); ga.N = batch; ga.S = h.S;
+  hipCheck(launchGPoolApply(dtype, ga, h.st), "gpool launch");
+  h.conv(f2, r.get(), rStride, raw.get(), stride, raw.get(), stride, 0, roundUp(C, 4), nullptr, 0, 0, 0, KMX_ACT_IDENTITY);
+  h.toHost(raw, stride, C, out);
+}
+
+}  // namespace kmx

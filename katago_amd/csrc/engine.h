@@ -1,0 +1,154 @@
+// engine.h — per-GPU executor of one KataGo net: owns the device copy of the weights (re-tiled for the
+// MFMA kernel), the activation buffers for maxBatch boards, and the static launch schedule.
+//
+// One Engine == one reference ComputeHandle (+ its InputBuffers): cpp/neuralnet/nninterface.h:76-99.
+// The schedule it runs is Model::apply of the reference (eigenbackend.cpp:2162-2216) with every
+// BatchNorm/activation/mask/bias/residual fused into the epilogue of the producing convolution.
+#ifndef KMX_ENGINE_H_
+#define KMX_ENGINE_H_
+
+#include <hip/hip_runtime.h>
+
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/katamx.h"
+#include "kernels.h"
+#include "model_desc.h"
+
+namespace kmx {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+void hipCheck(hipError_t e, const char* what);
+
+// RAII device allocation
+class DevBuf {
+ public:
+  DevBuf() : p_(nullptr), bytes_(0) {}
+  explicit DevBuf(size_t bytes, bool zero = true);
+  ~DevBuf();
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p_(o.p_), bytes_(o.bytes_) { o.p_ = nullptr; o.bytes_ = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept;
+  void* get() const { return p_; }
+  template <class T> T* as() const { return (T*)p_; }
+  size_t bytes() const { return bytes_; }
+  void upload(const void* src, size_t bytes);
+
+ private:
+  void* p_;
+  size_t bytes_;
+};
+
+inline int roundUp(int x, int m) { return (x + m - 1) / m * m; }
+
+// Device-resident weights of one fused convolution (several reference convs concatenated along Cout).
+struct FusedConv {
+  int ks = 1;
+  int cin = 0;       // real input channels
+  int nChunks = 0;   // ceil(cin/32)
+  int cout = 0;      // channels in the fused output space (segments padded to multiples of 4)
+  int coutPad = 0;   // multiple of 64
+  DevBuf w;          // T[nChunks][ks*ks][coutPad][40]
+  DevBuf scale, bias;  // float[coutPad]; zero outside act segments
+  double macPerCell = 0;  // real MACs per board cell (for flop accounting)
+};
+struct ConvSegment {
+  const ConvDesc* conv;
+  const BnDesc* bn;  // null => raw segment
+};
+FusedConv buildFusedConv(int dtype, const std::vector<ConvSegment>& segs, std::vector<int>* segOffsets);
+
+class Engine {
+ public:
+  Engine(const ModelDesc& model, int nnXLen, int nnYLen, int maxBatch, int dtype, int device);
+  ~Engine();
+
+  int dtype() const { return dtype_; }
+  int maxBatch() const { return maxBatch_; }
+  int nnXLen() const { return X_; }
+  int nnYLen() const { return Y_; }
+  hipStream_t stream() const { return stream_; }
+  int device() const { return device_; }
+
+  // Host-buffer entry (kmx_eval). Synchronous.
+  void evalHost(int n, const float* const* rowSpatial, const float* const* rowGlobal, const int* symmetry,
+                const float* policyOptimism, float* const* outPolicy, float* outValue, float* outScore,
+                float* const* outOwnership);
+  // Device-buffer entry (kmx_eval_device).
+  void evalDevice(int n, const float* dSpatial, const float* dGlobal, const int* symmetry, const float* policyOptimism,
+                  float* dPolicy, float* dValue, float* dScore, float* dOwnership, bool sync);
+  void sync();
+
+  uint64_t rowsProcessed() const { return rows_; }
+  uint64_t batchesProcessed() const { return batches_; }
+  int numLaunchesPerEval() const { return (int)ops_.size(); }
+
+ private:
+  struct Stream {  // a residual stream: raw values and their next-BN-activated image
+    void* raw;
+    void* act;
+    int stride;
+  };
+  typedef std::function<void(int, hipStream_t)> Op;
+
+  void buildSchedule(const ModelDesc& m);
+  void buildStack(const std::vector<BlockDesc>& blocks, const Stream& s, const BnDesc* bnAfter, int depth);
+  void addConv(const FusedConv* fc, const void* in, int inStride, const float* ncBias, int ncBiasStride,
+               const void* resid, int residStride, void* rawOut, int rawStride, int rawBegin, int rawEnd, void* actOut,
+               int actStride, int actBegin, int actEnd, int actKind);
+  const FusedConv* newConv(const std::vector<ConvSegment>& segs, std::vector<int>* offs = nullptr);
+  float* uploadFloats(const std::vector<float>& v);
+  void runSchedule(int n, const float* dSpatial, const float* dGlobal, float* dPolicy, float* dValue, float* dScore,
+                   float* dOwnership);
+
+  int dtype_, device_, X_, Y_, S_, maxBatch_;
+  hipStream_t stream_;
+  std::vector<std::unique_ptr<FusedConv>> convs_;
+  std::vector<std::unique_ptr<DevBuf>> params_;  // small fp32 parameter arrays
+  std::vector<std::unique_ptr<DevBuf>> acts_;    // activation buffers
+  std::vector<Op> ops_;
+
+  DevBuf zeroPage_;
+  DevBuf inputT_, mask_, maskSum_, ncBias_;
+  DevBuf dSymmetry_, dOptimism_;
+  DevBuf dSpatialIn_, dGlobalIn_;  // staging for the host entry
+  DevBuf dPolicy_, dValue_, dScore_, dOwnership_, polFeat_;
+  // pinned host staging
+  float* hSpatial_ = nullptr;
+  float* hGlobal_ = nullptr;
+  float* hPolicy_ = nullptr;
+  float* hValue_ = nullptr;
+  float* hScore_ = nullptr;
+  float* hOwnership_ = nullptr;
+  int* hSymmetry_ = nullptr;
+  float* hOptimism_ = nullptr;
+  int cin_ = 0, gin_ = 0;
+
+  // pointers the ops read at run time (set by runSchedule)
+  const float* curSpatial_ = nullptr;
+  const float* curGlobal_ = nullptr;
+  float* curPolicy_ = nullptr;
+  float* curValue_ = nullptr;
+  float* curScore_ = nullptr;
+  float* curOwnership_ = nullptr;
+
+  uint64_t rows_ = 0, batches_ = 0;
+};
+
+// Layer test hooks (nninterface.h:134-180) executed with the same kernels as the full net.
+void testConv(int dtype, const kmx_conv_desc* d, int batch, int X, int Y, const float* in, float* out);
+void testBnAct(int dtype, const kmx_bnact_desc* d, int batch, int X, int Y, const float* in, const float* mask, float* out);
+void testResBlock(int dtype, const kmx_resblock_desc* d, int batch, int X, int Y, const float* in, const float* mask, float* out);
+void testGPoolBlock(int dtype, const kmx_gpoolblock_desc* d, int batch, int X, int Y, const float* in, const float* mask,
+                    float* out);
+
+}  // namespace kmx
+#endif

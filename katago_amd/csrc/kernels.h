@@ -1,0 +1,163 @@
+// kernels.h — launch interface of the gfx950 kernels (conv_mfma.hip, misc_kernels.hip).
+//
+// Data layout in HBM:
+//   activations : T[N][S][Cs]   "NHWC", S = nnY*nnX, Cs = channel stride, a multiple of 32;
+//                 channels beyond the real count are zero; cells off the board are zero.
+//   conv weights: T[chunk][tap][coutPad][40]  chunk = 32 input channels, tap = ky*KS+kx,
+//                 40 = 32 k-values + 8 pad halfs (80-byte rows: conflict-free ds_read_b128 and an
+//                 LDS image that is a plain linear copy for global_load_lds).
+//   T is fp16 or bf16 (KMX_PREC_FP16 / KMX_PREC_BF16); all accumulation and epilogue math is fp32.
+#ifndef KMX_KERNELS_H_
+#define KMX_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kmx {
+
+enum { DT_F16 = 0, DT_BF16 = 1 };
+
+constexpr int KCHUNK = 32;      // input channels per K chunk
+constexpr int WROW_HALFS = 40;  // halfs per weight/activation LDS row (32 + 8 pad)
+
+// One fused convolution: out = epilogue( conv(in, w) ).
+// Epilogue per output channel c in [0, coutPad) and board cell p:
+//   v = acc(p,c) + ncBias[n][c] (if ncBias) + resid[n][p][c - rawBegin] (if resid and c in raw range)
+//   raw range [rawBegin, rawEnd):  rawOut[n][p][c - rawBegin] = v
+//   act range [actBegin, actEnd):  actOut[n][p][c - actBegin] = act(v*scale[c] + bias[c]) * mask[n][p]
+// (reference ops fused here: BatchNormLayer::apply eigenbackend.cpp:739-762, addNCBiasInplace :137-148,
+//  the residual accumulate of ConvLayer::apply :659-686)
+struct ConvArgs {
+  const void* in;
+  const void* w;
+  const void* zeroPage;  // >= 64 bytes of zeros
+  int inC;               // channel stride of `in`
+  int nChunks;           // ceil(real Cin / 32)
+  int coutPad;           // multiple of 64
+  int N, X, Y;
+  const float* ncBias;
+  int ncBiasStride;
+  const void* resid;
+  int residC;
+  void* rawOut;
+  int rawC, rawBegin, rawEnd;
+  void* actOut;
+  int actC, actBegin, actEnd;
+  const float* scale;
+  const float* bias;
+  int actKind;
+  const float* mask;  // [N][S]
+};
+
+// KS in {1,3,5}; wn = output-channel tiles of 32 per wave (work-group covers 64*wn channels).
+// Returns hipSuccess or an error (unsupported combination -> hipErrorInvalidValue).
+hipError_t launchConv(int dtype, int ks, int wn, const ConvArgs& a, hipStream_t stream);
+// Allowed wn values for a given (ks, coutPad); picks the largest that divides coutPad/64 unless
+// the batch is too small to fill the chip.
+int chooseConvWN(int ks, int coutPad, int batch);
+
+// Input staging: fp32 NHWC rows (not symmetrised) -> T[N][S][32] symmetrised + mask + maskSum +
+// ncBias[n][C] = W_global^T * global[n]   (copyInputsWithSymmetry nninputs.cpp:529-597, Model::apply
+// eigenbackend.cpp:2181-2182, initialMatMul eigenbackend.cpp:1928-1930)
+struct InputArgs {
+  const float* spatial;  // [N][S][cin]
+  const float* global;   // [N][gin]
+  const int* symmetry;   // [N] device
+  int cin, gin;
+  int N, X, Y;
+  void* out;             // T[N][S][32]
+  float* mask;           // [N][S]
+  float* maskSum;        // [N]
+  const float* wGlobal;  // [gin][C]
+  float* ncBias;         // [N][ncStride]
+  int C, ncStride;
+};
+hipError_t launchInputExpand(int dtype, const InputArgs& a, hipStream_t stream);
+
+// Global pooling + bias + BN/act for a gpool residual block and for the policy head:
+//   feat = poolRowsGPool(g)  (eigenbackend.cpp:152-177);  b = W^T feat (MatMulLayer);
+//   r[n][p][c] = act((r + b[c])*scale[c] + bias[c]) * mask      (addNCBiasInplace + BatchNormLayer)
+struct GPoolArgs {
+  const void* g;  // T, activated gpool channels
+  int gStride, gOffset, G;
+  void* r;        // T, in place
+  int rStride, rOffset, R;
+  const float* w;  // [3G][R]
+  const float* scale;
+  const float* bias;  // [R]
+  int actKind;
+  const float* mask;
+  const float* maskSum;
+  float* featOut;  // [N][3G] or null
+  int N, S;
+};
+hipError_t launchGPoolApply(int dtype, const GPoolArgs& a, hipStream_t stream);
+
+// Policy head tail: p2Conv (1x1), pass logits, optimism blend, inverse symmetry
+// (PolicyHead::apply eigenbackend.cpp:2019-2035; getOutput :2553-2567)
+struct PolicyArgs {
+  const void* p;  // T p1 after BN/act
+  int pStride, pOffset, P;
+  const float* w2;       // [P][NP]
+  int NP;                // policy channels 1,2,4
+  const float* feat;     // [N][3G]
+  int G3;
+  const float* wPass;    // [3G][passHidden or NP]
+  const float* bPass;    // [passHidden] or null
+  const float* wPass2;   // [passHidden][NP] or null
+  int passHidden;        // 0 => single matmul
+  int passAct;
+  const int* symmetry;
+  const float* optimism;  // [N] device
+  float* out;             // [N][S+1]
+  int N, X, Y;
+};
+hipError_t launchPolicyFinal(int dtype, const PolicyArgs& a, hipStream_t stream);
+
+// Value head tail: value pooling, v2/v3/sv3 MLP, ownership conv + inverse symmetry
+// (ValueHead::apply eigenbackend.cpp:2100-2113; poolRowsValueHead :179-197)
+struct ValueArgs {
+  const void* v;  // T v1 after BN/act
+  int vStride, vOffset, V1;
+  const float* w2;  // [3V1][V2]
+  const float* b2;
+  int V2, v2Act;
+  const float* w3;  // [V2][3]
+  const float* b3;
+  const float* wsv;  // [V2][NSV]
+  const float* bsv;
+  int NSV;
+  const float* wOwn;  // [V1]
+  const float* maskSum;
+  const int* symmetry;
+  float* value;      // [N][3]
+  float* score;      // [N][6]
+  float* ownership;  // [N][S]
+  int N, X, Y;
+};
+hipError_t launchValueFinal(int dtype, const ValueArgs& a, hipStream_t stream);
+
+// Stand-alone masked BN + activation (only the layer test hooks need it un-fused).
+struct BnActArgs {
+  const void* in;
+  void* out;
+  int stride, C;
+  const float* scale;
+  const float* bias;
+  int actKind;
+  const float* mask;
+  int N, S;
+};
+hipError_t launchBnAct(int dtype, const BnActArgs& a, hipStream_t stream);
+
+// fp32 <-> T conversion of dense activation tensors (test hooks / debugging)
+hipError_t launchFloatToT(int dtype, const float* in, int inC, void* out, int outStride, size_t cells, hipStream_t stream);
+hipError_t launchTToFloat(int dtype, const void* in, int inStride, int offset, float* out, int outC, size_t cells, hipStream_t stream);
+
+// host helpers
+uint16_t floatToHalfBits(float f);
+uint16_t floatToBf16Bits(float f);
+inline uint16_t floatToTBits(int dtype, float f) { return dtype == DT_F16 ? floatToHalfBits(f) : floatToBf16Bits(f); }
+
+}  // namespace kmx
+#endif

@@ -1,0 +1,250 @@
+// kmx_api.cpp — the C ABI of include/katamx.h on top of the Engine. Every entry point converts C++
+// exceptions into a status code + thread-local message; nothing here computes.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "../../include/katamx.h"
+#include "engine.h"
+#include "model_desc.h"
+
+using namespace kmx;
+
+struct kmx_model {
+  std::unique_ptr<ModelDesc> desc;
+};
+struct kmx_context {
+  int nnXLen, nnYLen, precisionMode;
+  std::vector<int> gpuIdxs;
+};
+struct kmx_handle {
+  std::unique_ptr<Engine> engine;
+  int precision;
+};
+
+namespace {
+thread_local std::string g_lastError;
+
+int setError(int code, const std::string& msg) {
+  g_lastError = msg;
+  return code;
+}
+template <class F>
+int guarded(F&& f) {
+  try {
+    f();
+    return KMX_OK;
+  }
+  catch(const ModelError& e) { return setError(e.code, e.what()); }
+  catch(const Error& e) { return setError(e.code, e.what()); }
+  catch(const std::bad_alloc&) { return setError(KMX_ERR_INTERNAL, "out of host memory"); }
+  catch(const std::exception& e) { return setError(KMX_ERR_INTERNAL, e.what()); }
+}
+int dtypeForPrecision(int mode) {
+  switch(mode) {
+    case KMX_PREC_AUTO: return DT_BF16;
+    case KMX_PREC_BF16: return DT_BF16;
+    case KMX_PREC_FP16: return DT_F16;
+    default: return -1;
+  }
+}
+int deviceCountOrThrow() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if(e != hipSuccess || n <= 0)
+    throw Error(KMX_ERR_DEVICE, std::string("no usable HIP device (katamx has no CPU fallback): ") + hipGetErrorString(e));
+  return n;
+}
+}  // namespace
+
+extern "C" {
+
+int kmx_abi_version(void) { return KMX_ABI_VERSION; }
+const char* kmx_last_error(void) { return g_lastError.c_str(); }
+
+int kmx_global_init(void) {
+  return guarded([] { (void)deviceCountOrThrow(); });
+}
+void kmx_global_cleanup(void) {}
+
+int kmx_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if(e != hipSuccess) return setError(KMX_ERR_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  return n;
+}
+int kmx_device_name(int device, char* buf, size_t buflen) {
+  return guarded([&] {
+    if(!buf || buflen == 0) throw Error(KMX_ERR_INVALID_ARG, "kmx_device_name: null buffer");
+    hipDeviceProp_t prop;
+    hipCheck(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
+    snprintf(buf, buflen, "%s (%s, %d CUs, %.1f GB)", prop.name, prop.gcnArchName, prop.multiProcessorCount,
+             (double)prop.totalGlobalMem / 1e9);
+  });
+}
+
+int kmx_model_load(const char* path, const char* expected_sha256, kmx_model** out) {
+  return guarded([&] {
+    if(!path || !out) throw Error(KMX_ERR_INVALID_ARG, "kmx_model_load: null argument");
+    *out = nullptr;
+    std::unique_ptr<kmx_model> m(new kmx_model());
+    m->desc = ModelDesc::loadFromFile(path, expected_sha256 ? expected_sha256 : "");
+    *out = m.release();
+  });
+}
+void kmx_model_free(kmx_model* model) { delete model; }
+
+int kmx_model_info_get(const kmx_model* model, kmx_model_info* out) {
+  return guarded([&] {
+    if(!model || !out) throw Error(KMX_ERR_INVALID_ARG, "kmx_model_info_get: null argument");
+    const ModelDesc& d = *model->desc;
+    memset(out, 0, sizeof(*out));
+    snprintf(out->name, sizeof(out->name), "%s", d.name.c_str());
+    out->model_version = d.version;
+    out->num_input_channels = d.numInputChannels;
+    out->num_input_global_channels = d.numInputGlobalChannels;
+    out->num_input_meta_channels = 0;
+    out->num_policy_channels = d.numPolicyChannels;
+    out->num_value_channels = d.numValueChannels;
+    out->num_score_value_channels = d.numScoreValueChannels;
+    out->num_ownership_channels = d.numOwnershipChannels;
+    out->trunk_num_channels = d.trunkC;
+    out->mid_num_channels = d.midC;
+    out->num_blocks = d.numBlocks;
+    out->td_score_multiplier = d.postProcess[0];
+    out->score_mean_multiplier = d.postProcess[1];
+    out->score_stdev_multiplier = d.postProcess[2];
+    out->lead_multiplier = d.postProcess[3];
+    out->variance_time_multiplier = d.postProcess[4];
+    out->shortterm_value_error_multiplier = d.postProcess[5];
+    out->shortterm_score_error_multiplier = d.postProcess[6];
+    out->output_scale_multiplier = 1.0f;
+    out->num_parameters = d.numParameters;
+    out->flops_per_position = 2.0 * d.macPerPosition;
+  });
+}
+
+int kmx_context_create(const int* gpu_idxs, int num_gpu_idxs, int nn_x_len, int nn_y_len, int precision_mode, kmx_context** out) {
+  return guarded([&] {
+    if(!out) throw Error(KMX_ERR_INVALID_ARG, "kmx_context_create: null argument");
+    *out = nullptr;
+    if(nn_x_len < 2 || nn_y_len < 2 || nn_x_len > 19 || nn_y_len > 19)
+      throw Error(KMX_ERR_INVALID_ARG, "kmx_context_create: nnXLen/nnYLen must be in 2..19");
+    if(precision_mode == KMX_PREC_FP32)
+      throw Error(KMX_ERR_UNSUPPORTED, "katamx: fp32 device arithmetic is not implemented; use fp16/bf16 (fp32 accumulate)");
+    if(dtypeForPrecision(precision_mode) < 0) throw Error(KMX_ERR_INVALID_ARG, "kmx_context_create: unknown precision mode");
+    const int ndev = deviceCountOrThrow();
+    std::unique_ptr<kmx_context> c(new kmx_context());
+    c->nnXLen = nn_x_len;
+    c->nnYLen = nn_y_len;
+    c->precisionMode = precision_mode;
+    for(int i = 0; i < num_gpu_idxs; i++) {
+      int g = gpu_idxs ? gpu_idxs[i] : -1;
+      if(g >= ndev) throw Error(KMX_ERR_DEVICE, "kmx_context_create: device index " + std::to_string(g) + " out of range (" + std::to_string(ndev) + " devices)");
+      c->gpuIdxs.push_back(g);
+    }
+    *out = c.release();
+  });
+}
+void kmx_context_free(kmx_context* ctx) { delete ctx; }
+
+int kmx_handle_create(kmx_context* ctx, const kmx_model* model, int max_batch_size, int require_exact_nn_len, int gpu_idx,
+                      kmx_handle** out) {
+  (void)require_exact_nn_len;  // masking is always on: it costs one multiply in the conv epilogue
+  return guarded([&] {
+    if(!ctx || !model || !out) throw Error(KMX_ERR_INVALID_ARG, "kmx_handle_create: null argument");
+    *out = nullptr;
+    const int ndev = deviceCountOrThrow();
+    const int dev = gpu_idx < 0 ? 0 : gpu_idx;
+    if(dev >= ndev) throw Error(KMX_ERR_DEVICE, "kmx_handle_create: device index out of range");
+    std::unique_ptr<kmx_handle> h(new kmx_handle());
+    const int dtype = dtypeForPrecision(ctx->precisionMode);
+    h->precision = dtype == DT_F16 ? KMX_PREC_FP16 : KMX_PREC_BF16;
+    h->engine.reset(new Engine(*model->desc, ctx->nnXLen, ctx->nnYLen, max_batch_size, dtype, dev));
+    *out = h.release();
+  });
+}
+void kmx_handle_free(kmx_handle* handle) { delete handle; }
+int kmx_handle_precision(const kmx_handle* handle) { return handle ? handle->precision : KMX_ERR_INVALID_ARG; }
+
+int kmx_eval(kmx_handle* handle, int n_rows, const float* const* row_spatial, const float* const* row_global,
+             const int* symmetry, const float* policy_optimism, float* const* out_policy, float* out_value, float* out_score,
+             float* const* out_ownership) {
+  return guarded([&] {
+    if(!handle || !row_spatial || !row_global || !out_policy || !out_value || !out_score)
+      throw Error(KMX_ERR_INVALID_ARG, "kmx_eval: null argument");
+    for(int i = 0; i < n_rows; i++)
+      if(!row_spatial[i] || !row_global[i] || !out_policy[i]) throw Error(KMX_ERR_INVALID_ARG, "kmx_eval: null row pointer");
+    if(symmetry)
+      for(int i = 0; i < n_rows; i++)
+        if(symmetry[i] < 0 || symmetry[i] > 7) throw Error(KMX_ERR_INVALID_ARG, "kmx_eval: symmetry must be in 0..7");
+    handle->engine->evalHost(n_rows, row_spatial, row_global, symmetry, policy_optimism, out_policy, out_value, out_score,
+                             out_ownership);
+  });
+}
+
+int kmx_eval_device(kmx_handle* handle, int n_rows, const float* d_spatial, const float* d_global, const int* symmetry,
+                    const float* policy_optimism, float* d_policy, float* d_value, float* d_score, float* d_ownership, int sync) {
+  return guarded([&] {
+    if(!handle || !d_spatial || !d_global || !d_policy || !d_value || !d_score)
+      throw Error(KMX_ERR_INVALID_ARG, "kmx_eval_device: null argument");
+    if(symmetry)
+      for(int i = 0; i < n_rows; i++)
+        if(symmetry[i] < 0 || symmetry[i] > 7) throw Error(KMX_ERR_INVALID_ARG, "kmx_eval_device: symmetry must be in 0..7");
+    handle->engine->evalDevice(n_rows, d_spatial, d_global, symmetry, policy_optimism, d_policy, d_value, d_score, d_ownership,
+                               sync != 0);
+  });
+}
+void* kmx_handle_stream(kmx_handle* handle) { return handle ? (void*)handle->engine->stream() : nullptr; }
+int kmx_handle_sync(kmx_handle* handle) {
+  return guarded([&] {
+    if(!handle) throw Error(KMX_ERR_INVALID_ARG, "kmx_handle_sync: null handle");
+    handle->engine->sync();
+  });
+}
+int kmx_handle_stats(const kmx_handle* handle, uint64_t* rows, uint64_t* batches) {
+  if(!handle) return setError(KMX_ERR_INVALID_ARG, "kmx_handle_stats: null handle");
+  if(rows) *rows = handle->engine->rowsProcessed();
+  if(batches) *batches = handle->engine->batchesProcessed();
+  return KMX_OK;
+}
+
+static int hookDtype(int precision_mode) {
+  if(precision_mode == KMX_PREC_FP32) throw Error(KMX_ERR_UNSUPPORTED, "fp32 device arithmetic is not implemented");
+  int dt = dtypeForPrecision(precision_mode);
+  if(dt < 0) throw Error(KMX_ERR_INVALID_ARG, "unknown precision mode");
+  (void)deviceCountOrThrow();
+  return dt;
+}
+int kmx_test_conv(const kmx_conv_desc* desc, int batch, int nn_x_len, int nn_y_len, int precision_mode, const float* in_nhwc,
+                  float* out_nhwc) {
+  return guarded([&] {
+    if(!desc || !in_nhwc || !out_nhwc) throw Error(KMX_ERR_INVALID_ARG, "kmx_test_conv: null argument");
+    testConv(hookDtype(precision_mode), desc, batch, nn_x_len, nn_y_len, in_nhwc, out_nhwc);
+  });
+}
+int kmx_test_bnact(const kmx_bnact_desc* desc, int batch, int nn_x_len, int nn_y_len, int precision_mode, const float* in_nhwc,
+                   const float* mask_nhw, float* out_nhwc) {
+  return guarded([&] {
+    if(!desc || !in_nhwc || !out_nhwc) throw Error(KMX_ERR_INVALID_ARG, "kmx_test_bnact: null argument");
+    testBnAct(hookDtype(precision_mode), desc, batch, nn_x_len, nn_y_len, in_nhwc, mask_nhw, out_nhwc);
+  });
+}
+int kmx_test_resblock(const kmx_resblock_desc* desc, int batch, int nn_x_len, int nn_y_len, int precision_mode,
+                      const float* in_nhwc, const float* mask_nhw, float* out_nhwc) {
+  return guarded([&] {
+    if(!desc || !in_nhwc || !out_nhwc) throw Error(KMX_ERR_INVALID_ARG, "kmx_test_resblock: null argument");
+    testResBlock(hookDtype(precision_mode), desc, batch, nn_x_len, nn_y_len, in_nhwc, mask_nhw, out_nhwc);
+  });
+}
+int kmx_test_gpoolblock(const kmx_gpoolblock_desc* desc, int batch, int nn_x_len, int nn_y_len, int precision_mode,
+                        const float* in_nhwc, const float* mask_nhw, float* out_nhwc) {
+  return guarded([&] {
+    if(!desc || !in_nhwc || !out_nhwc) throw Error(KMX_ERR_INVALID_ARG, "kmx_test_gpoolblock: null argument");
+    testGPoolBlock(hookDtype(precision_mode), desc, batch, nn_x_len, nn_y_len, in_nhwc, mask_nhw, out_nhwc);
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,360 @@
+// misc_kernels.hip — the small, HBM-bound kernels around the MFMA convolution: input staging
+// (symmetry + 16-bit conversion + mask), global pooling + bias + BN/act, the policy and value head
+// tails, and the stand-alone ops the layer test hooks need. One work-group (256 threads) per board;
+// all arithmetic in fp32. Reference citations are at the launch structs in kernels.h.
+#include <cstring>
+
+#include "device_common.h"
+
+namespace kmx {
+
+namespace {
+
+constexpr int BT = 256;  // threads per board work-group
+
+template <class TR>
+__device__ __forceinline__ float ldT(const void* base, size_t idx) {
+  return TR::toFloat(((const typename TR::T*)base)[idx]);
+}
+template <class TR>
+__device__ __forceinline__ void stT(void* base, size_t idx, float v) {
+  ((typename TR::T*)base)[idx] = TR::fromFloat(v);
+}
+
+__device__ __forceinline__ float blockSum(float v, float* red) {
+  // red: BT floats of LDS
+  const int tid = threadIdx.x;
+  red[tid] = v;
+  __syncthreads();
+  for(int s = BT / 2; s > 0; s >>= 1) {
+    if(tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  float r = red[0];
+  __syncthreads();
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <class TR>
+__global__ __launch_bounds__(BT) void inputExpandKernel(const InputArgs a) {
+  __shared__ float red[BT];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int S = a.X * a.Y;
+  const int sym = a.symmetry ? a.symmetry[n] : 0;
+  const float* src = a.spatial + (size_t)n * S * a.cin;
+  typename TR::T* dst = (typename TR::T*)a.out + (size_t)n * S * KCHUNK;
+  float localMask = 0.0f;
+  for(int p = tid; p < S; p += BT) {
+    const int h = p / a.X, w = p - h * a.X;
+    const int q = symDst(h, w, a.Y, a.X, sym, false);
+    const float* sp = src + (size_t)p * a.cin;
+    typename TR::T* dp = dst + (size_t)q * KCHUNK;
+    for(int c = 0; c < KCHUNK; c++) dp[c] = TR::fromFloat(c < a.cin ? sp[c] : 0.0f);
+    const float m = sp[0];  // mask = input channel 0 (eigenbackend.cpp:2181)
+    a.mask[(size_t)n * S + q] = m;
+    localMask += m;
+  }
+  const float ms = blockSum(localMask, red);
+  if(tid == 0) a.maskSum[n] = ms;
+  // ncBias[n][c] = sum_g global[n][g] * W[g][c]
+  const float* gl = a.global + (size_t)n * a.gin;
+  for(int c = tid; c < a.C; c += BT) {
+    float s = 0.0f;
+    for(int g = 0; g < a.gin; g++) s += gl[g] * a.wGlobal[(size_t)g * a.C + c];
+    a.ncBias[(size_t)n * a.ncStride + c] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <class TR>
+__global__ __launch_bounds__(BT) void gpoolApplyKernel(const GPoolArgs a) {
+  extern __shared__ float sm[];
+  // layout: partSum[BT], partMax[BT], feat[3G], biasv[R]
+  float* partSum = sm;
+  float* partMax = sm + BT;
+  float* feat = sm + 2 * BT;
+  float* biasv = feat + 3 * a.G;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int S = a.S, G = a.G, R = a.R;
+  const float* maskB = a.mask + (size_t)n * S;
+  const size_t cell0 = (size_t)n * S;
+
+  // phase 1: per-channel sum and max over the board. Threads = (cell group) x (channel).
+  // groups = BT / Gc where Gc = channels handled per pass (<= BT).
+  for(int c0 = 0; c0 < G; c0 += BT) {
+    const int Gc = (G - c0) < BT ? (G - c0) : BT;
+    int groups = BT / Gc;
+    if(groups < 1) groups = 1;
+    const int c = tid % Gc, grp = tid / Gc;
+    float s = 0.0f, m = -1.0f;  // -1 init + (mask-1) trick: eigenbackend.cpp:156-166
+    if(grp < groups) {
+      for(int p = grp; p < S; p += groups) {
+        const float x = ldT<TR>(a.g, (cell0 + p) * a.gStride + a.gOffset + c0 + c);
+        s += x;
+        m = fmaxf(m, x + (maskB[p] - 1.0f));
+      }
+    }
+    partSum[tid] = s;
+    partMax[tid] = m;
+    __syncthreads();
+    if(tid < Gc) {
+      float ts = 0.0f, tm = -1.0f;
+      for(int g = 0; g < groups; g++) {
+        ts += partSum[g * Gc + tid];
+        tm = fmaxf(tm, partMax[g * Gc + tid]);
+      }
+      const float div = a.maskSum[n];
+      const float sqrtdiv = sqrtf(div);
+      const float mean = ts / div;
+      feat[c0 + tid] = mean;
+      feat[G + c0 + tid] = mean * (sqrtdiv - 14.0f) * 0.1f;
+      feat[2 * G + c0 + tid] = tm;
+    }
+    __syncthreads();
+  }
+  if(a.featOut != nullptr)
+    for(int i = tid; i < 3 * G; i += BT) a.featOut[(size_t)n * 3 * G + i] = feat[i];
+  // phase 2: bias[r] = sum_k feat[k] * W[k][r]
+  for(int r = tid; r < R; r += BT) {
+    float s = 0.0f;
+    for(int k = 0; k < 3 * G; k++) s += feat[k] * a.w[(size_t)k * R + r];
+    biasv[r] = s;
+  }
+  __syncthreads();
+  // phase 3: r = act((r + bias)*scale + bnBias) * mask, in place
+  const int total = S * R;
+  for(int i = tid; i < total; i += BT) {
+    const int p = i / R, r = i - p * R;
+    const size_t idx = (cell0 + p) * a.rStride + a.rOffset + r;
+    const float x = ldT<TR>(a.r, idx) + biasv[r];
+    const float y = (maskB[p] == 1.0f) ? actApply(x * a.scale[r] + a.bias[r], a.actKind) : 0.0f;
+    stT<TR>(a.r, idx, y);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <class TR>
+__global__ __launch_bounds__(BT) void policyFinalKernel(const PolicyArgs a) {
+  extern __shared__ float sm[];
+  float* hidden = sm;  // passHidden floats
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int S = a.X * a.Y, P = a.P, NP = a.NP;
+  const int sym = a.symmetry ? a.symmetry[n] : 0;
+  const float opt = a.optimism ? a.optimism[n] : 0.0f;
+  const bool blend = (NP == 2 || NP == 4);  // channels 0,1 = policy, optimistic policy (eigenbackend.cpp:2553)
+  float* out = a.out + (size_t)n * (S + 1);
+  for(int p = tid; p < S; p += BT) {
+    float l0 = 0.0f, l1 = 0.0f;
+    const size_t base = ((size_t)n * S + p) * a.pStride + a.pOffset;
+    for(int c = 0; c < P; c++) {
+      const float x = ldT<TR>(a.p, base + c);
+      l0 += x * a.w2[(size_t)c * NP];
+      if(blend) l1 += x * a.w2[(size_t)c * NP + 1];
+    }
+    const float v = blend ? l0 + (l1 - l0) * opt : l0;
+    const int h = p / a.X, w = p - h * a.X;
+    out[symDst(h, w, a.Y, a.X, sym, true)] = v;
+  }
+  // pass logit
+  const float* feat = a.feat + (size_t)n * a.G3;
+  if(a.passHidden > 0) {
+    for(int j = tid; j < a.passHidden; j += BT) {
+      float s = 0.0f;
+      for(int k = 0; k < a.G3; k++) s += feat[k] * a.wPass[(size_t)k * a.passHidden + j];
+      hidden[j] = actApply(s + a.bPass[j], a.passAct);
+    }
+    __syncthreads();
+    if(tid == 0) {
+      float p0 = 0.0f, p1 = 0.0f;
+      for(int j = 0; j < a.passHidden; j++) {
+        p0 += hidden[j] * a.wPass2[(size_t)j * NP];
+        if(blend) p1 += hidden[j] * a.wPass2[(size_t)j * NP + 1];
+      }
+      out[S] = blend ? p0 + (p1 - p0) * opt : p0;
+    }
+  }
+  else if(tid == 0) {
+    float p0 = 0.0f, p1 = 0.0f;
+    for(int k = 0; k < a.G3; k++) {
+      p0 += feat[k] * a.wPass[(size_t)k * NP];
+      if(blend) p1 += feat[k] * a.wPass[(size_t)k * NP + 1];
+    }
+    out[S] = blend ? p0 + (p1 - p0) * opt : p0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <class TR>
+__global__ __launch_bounds__(BT) void valueFinalKernel(const ValueArgs a) {
+  extern __shared__ float sm[];
+  // layout: part[BT], feat[3*V1], h[V2]
+  float* part = sm;
+  float* feat = sm + BT;
+  float* hid = feat + 3 * a.V1;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int S = a.X * a.Y, V1 = a.V1, V2 = a.V2;
+  const int sym = a.symmetry ? a.symmetry[n] : 0;
+  const size_t cell0 = (size_t)n * S;
+  // pooling (poolRowsValueHead)
+  for(int c0 = 0; c0 < V1; c0 += BT) {
+    const int Vc = (V1 - c0) < BT ? (V1 - c0) : BT;
+    const int groups = BT / Vc;
+    const int c = tid % Vc, grp = tid / Vc;
+    float s = 0.0f;
+    if(grp < groups)
+      for(int p = grp; p < S; p += groups) s += ldT<TR>(a.v, (cell0 + p) * a.vStride + a.vOffset + c0 + c);
+    part[tid] = s;
+    __syncthreads();
+    if(tid < Vc) {
+      float ts = 0.0f;
+      for(int g = 0; g < groups; g++) ts += part[g * Vc + tid];
+      const float div = a.maskSum[n];
+      const float sqrtdiv = sqrtf(div);
+      const float mean = ts / div;
+      feat[c0 + tid] = mean;
+      feat[V1 + c0 + tid] = mean * (sqrtdiv - 14.0f) * 0.1f;
+      feat[2 * V1 + c0 + tid] = mean * ((sqrtdiv - 14.0f) * (sqrtdiv - 14.0f) * 0.01f - 0.1f);
+    }
+    __syncthreads();
+  }
+  for(int j = tid; j < V2; j += BT) {
+    float s = 0.0f;
+    for(int k = 0; k < 3 * V1; k++) s += feat[k] * a.w2[(size_t)k * V2 + j];
+    hid[j] = actApply(s + a.b2[j], a.v2Act);
+  }
+  __syncthreads();
+  if(tid < 3) {
+    float s = 0.0f;
+    for(int j = 0; j < V2; j++) s += hid[j] * a.w3[(size_t)j * 3 + tid];
+    a.value[(size_t)n * 3 + tid] = s + a.b3[tid];
+  }
+  else if(tid >= 32 && tid < 32 + 6) {
+    const int k = tid - 32;
+    float s = 0.0f;
+    if(k < a.NSV) {
+      for(int j = 0; j < V2; j++) s += hid[j] * a.wsv[(size_t)j * a.NSV + k];
+      s += a.bsv[k];
+    }
+    a.score[(size_t)n * 6 + k] = s;
+  }
+  // ownership: 1x1 conv V1 -> 1, then inverse symmetry
+  if(a.ownership != nullptr) {
+    float* own = a.ownership + (size_t)n * S;
+    for(int p = tid; p < S; p += BT) {
+      float s = 0.0f;
+      const size_t base = (cell0 + p) * a.vStride + a.vOffset;
+      for(int c = 0; c < V1; c++) s += ldT<TR>(a.v, base + c) * a.wOwn[c];
+      const int h = p / a.X, w = p - h * a.X;
+      own[symDst(h, w, a.Y, a.X, sym, true)] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <class TR>
+__global__ void bnActKernel(const BnActArgs a) {
+  const size_t total = (size_t)a.N * a.S * a.C;
+  for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t cell = i / a.C;
+    const int c = (int)(i - cell * a.C);
+    const float x = ldT<TR>(a.in, cell * a.stride + c);
+    const float y = (a.mask[cell] == 1.0f) ? actApply(x * a.scale[c] + a.bias[c], a.actKind) : 0.0f;
+    stT<TR>(a.out, cell * a.stride + c, y);
+  }
+}
+template <class TR>
+__global__ void floatToTKernel(const float* in, int inC, void* out, int outStride, size_t cells) {
+  const size_t total = cells * outStride;
+  for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t cell = i / outStride;
+    const int c = (int)(i - cell * outStride);
+    stT<TR>(out, i, c < inC ? in[cell * inC + c] : 0.0f);
+  }
+}
+template <class TR>
+__global__ void tToFloatKernel(const void* in, int inStride, int offset, float* out, int outC, size_t cells) {
+  const size_t total = cells * outC;
+  for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t cell = i / outC;
+    const int c = (int)(i - cell * outC);
+    out[i] = ldT<TR>(in, cell * inStride + offset + c);
+  }
+}
+
+inline int gridFor(size_t total) {
+  size_t b = (total + 255) / 256;
+  if(b > 4096) b = 4096;
+  if(b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+#define KMX_DISPATCH(dtype, KERNEL, grid, block, lds, stream, ...)                               \
+  do {                                                                                             \
+    if((dtype) == DT_F16) hipLaunchKernelGGL(KERNEL<TraitsF16>, grid, block, lds, stream, __VA_ARGS__); \
+    else if((dtype) == DT_BF16) hipLaunchKernelGGL(KERNEL<TraitsBF16>, grid, block, lds, stream, __VA_ARGS__); \
+    else return hipErrorInvalidValue;                                                              \
+    return hipGetLastError();                                                                      \
+  } while(0)
+
+hipError_t launchInputExpand(int dtype, const InputArgs& a, hipStream_t stream) {
+  if(a.cin > KCHUNK) return hipErrorInvalidValue;
+  KMX_DISPATCH(dtype, inputExpandKernel, dim3(a.N), dim3(BT), 0, stream, a);
+}
+hipError_t launchGPoolApply(int dtype, const GPoolArgs& a, hipStream_t stream) {
+  size_t lds = sizeof(float) * (2 * BT + 3 * a.G + a.R);
+  KMX_DISPATCH(dtype, gpoolApplyKernel, dim3(a.N), dim3(BT), lds, stream, a);
+}
+hipError_t launchPolicyFinal(int dtype, const PolicyArgs& a, hipStream_t stream) {
+  size_t lds = sizeof(float) * (a.passHidden > 0 ? a.passHidden : 1);
+  KMX_DISPATCH(dtype, policyFinalKernel, dim3(a.N), dim3(BT), lds, stream, a);
+}
+hipError_t launchValueFinal(int dtype, const ValueArgs& a, hipStream_t stream) {
+  size_t lds = sizeof(float) * (BT + 3 * a.V1 + a.V2);
+  KMX_DISPATCH(dtype, valueFinalKernel, dim3(a.N), dim3(BT), lds, stream, a);
+}
+hipError_t launchBnAct(int dtype, const BnActArgs& a, hipStream_t stream) {
+  KMX_DISPATCH(dtype, bnActKernel, dim3(gridFor((size_t)a.N * a.S * a.C)), dim3(256), 0, stream, a);
+}
+hipError_t launchFloatToT(int dtype, const float* in, int inC, void* out, int outStride, size_t cells, hipStream_t stream) {
+  KMX_DISPATCH(dtype, floatToTKernel, dim3(gridFor(cells * outStride)), dim3(256), 0, stream, in, inC, out, outStride, cells);
+}
+hipError_t launchTToFloat(int dtype, const void* in, int inStride, int offset, float* out, int outC, size_t cells, hipStream_t stream) {
+  KMX_DISPATCH(dtype, tToFloatKernel, dim3(gridFor(cells * outC)), dim3(256), 0, stream, in, inStride, offset, out, outC, cells);
+}
+
+// ---- host float -> 16-bit conversions (round to nearest even) ----
+uint16_t floatToBf16Bits(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+  uint32_t r = u + 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(r >> 16);
+}
+uint16_t floatToHalfBits(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u;
+  const uint32_t absu = u & 0x7fffffffu;
+  if(absu > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);   // NaN
+  if(absu >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);  // >= 65520 -> inf
+  if(absu < 0x33000001u) return (uint16_t)sign;               // < 2^-25 -> 0
+  int exp = (int)(absu >> 23) - 127;
+  uint32_t mant = (absu & 0x7fffffu) | 0x800000u;
+  if(exp < -14) {  // subnormal half
+    int shift = -14 - exp;
+    uint32_t m = mant >> (13 + shift);
+    uint32_t rem = mant & ((1u << (13 + shift)) - 1u);
+    uint32_t halfway = 1u << (12 + shift);
+    if(rem > halfway || (rem == halfway && (m & 1u))) m++;
+    return (uint16_t)(sign | m);
+  }
+  uint32_t h = ((uint32_t)(exp + 15) << 10) | ((mant & 0x7fffffu) >> 13);
+  uint32_t rem = mant & 0x1fffu;
+  if(rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;
+  return (uint16_t)(sign | h);
+}
+
+}  // namespace kmx

@@ -1,0 +1,288 @@
+"""Python mirror of the reference's backend interface `namespace NeuralNet`
+(cpp/neuralnet/nninterface.h:32-182) over the katamx C ABI.
+
+Same names, argument meaning and error behaviour as the reference (errors raise KatamxError where the
+reference throws StringError), so that the parity tests read like the reference's own tests:
+
+    model   = loadModelFile(path, expectedSha256)
+    ctx     = createComputeContext([0], nnXLen, nnYLen, useFP16Mode="auto")
+    handle  = createComputeHandle(ctx, model, maxBatchSize, requireExactNNLen, gpuIdxForThisThread)
+    outputs = getOutput(handle, rowSpatial, rowGlobal, symmetries, policyOptimisms)
+
+This file is host plumbing for tests and bench.py; the product is the C ABI underneath it.
+"""
+import ctypes
+
+import numpy as np
+
+from . import capi
+from .capi import KatamxError  # noqa: F401  (re-export)
+
+_FP = ctypes.POINTER(ctypes.c_float)
+
+
+def _fp(a):
+    return a.ctypes.data_as(_FP)
+
+
+def globalInitialize():
+    lib = capi.load_library()
+    capi.check(lib.kmx_global_init(), lib)
+
+
+def globalCleanup():
+    capi.load_library().kmx_global_cleanup()
+
+
+def printDevices():
+    lib = capi.load_library()
+    n = lib.kmx_device_count()
+    out = []
+    for i in range(max(n, 0)):
+        buf = ctypes.create_string_buffer(256)
+        if lib.kmx_device_name(i, buf, 256) == capi.KMX_OK:
+            out.append("Found HIP device %d: %s" % (i, buf.value.decode()))
+    print("\n".join(out))
+    return out
+
+
+class LoadedModel:
+    def __init__(self, file, expectedSha256=""):
+        self._lib = capi.load_library()
+        p = ctypes.c_void_p()
+        capi.check(self._lib.kmx_model_load(file.encode(), (expectedSha256 or "").encode(), ctypes.byref(p)), self._lib)
+        self._p = p
+        info = capi.ModelInfo()
+        capi.check(self._lib.kmx_model_info_get(self._p, ctypes.byref(info)), self._lib)
+        self.info = info
+        self.file = file
+
+    def close(self):
+        if self._p:
+            self._lib.kmx_model_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def loadModelFile(file, expectedSha256=""):
+    return LoadedModel(file, expectedSha256)
+
+
+def freeLoadedModel(model):
+    model.close()
+
+
+def getModelDesc(model):
+    """The fields NNEvaluator reads from ModelDesc (nneval.cpp:138-143,292,306,327)."""
+    i = model.info
+    return {
+        "name": i.name.decode(),
+        "modelVersion": i.model_version,
+        "numInputChannels": i.num_input_channels,
+        "numInputGlobalChannels": i.num_input_global_channels,
+        "numPolicyChannels": i.num_policy_channels,
+        "numValueChannels": i.num_value_channels,
+        "numScoreValueChannels": i.num_score_value_channels,
+        "numOwnershipChannels": i.num_ownership_channels,
+        "trunkNumChannels": i.trunk_num_channels,
+        "numBlocks": i.num_blocks,
+        "numParameters": i.num_parameters,
+        "flopsPerPosition": i.flops_per_position,
+        "postProcessParams": {
+            "tdScoreMultiplier": i.td_score_multiplier,
+            "scoreMeanMultiplier": i.score_mean_multiplier,
+            "scoreStdevMultiplier": i.score_stdev_multiplier,
+            "leadMultiplier": i.lead_multiplier,
+            "varianceTimeMultiplier": i.variance_time_multiplier,
+            "shorttermValueErrorMultiplier": i.shortterm_value_error_multiplier,
+            "shorttermScoreErrorMultiplier": i.shortterm_score_error_multiplier,
+            "outputScaleMultiplier": i.output_scale_multiplier,
+        },
+    }
+
+
+class ComputeContext:
+    def __init__(self, gpuIdxs, nnXLen, nnYLen, useFP16Mode="auto", precision=None):
+        self._lib = capi.load_library()
+        if precision is None:
+            # tri-state enabled_t (cpp/core/commontypes.h): False -> fp32, True/Auto -> backend 16-bit default
+            precision = capi.PREC_FP32 if useFP16Mode in (False, "false") else capi.PREC_AUTO
+        elif isinstance(precision, str):
+            precision = {"auto": capi.PREC_AUTO, "fp32": capi.PREC_FP32, "fp16": capi.PREC_FP16, "bf16": capi.PREC_BF16}[precision]
+        idxs = (ctypes.c_int * max(len(gpuIdxs), 1))(*gpuIdxs)
+        p = ctypes.c_void_p()
+        capi.check(self._lib.kmx_context_create(idxs, len(gpuIdxs), nnXLen, nnYLen, precision, ctypes.byref(p)), self._lib)
+        self._p = p
+        self.nnXLen, self.nnYLen = nnXLen, nnYLen
+
+    def close(self):
+        if self._p:
+            self._lib.kmx_context_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def createComputeContext(gpuIdxs, nnXLen, nnYLen, useFP16Mode="auto", precision=None):
+    return ComputeContext(gpuIdxs, nnXLen, nnYLen, useFP16Mode, precision)
+
+
+def freeComputeContext(ctx):
+    ctx.close()
+
+
+class ComputeHandle:
+    def __init__(self, context, loadedModel, maxBatchSize, requireExactNNLen=False, gpuIdxForThisThread=-1):
+        self._lib = capi.load_library()
+        p = ctypes.c_void_p()
+        capi.check(self._lib.kmx_handle_create(context._p, loadedModel._p, maxBatchSize, 1 if requireExactNNLen else 0,
+                                                gpuIdxForThisThread, ctypes.byref(p)), self._lib)
+        self._p = p
+        self.context = context
+        self.model = loadedModel
+        self.maxBatchSize = maxBatchSize
+
+    @property
+    def precision(self):
+        return capi.PREC_NAMES[self._lib.kmx_handle_precision(self._p)]
+
+    def stats(self):
+        r, b = ctypes.c_uint64(), ctypes.c_uint64()
+        capi.check(self._lib.kmx_handle_stats(self._p, ctypes.byref(r), ctypes.byref(b)), self._lib)
+        return r.value, b.value
+
+    def sync(self):
+        capi.check(self._lib.kmx_handle_sync(self._p), self._lib)
+
+    def close(self):
+        if self._p:
+            self._lib.kmx_handle_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def createComputeHandle(context, loadedModel, maxBatchSize, requireExactNNLen=False, gpuIdxForThisThread=-1):
+    return ComputeHandle(context, loadedModel, maxBatchSize, requireExactNNLen, gpuIdxForThisThread)
+
+
+def freeComputeHandle(handle):
+    handle.close()
+
+
+def isUsingFP16(handle):
+    return handle.precision != "fp32"
+
+
+def getOutput(handle, rowSpatial, rowGlobal, symmetries=None, policyOptimisms=None, includeOwnerMap=True):
+    """NeuralNet::getOutput. rowSpatial: float32 [n, nnY*nnX, 22] NHWC (unsymmetrised), rowGlobal: [n, 19].
+    Returns dict of logits: policy [n, S+1] (last = pass), value [n,3], score [n,6], ownership [n,S] or None."""
+    lib = handle._lib
+    rowSpatial = np.ascontiguousarray(rowSpatial, dtype=np.float32)
+    rowGlobal = np.ascontiguousarray(rowGlobal, dtype=np.float32)
+    n = rowSpatial.shape[0]
+    S = handle.context.nnXLen * handle.context.nnYLen
+    assert rowSpatial.reshape(n, -1).shape[1] == S * handle.model.info.num_input_channels
+    assert rowGlobal.reshape(n, -1).shape[1] == handle.model.info.num_input_global_channels
+    sp2 = rowSpatial.reshape(n, -1)
+    gl2 = rowGlobal.reshape(n, -1)
+    sym = np.ascontiguousarray(symmetries if symmetries is not None else np.zeros(n), dtype=np.int32)
+    opt = np.ascontiguousarray(policyOptimisms if policyOptimisms is not None else np.zeros(n), dtype=np.float32)
+    policy = np.empty((n, S + 1), dtype=np.float32)
+    value = np.empty((n, 3), dtype=np.float32)
+    score = np.empty((n, 6), dtype=np.float32)
+    ownership = np.empty((n, S), dtype=np.float32) if includeOwnerMap else None
+    PT = _FP * n
+    sp_ptrs = PT(*[_fp(sp2[i]) for i in range(n)])
+    gl_ptrs = PT(*[_fp(gl2[i]) for i in range(n)])
+    pol_ptrs = PT(*[_fp(policy[i]) for i in range(n)])
+    own_ptrs = PT(*[_fp(ownership[i]) for i in range(n)]) if includeOwnerMap else None
+    capi.check(lib.kmx_eval(handle._p, n, sp_ptrs, gl_ptrs, sym.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _fp(opt),
+                            pol_ptrs, _fp(value), _fp(score), own_ptrs), lib)
+    return {"policy": policy, "value": value, "score": score, "ownership": ownership}
+
+
+# ---- layer test hooks (nninterface.h:134-180) ------------------------------------------------------
+
+def _conv_desc(w_oihw):
+    w = np.ascontiguousarray(w_oihw, dtype=np.float32)
+    oc, ic, ky, kx = w.shape
+    return capi.ConvDesc(ky, kx, ic, oc, _fp(w)), w
+
+
+def _bn_desc(scale, bias, activation):
+    s = np.ascontiguousarray(scale, dtype=np.float32)
+    b = np.ascontiguousarray(bias, dtype=np.float32)
+    return capi.BnActDesc(len(s), activation, _fp(s), _fp(b)), (s, b)
+
+
+def _prec(useFP16):
+    if isinstance(useFP16, str):
+        return {"fp16": capi.PREC_FP16, "bf16": capi.PREC_BF16, "fp32": capi.PREC_FP32, "auto": capi.PREC_AUTO}[useFP16]
+    return capi.PREC_AUTO if useFP16 else capi.PREC_FP32
+
+
+def testEvaluateConv(w_oihw, batchSize, nnXLen, nnYLen, useFP16, inputNHWC):
+    lib = capi.load_library()
+    d, keep = _conv_desc(w_oihw)
+    x = np.ascontiguousarray(inputNHWC, dtype=np.float32)
+    out = np.empty((batchSize, nnYLen, nnXLen, d.out_channels), dtype=np.float32)
+    capi.check(lib.kmx_test_conv(ctypes.byref(d), batchSize, nnXLen, nnYLen, _prec(useFP16), _fp(x), _fp(out)), lib)
+    return out
+
+
+def testEvaluateBatchNorm(scale, bias, activation, batchSize, nnXLen, nnYLen, useFP16, inputNHWC, maskNHW):
+    lib = capi.load_library()
+    d, keep = _bn_desc(scale, bias, activation)
+    x = np.ascontiguousarray(inputNHWC, dtype=np.float32)
+    m = np.ascontiguousarray(maskNHW, dtype=np.float32)
+    out = np.empty_like(x)
+    capi.check(lib.kmx_test_bnact(ctypes.byref(d), batchSize, nnXLen, nnYLen, _prec(useFP16), _fp(x), _fp(m), _fp(out)), lib)
+    return out
+
+
+def testEvaluateResidualBlock(block, batchSize, nnXLen, nnYLen, useFP16, inputNHWC, maskNHW):
+    """block: dict(pre=(scale,bias,act), conv1=w_oihw, mid=(scale,bias,act), conv2=w_oihw)"""
+    lib = capi.load_library()
+    pre, k1 = _bn_desc(*block["pre"])
+    c1, k2 = _conv_desc(block["conv1"])
+    mid, k3 = _bn_desc(*block["mid"])
+    c2, k4 = _conv_desc(block["conv2"])
+    d = capi.ResBlockDesc(pre, c1, mid, c2)
+    x = np.ascontiguousarray(inputNHWC, dtype=np.float32)
+    m = np.ascontiguousarray(maskNHW, dtype=np.float32)
+    out = np.empty_like(x)
+    capi.check(lib.kmx_test_resblock(ctypes.byref(d), batchSize, nnXLen, nnYLen, _prec(useFP16), _fp(x), _fp(m), _fp(out)), lib)
+    return out
+
+
+def testEvaluateGlobalPoolingResidualBlock(block, batchSize, nnXLen, nnYLen, useFP16, inputNHWC, maskNHW):
+    """block: dict(pre, convr, convg, gbn, gmul (w [3G][R]), mid, conv2)"""
+    lib = capi.load_library()
+    pre, k1 = _bn_desc(*block["pre"])
+    cr, k2 = _conv_desc(block["convr"])
+    cg, k3 = _conv_desc(block["convg"])
+    gbn, k4 = _bn_desc(*block["gbn"])
+    gw = np.ascontiguousarray(block["gmul"], dtype=np.float32)
+    gm = capi.MatMulDesc(gw.shape[0], gw.shape[1], _fp(gw))
+    mid, k5 = _bn_desc(*block["mid"])
+    c2, k6 = _conv_desc(block["conv2"])
+    d = capi.GPoolBlockDesc(pre, cr, cg, gbn, gm, mid, c2)
+    x = np.ascontiguousarray(inputNHWC, dtype=np.float32)
+    m = np.ascontiguousarray(maskNHW, dtype=np.float32)
+    out = np.empty_like(x)
+    capi.check(lib.kmx_test_gpoolblock(ctypes.byref(d), batchSize, nnXLen, nnYLen, _prec(useFP16), _fp(x), _fp(m), _fp(out)), lib)
+    return out
