@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py — NN evals/s of the katamx HIP backend on the BASELINE.json workload.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (NeuralNet::getOutput of the reference, cpp/neuralnet/nninterface.h:117)
+over one batch of 256 synthetic 19x19 positions of a random-weight b18c384nbt (BASELINE.json configs[1]),
+inputs already resident in HBM. Multi-GPU = independent replicas, one process per GPU, no collective on the data
+path (the reference's only multi-GPU mode: one server thread per GPU on a shared queue, nneval.cpp:399-407);
+value = rows evaluated by all ranks / max-over-ranks time ("weak" scaling: per-GPU work is fixed).
+
+Rank 0 prints ONE JSON line, including
+  roofline     : the dominant kernel (3x3 implicit-GEMM convolution) — algorithmic FLOPs per launch / average
+                 launch duration measured with hipEvents on the engine's own stream inside the timed region;
+  cpu_baseline : the CPU oracle (a port of the reference's Eigen path; Eigen itself is not buildable offline)
+                 timed on this host's cores on a bounded sample of the same workload. Reported, not optimised against.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def synthetic_rows(n, seed):
+    """Binary feature planes shaped like fillRowV7 output (SURVEY.md 8d fallback recipe) + globals."""
+    rng = np.random.default_rng(seed)
+    L = 19
+    sp = np.zeros((n, L, L, 22), dtype=np.float32)
+    sp[..., 0] = 1.0
+    st = rng.random((n, L, L))
+    sp[..., 1] = st < 0.2
+    sp[..., 2] = (st >= 0.2) & (st < 0.4)
+    occupied = (sp[..., 1] + sp[..., 2]) > 0
+    for c in range(3, 22):
+        plane = rng.random((n, L, L)) < 0.05
+        sp[..., c] = plane & (occupied if c in (3, 4, 5, 14, 15, 16, 17) else ~occupied if c in (6,) else plane)
+    gl = rng.normal(0.0, 0.5, (n, 19)).astype(np.float32)
+    gl[:, 5] = rng.uniform(-0.5, 0.5, n)
+    return sp.reshape(n, L * L, 22), gl
+
+
+def cpu_baseline(model_path, batch_rows, min_seconds=10.0, max_seconds=30.0):
+    from oracle import oracle
+
+    om = oracle.loadModelFile(model_path)
+    sp, gl = synthetic_rows(batch_rows, 4242)
+    cores = oracle.usable_cores()
+    rows = 0
+    t0 = time.time()
+    while True:
+        oracle.getOutput(om, 19, 19, sp, gl, None, None, True, cores)
+        rows += batch_rows
+        el = time.time() - t0
+        if el >= min_seconds or el + el / (rows / batch_rows) > max_seconds:
+            break
+    el = time.time() - t0
+    return {"value": rows / el, "unit": "evals/s", "cores": cores, "kind": "port",
+            "sample": "%d b18c384nbt 19x19 evals in batches of %d, fp32 C oracle (OpenMP), %.1f s" % (rows, batch_rows, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--model", default="b18c384nbt")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents in the timed region")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: katamx has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from katago_amd import capi, modelgen, nninterface as nn
+
+    lib = capi.load_library()
+    nn.globalInitialize()
+    tmp = os.environ.get("TMPDIR", "/tmp")
+    model_path = os.path.join(tmp, "kmx_bench_%s_r%d.bin" % (args.model, rank))
+    modelgen.write_model(model_path, args.model, seed=20260921)
+    model = nn.loadModelFile(model_path)
+    ctx = nn.createComputeContext([local_rank], 19, 19, precision=args.dtype)
+    handle = nn.createComputeHandle(ctx, model, args.batch, True, local_rank)
+
+    S, B = 361, args.batch
+    sp, gl = synthetic_rows(B, 20260921 + rank)
+    d_sp = torch.from_numpy(sp).cuda()
+    d_gl = torch.from_numpy(gl).cuda()
+    sym = (np.arange(B) % 8).astype(np.int32)
+    opt = np.zeros(B, dtype=np.float32)
+    d_pol = torch.empty((B, S + 1), device="cuda")
+    d_val = torch.empty((B, 3), device="cuda")
+    d_sc = torch.empty((B, 6), device="cuda")
+    d_own = torch.empty((B, S), device="cuda")
+    torch.cuda.synchronize()
+    sym_p = sym.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+    opt_p = opt.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+    def step(sync=False):
+        capi.check(lib.kmx_eval_device(handle._p, B, d_sp.data_ptr(), d_gl.data_ptr(), sym_p, opt_p, d_pol.data_ptr(),
+                                       d_val.data_ptr(), d_sc.data_ptr(), d_own.data_ptr(), 1 if sync else 0), lib)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        handle.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(True)
+    if not args.no_profile:
+        capi.check(lib.kmx_handle_set_profiling(handle._p, 1), lib)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(False)
+    handle.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    assert torch.isfinite(d_pol).all() and torch.isfinite(d_val).all(), "non-finite outputs"
+
+    roofline = None
+    if not args.no_profile:
+        ent = (capi.ProfileEntry * 32)()
+        cnt = ctypes.c_int()
+        capi.check(lib.kmx_handle_get_profile(handle._p, ent, 32, ctypes.byref(cnt)), lib)
+        prof = {ent[i].name.decode(): ent[i] for i in range(cnt.value)}
+        capi.check(lib.kmx_handle_set_profiling(handle._p, 0), lib)
+        dom = max(prof.values(), key=lambda e: e.total_ms)
+        achieved = dom.flops / (dom.total_ms * 1e-3) / 1e12
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        roofline = {"bound": "mfma", "kernel": dom.name.decode(), "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": None,
+                    "avg_launch_ms": round(dom.total_ms / dom.launches, 5), "launches": int(dom.launches),
+                    "flops_per_launch": dom.flops / dom.launches,
+                    "kernel_time_share": {k: round(v.total_ms / sum(e.total_ms for e in prof.values()), 4) for k, v in prof.items()}}
+
+    if rank == 0:
+        total_rows = world * args.steps * B
+        value = total_rows / elapsed
+        flops_eval = model.info.flops_per_position * S
+        out = {
+            "metric": "nn_evals_per_s", "value": round(value, 1), "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "%s 19x19 random weights, batch %d per GPU, NeuralNet::getOutput pass (device-resident inputs)" % (args.model, B),
+                       "gflop_per_eval": round(flops_eval / 1e9, 3), "parallelism": "replicas x%d" % world,
+                       "whole_net_tflops": round(value * flops_eval / 1e12, 1),
+                       "whole_net_frac_of_mfma_peak": round(value * flops_eval / 1e12 / (MFMA_PEAK_TFLOPS[args.dtype] * world), 4)},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model_path, 8)
+        print(json.dumps(out), flush=True)
+    handle.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -155,6 +155,22 @@ int kmx_handle_sync(kmx_handle* handle);
  * positions, batches = kmx_eval calls. */
 int kmx_handle_stats(const kmx_handle* handle, uint64_t* rows, uint64_t* batches);
 
+/* ---- instrumentation --------------------------------------------------------------- */
+/* Per-kernel-class timing with hipEvents recorded on the handle's own stream around every launch of the
+ * schedule (what bench.py's roofline figure is computed from; the reference has no equivalent, its
+ * benchmark only reports wall-clock nnEvals/s, cpp/program/playutils.cpp:834-855).
+ * flops/bytes are ALGORITHMIC totals over the recorded launches: 2*MAC*cells for convolutions
+ * (direct-convolution count on the real board area) and the tensor bytes a launch must read+write. */
+typedef struct kmx_profile_entry {
+  char name[48];
+  uint64_t launches;
+  double total_ms;
+  double flops;
+  double bytes;
+} kmx_profile_entry;
+int kmx_handle_set_profiling(kmx_handle* handle, int enabled); /* resets the accumulated profile */
+int kmx_handle_get_profile(kmx_handle* handle, kmx_profile_entry* entries, int max_entries, int* n_entries);
+
 /* ---- layer test hooks -------------------------------------------------------------- */
 /* NeuralNet::testEvaluateConv / BatchNorm / ResidualBlock / GlobalPoolingResidualBlock
  * (nninterface.h:134-180). Raw fp32 NHWC buffers in host memory; weights in the

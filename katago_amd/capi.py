@@ -73,6 +73,11 @@ class GPoolBlockDesc(ctypes.Structure):
                 ("gpool_to_bias_mul", MatMulDesc), ("mid_bn", BnActDesc), ("final_conv", ConvDesc)]
 
 
+class ProfileEntry(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 48), ("launches", ctypes.c_uint64), ("total_ms", ctypes.c_double),
+                ("flops", ctypes.c_double), ("bytes", ctypes.c_double)]
+
+
 _FP = ctypes.POINTER(ctypes.c_float)
 _FPP = ctypes.POINTER(_FP)
 _IP = ctypes.POINTER(ctypes.c_int)
@@ -99,6 +104,8 @@ SIGNATURES = {
     "kmx_handle_stream": (ctypes.c_void_p, [ctypes.c_void_p]),
     "kmx_handle_sync": (ctypes.c_int, [ctypes.c_void_p]),
     "kmx_handle_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
+    "kmx_handle_set_profiling": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "kmx_handle_get_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ProfileEntry), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "kmx_test_conv": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP]),
     "kmx_test_bnact": (ctypes.c_int, [ctypes.POINTER(BnActDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP, _FP]),
     "kmx_test_resblock": (ctypes.c_int, [ctypes.POINTER(ResBlockDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP, _FP]),
@@ -114,6 +121,13 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # torch wheels bundle their own ROCm runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7). Two HIP
+    # runtimes in one process cannot both own the GPU, so torch's must be loaded first: libkatamx.so then binds
+    # to the already-loaded soname. (torch is only plumbing here: device buffers, streams, torch.distributed.)
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch-less deployments use the system runtime
+        pass
     if not os.path.exists(p):
         raise KatamxError(KMX_ERR_INTERNAL, "%s not found: run `python -m katago_amd.build` (the HIP extension is mandatory)" % p)
     lib = ctypes.CDLL(p)

@@ -40,16 +40,21 @@ FusedConv buildFusedConv(int dtype, const std::vector<ConvSegment>& segs, std::v
   if(segs.empty()) throw Error(KMX_ERR_INTERNAL, "buildFusedConv: no segments");
   FusedConv fc;
   const ConvDesc& first = *segs[0].conv;
-  fc.ks = first.ky;
   fc.cin = first.inC;
-  if(first.ky != first.kx) throw Error(KMX_ERR_UNSUPPORTED, first.name + ": non-square convolution kernels are not supported");
+  // Segments may have different (odd, square) kernel sizes: a smaller kernel is embedded, centred, in the
+  // largest one with zero taps around it - exactly the same sums (the reference's layer tests pair a 1x1
+  // regular conv with a 3x3 gpool conv, cpp/tests/testnn.cpp:769-791).
+  fc.ks = 1;
+  for(const ConvSegment& s : segs) {
+    if(s.conv->ky != s.conv->kx) throw Error(KMX_ERR_UNSUPPORTED, s.conv->name + ": non-square convolution kernels are not supported");
+    fc.ks = std::max(fc.ks, s.conv->ky);
+  }
   if(fc.ks != 1 && fc.ks != 3 && fc.ks != 5)
     throw Error(KMX_ERR_UNSUPPORTED, first.name + ": only 1x1, 3x3 and 5x5 convolutions are supported");
   std::vector<int> offs;
   int cout = 0;
   for(const ConvSegment& s : segs) {
-    if(s.conv->ky != fc.ks || s.conv->kx != fc.ks || s.conv->inC != fc.cin)
-      throw Error(KMX_ERR_INTERNAL, "buildFusedConv: segments disagree on kernel size / input channels");
+    if(s.conv->inC != fc.cin) throw Error(KMX_ERR_INTERNAL, "buildFusedConv: segments disagree on input channels");
     offs.push_back(cout);
     cout += roundUp(s.conv->outC, 4);
   }
@@ -64,7 +69,9 @@ FusedConv buildFusedConv(int dtype, const std::vector<ConvSegment>& segs, std::v
     fc.macPerCell += (double)c.ky * c.kx * c.inC * c.outC;
     for(int chunk = 0; chunk < fc.nChunks; chunk++)
       for(int t = 0; t < nt; t++) {
-        const int ky = t / fc.ks, kx = t % fc.ks;
+        const int d = (fc.ks - c.ky) / 2;
+        const int ky = t / fc.ks - d, kx = t % fc.ks - d;
+        if(ky < 0 || ky >= c.ky || kx < 0 || kx >= c.kx) continue;  // zero tap of an embedded smaller kernel
         for(int oc = 0; oc < c.outC; oc++) {
           uint16_t* row = &w[(((size_t)chunk * nt + t) * fc.coutPad + offs[si] + oc) * WROW_HALFS];
           for(int k = 0; k < KCHUNK; k++) {
@@ -150,6 +157,11 @@ Engine::Engine(const ModelDesc& model, int nnXLen, int nnYLen, int maxBatch, int
 
 Engine::~Engine() {
   if(stream_) (void)hipStreamSynchronize(stream_);
+  for(const Pending& p : pending_) {
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  for(hipEvent_t e : eventPool_) (void)hipEventDestroy(e);
   (void)hipHostFree(hSpatial_);
   (void)hipHostFree(hGlobal_);
   (void)hipHostFree(hPolicy_);
@@ -204,7 +216,12 @@ void Engine::addConv(const FusedConv* fc, const void* in, int inStride, const fl
   a.mask = mask_.as<float>();
   if(inStride < fc->nChunks * KCHUNK) throw Error(KMX_ERR_INTERNAL, "addConv: input stride smaller than the padded channel count");
   const int dtype = dtype_, ks = fc->ks, coutPad = fc->coutPad;
-  ops_.push_back([=](int n, hipStream_t st) {
+  // algorithmic traffic: read the input once, the residual once, write each output once (16-bit elements)
+  double bytes = 2.0 * S_ * (double)fc->cin;
+  if(resid) bytes += 2.0 * S_ * (double)(a.rawEnd - a.rawBegin);
+  if(rawOut) bytes += 2.0 * S_ * (double)(a.rawEnd - a.rawBegin);
+  if(actOut) bytes += 2.0 * S_ * (double)(a.actEnd - a.actBegin);
+  addOp(ks == 1 ? "conv1x1" : ks == 3 ? "conv3x3" : "conv5x5", 2.0 * fc->macPerCell * S_, bytes, [=](int n, hipStream_t st) {
     ConvArgs b = a;
     b.N = n;
     hipCheck(launchConv(dtype, ks, chooseConvWN(ks, coutPad, n), b, st), "convolution launch");
@@ -249,7 +266,7 @@ void Engine::buildStack(const std::vector<BlockDesc>& blocks, const Stream& s, c
       ga.featOut = nullptr;
       ga.S = S_;
       const int dtype = dtype_;
-      ops_.push_back([=](int n, hipStream_t st) {
+      addOp("gpool_bias_act", 2.0 * 3 * G * R, 2.0 * S_ * (G + 2.0 * R), [=](int n, hipStream_t st) {
         GPoolArgs x = ga;
         x.N = n;
         hipCheck(launchGPoolApply(dtype, x, st), "gpool launch");
@@ -310,7 +327,7 @@ void Engine::buildSchedule(const ModelDesc& m) {
     ia.ncStride = roundUp(m.trunkC, 64);
     ia.symmetry = dSymmetry_.as<int>();
     const int dtype = dtype_;
-    ops_.push_back([=](int n, hipStream_t st) {
+    addOp("input_stage", 2.0 * gin_ * m.trunkC, S_ * (4.0 * cin_ + 2.0 * KCHUNK + 4.0), [=](int n, hipStream_t st) {
       InputArgs x = ia;
       x.N = n;
       x.spatial = curSpatial_;
@@ -365,7 +382,7 @@ void Engine::buildSchedule(const ModelDesc& m) {
     ga.featOut = polFeat_.as<float>();
     ga.S = S_;
     const int dtype = dtype_;
-    ops_.push_back([=](int n, hipStream_t st) {
+    addOp("gpool_bias_act", 2.0 * 3 * G1 * P1, 2.0 * S_ * (G1 + 2.0 * P1), [=](int n, hipStream_t st) {
       GPoolArgs x = ga;
       x.N = n;
       hipCheck(launchGPoolApply(dtype, x, st), "policy gpool launch");
@@ -391,7 +408,7 @@ void Engine::buildSchedule(const ModelDesc& m) {
     pa.X = X_;
     pa.Y = Y_;
     const int dtype = dtype_;
-    ops_.push_back([=](int n, hipStream_t st) {
+    addOp("policy_tail", 2.0 * S_ * P1 * m.numPolicyChannels, S_ * (2.0 * P1 + 4.0), [=](int n, hipStream_t st) {
       PolicyArgs x = pa;
       x.N = n;
       x.out = curPolicy_;
@@ -417,7 +434,7 @@ void Engine::buildSchedule(const ModelDesc& m) {
     va.X = X_;
     va.Y = Y_;
     const int dtype = dtype_;
-    ops_.push_back([=](int n, hipStream_t st) {
+    addOp("value_tail", 2.0 * (S_ * V1 + 3.0 * V1 * m.v2Mul.outC), S_ * (2.0 * V1 + 4.0), [=](int n, hipStream_t st) {
       ValueArgs x = va;
       x.N = n;
       x.value = curValue_;
@@ -436,7 +453,73 @@ void Engine::runSchedule(int n, const float* dSpatial, const float* dGlobal, flo
   curValue_ = dValue;
   curScore_ = dScore;
   curOwnership_ = dOwnership;
-  for(const Op& op : ops_) op(n, stream_);
+  if(!profiling_) {
+    for(const Op& op : ops_) op.fn(n, stream_);
+    return;
+  }
+  for(const Op& op : ops_) {
+    Pending p;
+    for(hipEvent_t* e : {&p.a, &p.b}) {
+      if(eventPool_.empty()) hipCheck(hipEventCreate(e), "hipEventCreate");
+      else {
+        *e = eventPool_.back();
+        eventPool_.pop_back();
+      }
+    }
+    p.cls = op.cls;
+    p.flops = op.flopsPerRow * n;
+    p.bytes = op.bytesPerRow * n;
+    hipCheck(hipEventRecord(p.a, stream_), "hipEventRecord");
+    op.fn(n, stream_);
+    hipCheck(hipEventRecord(p.b, stream_), "hipEventRecord");
+    pending_.push_back(p);
+  }
+}
+
+int Engine::opClass(const std::string& name) {
+  for(size_t i = 0; i < opClasses_.size(); i++)
+    if(opClasses_[i] == name) return (int)i;
+  opClasses_.push_back(name);
+  return (int)opClasses_.size() - 1;
+}
+void Engine::addOp(const std::string& cls, double flopsPerRow, double bytesPerRow, std::function<void(int, hipStream_t)> fn) {
+  Op op;
+  op.fn = std::move(fn);
+  op.cls = opClass(cls);
+  op.flopsPerRow = flopsPerRow;
+  op.bytesPerRow = bytesPerRow;
+  ops_.push_back(std::move(op));
+}
+void Engine::setProfiling(bool enabled) {
+  sync();
+  collectProfile();
+  profiling_ = enabled;
+  profile_.clear();
+}
+void Engine::collectProfile() {
+  if(pending_.empty()) return;
+  if(profile_.size() < opClasses_.size()) profile_.resize(opClasses_.size());
+  for(const Pending& p : pending_) {
+    float ms = 0.0f;
+    hipCheck(hipEventElapsedTime(&ms, p.a, p.b), "hipEventElapsedTime");
+    ProfileEntry& e = profile_[p.cls];
+    e.name = opClasses_[p.cls];
+    e.launches += 1;
+    e.ms += ms;
+    e.flops += p.flops;
+    e.bytes += p.bytes;
+    eventPool_.push_back(p.a);
+    eventPool_.push_back(p.b);
+  }
+  pending_.clear();
+}
+std::vector<Engine::ProfileEntry> Engine::getProfile() {
+  sync();
+  collectProfile();
+  std::vector<ProfileEntry> out;
+  for(const ProfileEntry& e : profile_)
+    if(e.launches > 0) out.push_back(e);
+  return out;
 }
 
 void Engine::sync() { hipCheck(hipStreamSynchronize(stream_), "stream synchronize"); }

@@ -87,6 +87,10 @@ class Engine {
                   float* dPolicy, float* dValue, float* dScore, float* dOwnership, bool sync);
   void sync();
 
+  void setProfiling(bool enabled);
+  struct ProfileEntry { std::string name; uint64_t launches = 0; double ms = 0, flops = 0, bytes = 0; };
+  std::vector<ProfileEntry> getProfile();  // synchronises
+
   uint64_t rowsProcessed() const { return rows_; }
   uint64_t batchesProcessed() const { return batches_; }
   int numLaunchesPerEval() const { return (int)ops_.size(); }
@@ -97,7 +101,15 @@ class Engine {
     void* act;
     int stride;
   };
-  typedef std::function<void(int, hipStream_t)> Op;
+  struct Op {
+    std::function<void(int, hipStream_t)> fn;
+    int cls;               // index into opClasses_
+    double flopsPerRow;    // algorithmic flops per evaluated position
+    double bytesPerRow;    // algorithmic HBM bytes per evaluated position
+  };
+  int opClass(const std::string& name);
+  void addOp(const std::string& cls, double flopsPerRow, double bytesPerRow, std::function<void(int, hipStream_t)> fn);
+  void collectProfile();
 
   void buildSchedule(const ModelDesc& m);
   void buildStack(const std::vector<BlockDesc>& blocks, const Stream& s, const BnDesc* bnAfter, int depth);
@@ -141,6 +153,14 @@ class Engine {
   float* curOwnership_ = nullptr;
 
   uint64_t rows_ = 0, batches_ = 0;
+
+  // profiling state
+  bool profiling_ = false;
+  std::vector<std::string> opClasses_;
+  std::vector<ProfileEntry> profile_;
+  struct Pending { hipEvent_t a, b; int cls; double flops, bytes; };
+  std::vector<Pending> pending_;
+  std::vector<hipEvent_t> eventPool_;
 };
 
 // Layer test hooks (nninterface.h:134-180) executed with the same kernels as the full net.

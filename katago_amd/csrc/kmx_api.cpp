@@ -211,6 +211,28 @@ int kmx_handle_stats(const kmx_handle* handle, uint64_t* rows, uint64_t* batches
   return KMX_OK;
 }
 
+int kmx_handle_set_profiling(kmx_handle* handle, int enabled) {
+  return guarded([&] {
+    if(!handle) throw Error(KMX_ERR_INVALID_ARG, "kmx_handle_set_profiling: null handle");
+    handle->engine->setProfiling(enabled != 0);
+  });
+}
+int kmx_handle_get_profile(kmx_handle* handle, kmx_profile_entry* entries, int max_entries, int* n_entries) {
+  return guarded([&] {
+    if(!handle || !n_entries || (max_entries > 0 && !entries)) throw Error(KMX_ERR_INVALID_ARG, "kmx_handle_get_profile: null argument");
+    std::vector<Engine::ProfileEntry> prof = handle->engine->getProfile();
+    *n_entries = (int)prof.size();
+    for(int i = 0; i < (int)prof.size() && i < max_entries; i++) {
+      memset(&entries[i], 0, sizeof(entries[i]));
+      snprintf(entries[i].name, sizeof(entries[i].name), "%s", prof[i].name.c_str());
+      entries[i].launches = prof[i].launches;
+      entries[i].total_ms = prof[i].ms;
+      entries[i].flops = prof[i].flops;
+      entries[i].bytes = prof[i].bytes;
+    }
+  });
+}
+
 static int hookDtype(int precision_mode) {
   if(precision_mode == KMX_PREC_FP32) throw Error(KMX_ERR_UNSUPPORTED, "fp32 device arithmetic is not implemented");
   int dt = dtypeForPrecision(precision_mode);

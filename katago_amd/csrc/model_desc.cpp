@@ -282,8 +282,6 @@ BlockDesc parseBlock(Reader& r, int version, int trunkC, const std::string& owne
        b.gpoolBN.c * 3 != b.gpoolToBiasMul.inC || b.midBN.c != b.regularConv.outC ||
        b.midBN.c != b.gpoolToBiasMul.outC || b.midBN.c != b.finalConv.inC)
       bad(b.name + ": gpool block channel counts are inconsistent");
-    if(b.regularConv.ky != b.gpoolConv.ky || b.regularConv.kx != b.gpoolConv.kx)
-      bad(b.name + ": gpool block regular/gpool conv sizes differ");
   }
   else if(kind == "nested_bottleneck_block") {
     b.kind = BlockKind::Nested;

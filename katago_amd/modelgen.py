@@ -33,16 +33,21 @@ ACT_NAMES = {"relu": "ACTIVATION_RELU", "mish": "ACTIVATION_MISH", "silu": "ACTI
 
 
 class _Writer:
-    def __init__(self, f, rng, act):
+    def __init__(self, f, rng, act, text=False, version=15):
+        self.version = version
         self.f = f
         self.rng = rng
         self.act = act
+        self.text = text
 
     def ln(self, s):
         self.f.write((str(s) + "\n").encode("ascii"))
 
     def floats(self, arr):
         arr = np.ascontiguousarray(arr, dtype="<f4").reshape(-1)
+        if self.text:  # .txt models: whitespace-separated decimal tokens (desc.cpp:44-51); %.9g round-trips fp32
+            self.f.write((" ".join("%.9g" % v for v in arr) + "\n").encode("ascii"))
+            return
         self.f.write(b"@BIN@")
         self.f.write(arr.tobytes())
         self.f.write(b"\n")
@@ -67,7 +72,8 @@ class _Writer:
 
     def activation(self, name, kind=None):
         self.ln(name)
-        self.ln(ACT_NAMES[kind or self.act])
+        if self.version >= 11:  # older formats have no activation-kind token: relu is implied (desc.cpp:384-402)
+            self.ln(ACT_NAMES[kind or self.act])
 
     def matmul(self, name, cin, cout, gain=1.0):
         self.ln(name)
@@ -125,12 +131,12 @@ def _nested(w, name, c, mid, gpool, with_gpool):
 
 
 def write_model(path, arch, seed=20260921, version=15, activation="mish", name=None, stem_kernel=3):
-    """Write a random-weight model file. `path` may end in .bin or .bin.gz. Returns the architecture dict."""
+    """Write a random-weight model file. `path` may end in .bin, .bin.gz, .txt or .txt.gz. Returns the architecture dict."""
     a = ARCHS[arch] if isinstance(arch, str) else arch
     rng = np.random.default_rng(seed)
     opener = gzip.open if path.endswith(".gz") else open
     with opener(path, "wb") as f:
-        w = _Writer(f, rng, activation)
+        w = _Writer(f, rng, activation, text=path.endswith(".txt") or path.endswith(".txt.gz"), version=version)
         w.ln(name or ("kmxrand-" + (arch if isinstance(arch, str) else "custom")))
         w.ln(version)
         w.ln(22)
@@ -204,7 +210,7 @@ def write_model(path, arch, seed=20260921, version=15, activation="mish", name=N
     return a
 
 
-def mac_per_position(arch, stem_kernel=3):
+def mac_per_position(arch, stem_kernel=3, version=15):
     """Direct-convolution multiply-accumulates per board point (SURVEY.md 8d / BASELINE.md section 2)."""
     a = ARCHS[arch] if isinstance(arch, str) else arch
     C, mid, gp = a["C"], a["mid"], a["gpool"]
@@ -224,5 +230,6 @@ def mac_per_position(arch, stem_kernel=3):
         else:
             total += C * mid + mid * C + ordinary(mid, mid)
             total += gpoolb(mid, mid - gp, gp) if kind == "ng" else ordinary(mid, mid)
-    total += C * a["p1"] + C * a["g1"] + a["p1"] * 2 + C * a["v1"] + a["v1"]
+    npol = 4 if version == 16 else (2 if version >= 12 else 1)
+    total += C * a["p1"] + C * a["g1"] + a["p1"] * npol + C * a["v1"] + a["v1"]
     return total

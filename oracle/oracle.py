@@ -88,8 +88,17 @@ def loadModelFile(file):
     return OracleModel(file)
 
 
+def usable_cores():
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
 def getOutput(model, nnXLen, nnYLen, rowSpatial, rowGlobal, symmetries=None, policyOptimisms=None, includeOwnerMap=True,
               numThreads=0):
+    if numThreads <= 0:
+        numThreads = usable_cores()  # never oversubscribe a cgroup-limited box with one thread per host core
     rowSpatial = np.ascontiguousarray(rowSpatial, dtype=np.float32)
     rowGlobal = np.ascontiguousarray(rowGlobal, dtype=np.float32)
     n = rowSpatial.shape[0]

@@ -1,0 +1,67 @@
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+REF = os.environ.get("KATAGO_REFERENCE", "/root/reference")
+REF_BIN_DIR = os.path.join(REPO, "oracle", "_ref")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: takes more than ~30 s on CPU")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """The HIP library and the oracle must exist; build them if a fresh checkout lacks them."""
+    from katago_amd import build as kbuild
+
+    kbuild.build(verbose=False)
+    subprocess.run(["make", "-s", "-C", os.path.join(REPO, "oracle"), "oracle"], check=True)
+
+
+@pytest.fixture(scope="session")
+def model_dir(tmp_path_factory):
+    return str(tmp_path_factory.mktemp("kmx_models"))
+
+
+@pytest.fixture(scope="session")
+def small_model(model_dir):
+    from katago_amd import modelgen
+
+    p = os.path.join(model_dir, "b3c64nbt.bin.gz")
+    modelgen.write_model(p, "b3c64nbt", seed=123)
+    return p
+
+
+def ref_binary(name):
+    """oracle/_ref/<name>: prebuilt (GPU box) or built here from the mounted reference."""
+    path = os.path.join(REF_BIN_DIR, name)
+    if not os.path.exists(path):
+        if not os.path.isdir(os.path.join(REF, "cpp")):
+            pytest.skip("%s not built and the reference tree is not mounted" % name)
+        subprocess.run(["make", "-s", "-C", os.path.join(REPO, "oracle"), "-j%d" % (os.cpu_count() or 4), "ref", "REF=" + REF],
+                       check=True, stdout=subprocess.DEVNULL)
+    return path
+
+
+def make_rows(rng, n, L=19, sizes=None):
+    """Binary V7-like feature planes on an LxL buffer; sizes[b] = (x_size, y_size) of the real board."""
+    sp = np.zeros((n, L, L, 22), dtype=np.float32)
+    for b in range(n):
+        xs, ys = sizes[b] if sizes else (L, L)
+        sp[b, :ys, :xs, 0] = 1
+        st = rng.random((ys, xs))
+        sp[b, :ys, :xs, 1] = st < 0.25
+        sp[b, :ys, :xs, 2] = (st >= 0.25) & (st < 0.5)
+        for c in range(3, 22):
+            sp[b, :ys, :xs, c] = rng.random((ys, xs)) < 0.08
+    gl = rng.normal(0, 0.5, (n, 19)).astype(np.float32)
+    return sp.reshape(n, L * L, 22), gl

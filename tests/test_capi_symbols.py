@@ -1,0 +1,42 @@
+"""The C ABI library loads (no GPU needed) and exports every symbol include/katamx.h declares."""
+import ctypes
+import os
+import re
+
+from katago_amd import capi
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(REPO, "include", "katamx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(kmx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), "libkatamx.so does not export %s" % s
+    assert sorted(capi.SIGNATURES) == syms, "capi.SIGNATURES is out of sync with include/katamx.h"
+
+
+def test_abi_version_and_errors_without_gpu():
+    lib = capi.load_library()
+    assert lib.kmx_abi_version() == 1
+    p = ctypes.c_void_p()
+    rc = lib.kmx_model_load(b"/nonexistent/model.bin.gz", b"", ctypes.byref(p))
+    assert rc == capi.KMX_ERR_IO and b"model.bin.gz" in lib.kmx_last_error()
+    rc = lib.kmx_model_load(b"/nonexistent/model.xyz", b"", ctypes.byref(p))
+    assert rc == capi.KMX_ERR_MODEL
+
+
+def test_no_oracle_in_product():
+    """The product path must never route through the oracle (or any CPU fallback)."""
+    for root, _, files in os.walk(os.path.join(REPO, "katago_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")):
+                src = open(os.path.join(root, f), errors="replace").read()
+                assert "okmx_" not in src and "kmx_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f

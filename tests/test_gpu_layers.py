@@ -1,0 +1,93 @@
+"""-m gpu: the HIP kernels behind the layer test hooks (NeuralNet::testEvaluate*, nninterface.h:134-180) against
+the oracle on seeded inputs. Pass bar = the reference's own reduced-precision tolerance for these hooks,
+|x-y| < 0.03*max(|x|,|y|,3) (cpp/tests/testnn.cpp:8-15); typical errors are printed and are ~10x smaller."""
+import numpy as np
+import pytest
+
+from katago_amd import capi, nninterface as nn
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def close(got, want, scale=0.03):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    tol = scale * np.maximum(np.maximum(np.abs(got), np.abs(want)), 3.0)
+    err = np.abs(got - want)
+    print("max err %.4g rms %.4g scale %.3g" % (err.max(), np.sqrt((err ** 2).mean()), np.abs(want).max()))
+    return bool(np.isfinite(got).all() and (err < tol).all())
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("ks,cin,cout,X,Y,n", [(1, 32, 64, 19, 19, 2), (3, 32, 64, 19, 19, 2), (3, 192, 192, 19, 19, 2),
+                                               (1, 384, 192, 19, 19, 1), (1, 192, 384, 19, 19, 1), (3, 22, 384, 19, 19, 1),
+                                               (5, 22, 96, 19, 19, 1), (3, 64, 48, 9, 13, 3), (3, 40, 20, 13, 9, 2),
+                                               (1, 96, 4, 7, 7, 2), (3, 128, 192, 19, 19, 1), (3, 5, 3, 2, 2, 4), (1, 1, 1, 19, 2, 1)])
+def test_conv(dtype, ks, cin, cout, X, Y, n):
+    rng = np.random.default_rng(ks * 1000 + cin + cout)
+    w = (rng.standard_normal((cout, cin, ks, ks)) / np.sqrt(ks * ks * cin)).astype(np.float32)
+    x = rng.standard_normal((n, Y, X, cin)).astype(np.float32)
+    x += (np.arange(cin) % 7 - 3)[None, None, None, :] * 0.1 + (np.arange(X) % 5)[None, None, :, None] * 0.05  # asymmetric
+    assert close(nn.testEvaluateConv(w, n, X, Y, dtype, x), oracle.testEvaluateConv(w, n, X, Y, x))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("act", [capi.ACT_IDENTITY, capi.ACT_RELU, capi.ACT_MISH, capi.ACT_SILU])
+def test_bnact_with_mask(dtype, act):
+    rng = np.random.default_rng(act)
+    n, X, Y, C = 3, 9, 7, 20
+    x = (rng.standard_normal((n, Y, X, C)) * 3).astype(np.float32)
+    x[0, 0, 0, :] = 25.0  # mish linearised region (x > 20)
+    x[0, 0, 1, :] = -30.0
+    mask = (rng.random((n, Y, X)) < 0.8).astype(np.float32)
+    sc, bi = rng.uniform(0.5, 1.5, C).astype(np.float32), rng.normal(0, 0.3, C).astype(np.float32)
+    got = nn.testEvaluateBatchNorm(sc, bi, act, n, X, Y, dtype, x, mask)
+    assert close(got, oracle.testEvaluateBatchNorm(sc, bi, act, n, X, Y, x, mask))
+    assert (got[mask == 0] == 0).all()  # masked cells are exactly zero (eigenbackend.cpp:739-762)
+
+
+def _bn(rng, c, act):
+    return (rng.uniform(0.6, 1.4, c).astype(np.float32), rng.normal(0, 0.25, c).astype(np.float32), act)
+
+
+def _cw(rng, co, ci, k, g=1.0):
+    return (rng.standard_normal((co, ci, k, k)) * g * np.sqrt(2.0 / (k * k * ci))).astype(np.float32)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("C,M,X,Y,n,act", [(64, 64, 19, 19, 2, capi.ACT_MISH), (192, 192, 19, 19, 1, capi.ACT_MISH),
+                                           (96, 96, 13, 13, 3, capi.ACT_RELU), (32, 48, 9, 19, 2, capi.ACT_SILU)])
+def test_residual_block(dtype, C, M, X, Y, n, act):
+    rng = np.random.default_rng(C + M)
+    blk = dict(pre=_bn(rng, C, act), conv1=_cw(rng, M, C, 3), mid=_bn(rng, M, act), conv2=_cw(rng, C, M, 3, 0.5))
+    mask = np.ones((n, Y, X), np.float32)
+    mask[0, :, X - 3:] = 0
+    x = rng.standard_normal((n, Y, X, C)).astype(np.float32) * mask[..., None]
+    got = nn.testEvaluateResidualBlock(blk, n, X, Y, dtype, x, mask)
+    want = oracle.testEvaluateResidualBlock(blk, n, X, Y, x, mask)
+    on = mask > 0  # off-board lanes of the trunk are don't-care
+    assert close(got[on], want[on])
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("C,R,G,X,Y,n,kr", [(64, 32, 16, 13, 13, 2, 3), (192, 128, 64, 19, 19, 1, 3), (32, 20, 8, 9, 9, 2, 1)])
+def test_gpool_block(dtype, C, R, G, X, Y, n, kr):
+    """kr=1: regular conv 1x1 next to a 3x3 gpool conv, as in the reference's own vector (testnn.cpp:769-791)."""
+    rng = np.random.default_rng(C + R + G)
+    blk = dict(pre=_bn(rng, C, capi.ACT_MISH), convr=_cw(rng, R, C, kr), convg=_cw(rng, G, C, 3), gbn=_bn(rng, G, capi.ACT_MISH),
+               gmul=(rng.standard_normal((3 * G, R)) * 0.5 / np.sqrt(3 * G)).astype(np.float32), mid=_bn(rng, R, capi.ACT_MISH),
+               conv2=_cw(rng, C, R, 3, 0.5))
+    mask = np.ones((n, Y, X), np.float32)
+    mask[0, Y - 4:, :] = 0
+    x = rng.standard_normal((n, Y, X, C)).astype(np.float32) * mask[..., None]
+    got = nn.testEvaluateGlobalPoolingResidualBlock(blk, n, X, Y, dtype, x, mask)
+    want = oracle.testEvaluateGlobalPoolingResidualBlock(blk, n, X, Y, x, mask)
+    on = mask > 0
+    assert close(got[on], want[on])
+
+
+def test_fp32_mode_is_refused_not_emulated():
+    rng = np.random.default_rng(0)
+    with pytest.raises(nn.KatamxError) as e:
+        nn.testEvaluateConv(_cw(rng, 4, 4, 3), 1, 5, 5, "fp32", rng.standard_normal((1, 5, 5, 4)).astype(np.float32))
+    assert e.value.code == capi.KMX_ERR_UNSUPPORTED

@@ -1,0 +1,163 @@
+"""-m gpu: the whole hot path through the C ABI (kmx_eval == NeuralNet::getOutput) against the oracle and the
+committed reference-torch golden vectors; size-independent properties at the BASELINE batch size."""
+import os
+
+import numpy as np
+import pytest
+
+import parity_stats as ps
+from conftest import REPO, make_rows
+from katago_amd import capi, modelgen, nninterface as nn
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(REPO, "tests", "golden")
+_ORACLE_CACHE = {}
+
+
+def oracle_outputs(key, path, sp, gl, sym, opt=None):
+    """The oracle is dtype-independent: compute it once per case, not once per device precision."""
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = oracle.getOutput(oracle.loadModelFile(path), 19, 19, sp, gl, sym, opt)
+    return _ORACLE_CACHE[key]
+
+
+def outputs_close(got, want, mask, rel, ab):
+    n = mask.shape[0]
+    full = np.concatenate([mask, np.ones((n, 1), bool)], axis=1)
+    ok = True
+    for name, g, w in (("policy", got["policy"][full], want["policy"][full]), ("value", got["value"], want["value"]),
+                       ("score", got["score"], want["score"]), ("ownership", got["ownership"][mask], want["ownership"][mask])):
+        err = np.abs(g.astype(np.float64) - w)
+        lim = ab + rel * np.maximum(np.abs(g), np.abs(w))
+        print("%-9s max err %.4g (scale %.3g)" % (name, err.max(), np.abs(w).max()))
+        ok = ok and bool(np.isfinite(g).all() and (err <= lim).all())
+    return ok
+
+
+@pytest.fixture(scope="module")
+def ctx19():
+    nn.globalInitialize()
+    c = {d: nn.createComputeContext([0], 19, 19, precision=d) for d in ("bf16", "fp16")}
+    yield c
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_reference_torch_golden(ctx19, dtype):
+    """HIP path vs the outputs of the reference PyTorch model (tools/gen_torch_golden.py): 13x9 and 9x9 boards in a
+    19x19 buffer exercise the mask path; optimism 0/1 select policy channel 0/1."""
+    v = np.load(os.path.join(GOLD, "torch_nbt_vectors.npz"))
+    h = nn.createComputeHandle(ctx19[dtype], nn.loadModelFile(os.path.join(GOLD, "torch_nbt.bin.gz")), 8)
+    mask = v["spatial_nhwc"][:, :, 0] > 0
+    for opt in (0.0, 1.0):
+        got = nn.getOutput(h, v["spatial_nhwc"], v["glob"], None, np.full(4, opt, np.float32))
+        want = dict(policy=v["policy"][:, int(opt), :], value=v["value"], score=v["score"], ownership=v["ownership"])
+        assert outputs_close(got, want, mask, 0.03, 0.08 if dtype == "bf16" else 0.02)
+    h.close()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("arch,version,act,stem", [("b3c64nbt", 15, "mish", 3), ("b6c96", 11, "relu", 5), ("b10c128", 14, "mish", 3),
+                                                   ("b2c32nbt", 9, "relu", 3), ("b2c32nbt", 16, "silu", 3), ("b18c384nbt", 15, "mish", 3)])
+def test_model_vs_oracle(ctx19, model_dir, dtype, arch, version, act, stem):
+    p = os.path.join(model_dir, "m_%s_v%d.bin.gz" % (arch, version))
+    if not os.path.exists(p):
+        modelgen.write_model(p, arch, version=version, activation=act, stem_kernel=stem, seed=version)
+    rng = np.random.default_rng(version)
+    n = 6
+    sizes = [(19, 19), (19, 19), (13, 13), (9, 9), (19, 10), (7, 11)]
+    sp, gl = make_rows(rng, n, 19, sizes)
+    sym = np.array([0, 5, 3, 6, 7, 1], np.int32)
+    opt = np.array([0, 0.3, 1.0, 0.0, 0.5, 0.2], np.float32)
+    want = oracle_outputs(("model", arch, version), p, sp, gl, sym, opt)
+    h = nn.createComputeHandle(ctx19[dtype], nn.loadModelFile(p), 16)
+    got = nn.getOutput(h, sp, gl, sym, opt)
+    mask = sp[:, :, 0] > 0
+    deep = arch == "b18c384nbt"
+    rel, ab = (0.05, 0.15 if deep else 0.08) if dtype == "bf16" else (0.02, 0.05 if deep else 0.02)
+    assert outputs_close(got, want, mask, rel, ab)
+    # rows are independent: a batch of 1 reproduces row 0 bit for bit, whatever else shares the batch
+    one = nn.getOutput(h, sp[:1], gl[:1], sym[:1], opt[:1])
+    assert np.array_equal(one["policy"][0], got["policy"][0]) and np.array_equal(one["value"][0], got["value"][0])
+    # counters (nneval.cpp:712-713): rows, batches
+    assert h.stats() == (n + 1, 2)
+    # includeOwnerMap=false rows skip the ownership copy
+    noown = nn.getOutput(h, sp[:2], gl[:2], sym[:2], opt[:2], includeOwnerMap=False)
+    assert noown["ownership"] is None and np.array_equal(noown["policy"], got["policy"][:2])
+    with pytest.raises(nn.KatamxError):
+        nn.getOutput(h, np.repeat(sp, 3, 0), np.repeat(gl, 3, 0))  # 18 rows > maxBatchSize 16
+    h.close()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_error_statistics_reference_thresholds(ctx19, model_dir, dtype):
+    """The reference's cross-backend acceptance test (testnnevalcanary.cpp:573-829) restated: 99th percentile and max
+    error of winrate / lead / score / top policy / policy KL over a batch of positions, against its thresholds for
+    reduced-precision backends (:806-807)."""
+    results = {}
+    for arch, npos in (("b10c128", 192), ("b18c384nbt", 48)):
+        p = os.path.join(model_dir, "stat_%s.bin.gz" % arch)
+        if not os.path.exists(p):
+            modelgen.write_model(p, arch, seed=77)
+        rng = np.random.default_rng(99)
+        sizes = [(19, 19)] * (npos * 3 // 4) + [(13, 13)] * (npos // 8) + [(9, 9)] * (npos - npos * 3 // 4 - npos // 8)
+        sp, gl = make_rows(rng, npos, 19, sizes)
+        sym = rng.integers(0, 8, npos).astype(np.int32)
+        model = nn.loadModelFile(p)
+        info = nn.getModelDesc(model)["postProcessParams"]
+        h = nn.createComputeHandle(ctx19[dtype], model, 64)
+        got = {k: [] for k in ("policy", "value", "score", "ownership")}
+        for i in range(0, npos, 64):  # several batches, ragged tail
+            o = nn.getOutput(h, sp[i:i + 64], gl[i:i + 64], sym[i:i + 64])
+            for k in got:
+                got[k].append(o[k])
+        got = {k: np.concatenate(v) for k, v in got.items()}
+        want = oracle_outputs(("stats", arch), p, sp, gl, sym)
+        stats = ps.error_stats(ps.postprocess(want, sp, info), ps.postprocess(got, sp, info))
+        print(arch, dtype, {k: float("%.4g" % v) for k, v in stats.items()})
+        results[arch] = ps.check(stats, ps.LIMITS_REDUCED)
+        h.close()
+    assert not any(results.values()), results
+
+
+def test_full_batch_properties(ctx19, model_dir):
+    """BASELINE size (b18c384nbt, batch 256): finite outputs; every row equals the same position evaluated in a
+    small batch (bit exact: rows never interact); evaluating with symmetry s equals evaluating the pre-symmetrised
+    board with symmetry 0 and un-symmetrising the outputs."""
+    p = os.path.join(model_dir, "prop_b18.bin")
+    if not os.path.exists(p):
+        modelgen.write_model(p, "b18c384nbt", seed=5)
+    rng = np.random.default_rng(1)
+    base, gbase = make_rows(rng, 8)
+    sp, gl = np.tile(base, (32, 1, 1)), np.tile(gbase, (32, 1))
+    sym = (np.arange(256) // 8 % 8).astype(np.int32)
+    h = nn.createComputeHandle(ctx19["bf16"], nn.loadModelFile(p), 256)
+    big = nn.getOutput(h, sp, gl, sym)
+    assert all(np.isfinite(big[k]).all() for k in big)
+    small = nn.getOutput(h, sp[:8], gl[:8], sym[:8])
+    for k in big:
+        assert np.array_equal(big[k][:8], small[k])
+    # row r (symmetry s) vs the explicitly symmetrised board at symmetry 0
+    for s in (1, 2, 4, 7):
+        r = 8 * s
+        img = oracle.copyWithSymmetry(sp[r].reshape(19, 19, 22), s, False).reshape(1, 361, 22)
+        o = nn.getOutput(h, img, gl[r:r + 1], [0])
+        pol = oracle.copyWithSymmetry(o["policy"][0, :361].reshape(19, 19, 1), s, True).reshape(361)
+        assert np.array_equal(pol, big["policy"][r, :361]) and np.array_equal(o["value"][0], big["value"][r])
+    h.close()
+
+
+def test_handle_errors(ctx19, small_model):
+    model = nn.loadModelFile(small_model)
+    with pytest.raises(nn.KatamxError):
+        nn.createComputeHandle(ctx19["bf16"], model, 0)
+    with pytest.raises(nn.KatamxError) as e:
+        nn.createComputeContext([0], 19, 19, precision="fp32")
+    assert e.value.code == capi.KMX_ERR_UNSUPPORTED
+    with pytest.raises(nn.KatamxError):
+        nn.createComputeContext([0], 25, 19)
+    h = nn.createComputeHandle(ctx19["bf16"], model, 4)
+    sp, gl = make_rows(np.random.default_rng(0), 2)
+    with pytest.raises(nn.KatamxError):
+        nn.getOutput(h, sp, gl, [0, 9])  # symmetry out of range
+    h.close()
