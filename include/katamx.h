@@ -170,6 +170,11 @@ typedef struct kmx_profile_entry {
 } kmx_profile_entry;
 int kmx_handle_set_profiling(kmx_handle* handle, int enabled); /* resets the accumulated profile */
 int kmx_handle_get_profile(kmx_handle* handle, kmx_profile_entry* entries, int max_entries, int* n_entries);
+/* Average duration (ms, hipEvents) of one launch of the bf16 convolution kernel on synthetic data: kernel size ks,
+ * wn = 32-channel tiles per wave, variant = 0 (product kernel) or depth*1000 + ablation mask (conv_kernel.h),
+ * epilogue_mode 0 = BN+act output, 1 = residual + raw + BN+act outputs. Kernel tuning instrumentation. */
+int kmx_bench_conv(int ks, int wn, int variant, int cin, int cout, int batch, int nn_x_len, int nn_y_len,
+                   int epilogue_mode, int iters, double* avg_ms);
 
 /* ---- layer test hooks -------------------------------------------------------------- */
 /* NeuralNet::testEvaluateConv / BatchNorm / ResidualBlock / GlobalPoolingResidualBlock

@@ -48,9 +48,9 @@ __device__ __forceinline__ float actApply(float x, int kind) {
   if(kind == KMX_ACT_MISH) {
     float e = __expf(fminf(x, 20.0f));
     float n = e * (e + 2.0f);
-    return x * (n / (n + 2.0f));
+    return x * n * __builtin_amdgcn_rcpf(n + 2.0f);  // v_rcp_f32 (1 ulp): outputs are rounded to 16 bits anyway
   }
-  if(kind == KMX_ACT_SILU) return x / (1.0f + __expf(-x));
+  if(kind == KMX_ACT_SILU) return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
   return x;
 }
 

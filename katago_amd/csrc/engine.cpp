@@ -56,7 +56,7 @@ FusedConv buildFusedConv(int dtype, const std::vector<ConvSegment>& segs, std::v
   for(const ConvSegment& s : segs) {
     if(s.conv->inC != fc.cin) throw Error(KMX_ERR_INTERNAL, "buildFusedConv: segments disagree on input channels");
     offs.push_back(cout);
-    cout += roundUp(s.conv->outC, 4);
+    cout += roundUp(s.conv->outC, 8);  // segment starts on 8-channel boundaries: the epilogue moves 16-byte pieces
   }
   fc.cout = cout;
   fc.coutPad = roundUp(cout, 64);
@@ -680,7 +680,7 @@ void testConv(int dtype, const kmx_conv_desc* d, int batch, int X, int Y, const 
   int inStride, outStride = roundUp(c.outC, 32);
   DevBuf x = h.toDevice(in, c.inC, &inStride);
   DevBuf y((size_t)batch * h.S * outStride * 2);
-  h.conv(fc, x.get(), inStride, nullptr, 0, y.get(), outStride, 0, roundUp(c.outC, 4), nullptr, 0, 0, 0, KMX_ACT_IDENTITY);
+  h.conv(fc, x.get(), inStride, nullptr, 0, y.get(), outStride, 0, roundUp(c.outC, 8), nullptr, 0, 0, 0, KMX_ACT_IDENTITY);
   h.toHost(y, outStride, c.outC, out);
 }
 
@@ -708,7 +708,7 @@ void testResBlock(int dtype, const kmx_resblock_desc* d, int batch, int X, int Y
   const int midStride = roundUp(c1.outC, 32);
   DevBuf mid((size_t)batch * h.S * midStride * 2);
   h.conv(f1, act.get(), stride, nullptr, 0, nullptr, 0, 0, 0, mid.get(), midStride, 0, f1.coutPad, midBN.act);
-  h.conv(f2, mid.get(), midStride, raw.get(), stride, raw.get(), stride, 0, roundUp(C, 4), nullptr, 0, 0, 0, KMX_ACT_IDENTITY);
+  h.conv(f2, mid.get(), midStride, raw.get(), stride, raw.get(), stride, 0, roundUp(C, 8), nullptr, 0, 0, 0, KMX_ACT_IDENTITY);
   h.toHost(raw, stride, C, out);
 }
 
@@ -745,7 +745,7 @@ void testGPoolBlock(int dtype, const kmx_gpoolblock_desc* d, int batch, int X, i
   ga.w = w.as<float>(); ga.scale = sc.as<float>(); ga.bias = bi.as<float>(); ga.actKind = midBN.act;
   ga.mask = h.mask.as<float>(); ga.maskSum = dms.as<float>(); ga.N = batch; ga.S = h.S;
   hipCheck(launchGPoolApply(dtype, ga, h.st), "gpool launch");
-  h.conv(f2, r.get(), rStride, raw.get(), stride, raw.get(), stride, 0, roundUp(C, 4), nullptr, 0, 0, 0, KMX_ACT_IDENTITY);
+  h.conv(f2, r.get(), rStride, raw.get(), stride, raw.get(), stride, 0, roundUp(C, 8), nullptr, 0, 0, 0, KMX_ACT_IDENTITY);
   h.toHost(raw, stride, C, out);
 }
 

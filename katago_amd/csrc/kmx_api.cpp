@@ -12,6 +12,10 @@
 
 using namespace kmx;
 
+namespace kmx {
+double benchConv(int ks, int wn, int variant, int cin, int cout, int batch, int X, int Y, int epilogueMode, int iters);  // conv_bench.hip
+}
+
 struct kmx_model {
   std::unique_ptr<ModelDesc> desc;
 };
@@ -230,6 +234,15 @@ int kmx_handle_get_profile(kmx_handle* handle, kmx_profile_entry* entries, int m
       entries[i].flops = prof[i].flops;
       entries[i].bytes = prof[i].bytes;
     }
+  });
+}
+
+int kmx_bench_conv(int ks, int wn, int variant, int cin, int cout, int batch, int nn_x_len, int nn_y_len, int epilogue_mode,
+                   int iters, double* avg_ms) {
+  return guarded([&] {
+    if(!avg_ms || iters < 1 || batch < 1 || cin < 1 || cout < 1) throw Error(KMX_ERR_INVALID_ARG, "kmx_bench_conv: bad argument");
+    (void)deviceCountOrThrow();
+    *avg_ms = benchConv(ks, wn, variant, cin, cout, batch, nn_x_len, nn_y_len, epilogue_mode, iters);
   });
 }
 

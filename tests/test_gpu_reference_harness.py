@@ -41,8 +41,27 @@ def test_real_net_tiny_board_golden_on_hip():
     rc, out = run("runnnontinyboardtest", G170, "true", "true", "3", "true")
     assert rc == 0, out[-3000:]
     gold = open(os.path.join(REPO, "tests", "golden", "ref_runNNOnTinyBoardTest.txt")).read()
-    num = lambda t: [float(x) for l in t.splitlines() if not l.startswith(":") and "Hash" not in l for x in re.findall(r"-?\d+\.?\d*", l)]
-    a, b = num(out), num(gold)
-    assert len(a) == len(b) and len(a) > 60
-    for u, v in zip(a, b):  # printed as probabilities %, points, or per-mille
-        assert abs(u - v) <= max(0.6, 0.03 * abs(v)) if abs(v) < 100 else abs(u - v) <= 25, (u, v)
+
+    def parse(t):
+        lines = [l for l in t.splitlines() if l.strip() and not l.startswith(":")]
+        scal = {}
+        for l in lines:
+            m = re.match(r"(Win|Loss|NoResult|ScoreMean|ScoreMeanSq|Lead)\s+(-?[\d.]+)", l)
+            if m:
+                scal[m.group(1)] = float(m.group(2))
+        k = next(i for i, l in enumerate(lines) if l.startswith("Pass"))
+        grid = lambda rows: [float(x) if x != "-" else None for l in rows for x in l.split()]
+        return scal, float(lines[k].split()[1]), grid(lines[k + 1:k + 6]), grid(lines[k + 6:k + 11])
+
+    sa, passa, pola, owna = parse(out)
+    sb, passb, polb, ownb = parse(gold)
+    # 16-bit device arithmetic against an fp32 golden: value within 1.5 %, score/lead within 0.5 point,
+    # policy within 1.5 % (printed per-mille), ownership within 0.025 (printed per-mille)
+    assert abs(sa["Win"] - sb["Win"]) <= 1.5 and abs(sa["Loss"] - sb["Loss"]) <= 1.5 and abs(sa["NoResult"] - sb["NoResult"]) <= 0.5
+    assert abs(sa["ScoreMean"] - sb["ScoreMean"]) <= 0.5 and abs(sa["Lead"] - sb["Lead"]) <= 0.5
+    assert abs(sa["ScoreMeanSq"] - sb["ScoreMeanSq"]) <= 0.05 * sb["ScoreMeanSq"]
+    assert abs(passa - passb) <= 15 and len(pola) == len(polb) == 25 and len(owna) == len(ownb) == 25
+    for u, v in zip(pola, polb):
+        assert (u is None) == (v is None) and (u is None or abs(u - v) <= 15), (u, v)  # same legality pattern
+    for u, v in zip(owna, ownb):
+        assert abs(u - v) <= 25, (u, v)
