@@ -17,9 +17,9 @@ hipError_t launchVariant(int ks, int wn, int variant, const ConvArgs& a, hipStre
 #define V(KS_, WN_, D_, ABL_) \
   if(ks == KS_ && wn == WN_ && variant == D_ * 1000 + ABL_) return launchOne<TR, KS_, WN_, D_, ABL_>(a, st);
   V(3, 3, 1, 0) V(3, 3, 2, 0) V(3, 3, 3, 0)
-  V(3, 3, 2, 1) V(3, 3, 2, 2) V(3, 3, 2, 4) V(3, 3, 2, 5) V(3, 3, 2, 12) V(3, 3, 2, 13) V(3, 3, 2, 16) V(3, 3, 2, 32)
+  V(3, 3, 2, 1) V(3, 3, 2, 2) V(3, 3, 2, 4) V(3, 3, 2, 5) V(3, 3, 2, 12) V(3, 3, 2, 13) V(3, 3, 2, 16) V(3, 3, 2, 32) V(3, 3, 2, 64) V(3, 3, 2, 192) V(3, 3, 2, 65) V(3, 3, 2, 193) V(3, 3, 2, 80) V(3, 3, 2, 256) V(3, 3, 2, 512) V(3, 3, 2, 1024) V(3, 3, 2, 1536)
   V(3, 2, 2, 0) V(3, 1, 2, 0) V(3, 1, 3, 0)
-  V(1, 3, 1, 0) V(1, 3, 2, 0) V(1, 3, 2, 1) V(1, 3, 2, 2) V(1, 3, 2, 4) V(1, 3, 2, 5) V(1, 3, 2, 32)
+  V(1, 3, 1, 0) V(1, 3, 2, 0) V(1, 3, 2, 1) V(1, 3, 2, 2) V(1, 3, 2, 4) V(1, 3, 2, 5) V(1, 3, 2, 32) V(1, 3, 2, 256) V(1, 3, 2, 257)
   V(1, 1, 2, 0) V(1, 1, 3, 0) V(1, 2, 2, 0)
 #undef V
   return hipErrorInvalidValue;

@@ -41,7 +41,7 @@ constexpr int SLACK_BYTES = NWAVES * 1024;
 constexpr int MASK_BYTES = NWAVES * 64 * 4;  // the board's mask (<= 361 floats) copied once per work-group
 
 // ablation switches (conv_bench.hip only; 0 in the product)
-enum { ABL_NO_EPILOGUE = 1, ABL_NO_COMPUTE = 2, ABL_NO_DMA = 4, ABL_NO_LDS_READ = 8, ABL_SETPRIO = 16, ABL_DIRECT_EPILOGUE = 32 };
+enum { ABL_NO_EPILOGUE = 1, ABL_NO_COMPUTE = 2, ABL_NO_DMA = 4, ABL_NO_LDS_READ = 8, ABL_SETPRIO = 16, ABL_DIRECT_EPILOGUE = 32, ABL_ORDER2 = 64, ABL_SGB = 128, ABL_PINGPONG = 256, ABL_EPI_NOACT = 512, ABL_EPI_NOSTORE = 1024 };
 
 template <int KS>
 struct ConvGeom {
@@ -228,6 +228,19 @@ __global__ __launch_bounds__(NTHREADS) void convMfmaKernel(const ConvArgs a) {
     }
   }
 
+  // ---- ping-pong schedule (ABL_PINGPONG) --------------------------------------------------------------------------
+  // With one barrier per step all eight waves run [requests, fragment reads, 18 MFMAs] in phase, and the matrix pipe
+  // idles while both waves of a SIMD sit in their load segment (measured: MFMA busy 29 %, 44 % of wave time in waits).
+  // Ping-pong keeps ONE instruction stream but splits every step in two segments, [requests + fragment reads] and
+  // [MFMAs], each behind its own barrier, and lets waves 4-7 (the SIMD partners of waves 0-3) enter the loop one
+  // barrier late: whenever one wave of a SIMD is in a load segment its partner is in an MFMA segment. The waits
+  // precede BOTH barriers because the late group must have its share of slab s landed by the barrier that releases the
+  // early group's reads of slab s, which is the late group's pre-MFMA barrier; this needs D >= 2.
+  constexpr bool PP = (ABL & ABL_PINGPONG) != 0;
+  static_assert(!PP || D >= 2, "ping-pong needs a pipeline depth of at least 2");
+  const int grp = wave >> 2;
+  if(PP && grp == 1) __builtin_amdgcn_s_barrier();
+  {
   int step = 0;
   for(int chunk = 0; chunk < nChunks; chunk++) {
     const char* const curA = bufA + (chunk % P::NSA) * G::ACT_BYTES;
@@ -238,18 +251,19 @@ __global__ __launch_bounds__(NTHREADS) void convMfmaKernel(const ConvArgs a) {
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
 
-      // (2) requests for step + D
-      issueW(step + D);
-      if(SPREAD) {
-        issueA(t < NPA ? chunk + 1 : nChunks, t < NPA ? t : 0, srcOff[t < NPA ? t : 0]);
-      }
-      else {
+      // (2) requests for step + D   (3) MFMA over the 32 input channels of this (chunk, tap)
+      auto requests = [&]() {
+        issueW(step + D);
+        if(SPREAD) {
+          issueA(t < NPA ? chunk + 1 : nChunks, t < NPA ? t : 0, srcOff[t < NPA ? t : 0]);
+        }
+        else {
 #pragma unroll
-        for(int j = 0; j < NPA; j++) issueA(chunk + D, j, srcOff[j]);
-      }
-
-      // (3) MFMA over the 32 input channels of this (chunk, tap)
+          for(int j = 0; j < NPA; j++) issueA(chunk + D, j, srcOff[j]);
+        }
+      };
       if(waveActive && !(ABL & ABL_NO_COMPUTE)) {
+        if(!(ABL & ABL_ORDER2)) requests();
         const int dy = t / KS - HALO, dx = t % KS - HALO;
         const char* const aTap = curA + (dy * W2 + dx) * ROWB;
         const char* const wCur = bufW + (step % P::NSW) * WG::W_BYTES + wOff;
@@ -276,17 +290,47 @@ __global__ __launch_bounds__(NTHREADS) void convMfmaKernel(const ConvArgs a) {
             for(int pt = 0; pt < MT; pt++) af[kk][pt] = *(const V8*)(aTap + aOff[pt] + kk * 32);
           }
         }
-        if(ABL & ABL_SETPRIO) __builtin_amdgcn_s_setprio(1);
+        // ORDER2: the DMA requests come after the fragment reads in program order (they never touch the buffers
+        // being read), so the scheduler may sink their address arithmetic and issue slots underneath the MFMAs
+        if(ABL & ABL_ORDER2) requests();
+        if(PP) {
+          waitVm<P::VMCNT>();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragment reads retire in the load segment, not the MFMA one
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        }
+        if(ABL & (ABL_SETPRIO | ABL_PINGPONG)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for(int kk = 0; kk < 2; kk++)
 #pragma unroll
           for(int ct = 0; ct < WN; ct++)
 #pragma unroll
             for(int pt = 0; pt < MT; pt++) acc[ct][pt] = TR::mfma(wf[kk][ct], af[kk][pt], acc[ct][pt]);
-        if(ABL & ABL_SETPRIO) __builtin_amdgcn_s_setprio(0);
+        if(ABL & (ABL_SETPRIO | ABL_PINGPONG)) __builtin_amdgcn_s_setprio(0);
+        if(ABL & ABL_SGB) {
+          // one MFMA, then a slice of the request code, repeated; the tail of the MFMAs follows
+#pragma unroll
+          for(int r = 0; r < 3; r++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);  // VALU
+            __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);  // SALU
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // VMEM
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 2 * WN * MT - 3, 0);
+        }
+      }
+      else {
+        requests();
+        if(PP) {
+          waitVm<P::VMCNT>();
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        }
       }
     }
   }
+  }  // schedule
+  if(PP && grp == 0) __builtin_amdgcn_s_barrier();
   if(!(ABL & ABL_NO_DMA)) waitVm<0>();  // retire the trailing dummies before the LDS is reused / the wave exits
 
   // ---- epilogue ----
@@ -407,13 +451,32 @@ __global__ __launch_bounds__(NTHREADS) void convMfmaKernel(const ConvArgs a) {
         V8 o;
 #pragma unroll
         for(int i = 0; i < 8; i++) o[i] = TR::fromFloat(v[i]);
+        if(ABL & ABL_EPI_NOSTORE) asm volatile("" ::"v"(o)); else
         *(V8*)((T*)a.rawOut + gcell * a.rawC + (c8 - a.rawBegin)) = o;
       }
       if(inAct) {
         const float maskVal = maskBoard[cell];
         V8 o;
+        // the activation kind is uniform for the launch: branch ONCE per row, not per element (a per-element switch
+        // compiles to every activation being evaluated and selected - measured 12 us of a 20 us epilogue)
+        const int kind = (ABL & ABL_EPI_NOACT) ? KMX_ACT_IDENTITY : a.actKind;
+        if(kind == KMX_ACT_MISH) {
 #pragma unroll
-        for(int i = 0; i < 8; i++) o[i] = TR::fromFloat(actApply(v[i] * sc[i] + bi[i], a.actKind) * maskVal);
+          for(int i = 0; i < 8; i++) o[i] = TR::fromFloat(actMish(v[i] * sc[i] + bi[i]) * maskVal);
+        }
+        else if(kind == KMX_ACT_RELU) {
+#pragma unroll
+          for(int i = 0; i < 8; i++) o[i] = TR::fromFloat(fmaxf(v[i] * sc[i] + bi[i], 0.0f) * maskVal);
+        }
+        else if(kind == KMX_ACT_SILU) {
+#pragma unroll
+          for(int i = 0; i < 8; i++) o[i] = TR::fromFloat(actSilu(v[i] * sc[i] + bi[i]) * maskVal);
+        }
+        else {
+#pragma unroll
+          for(int i = 0; i < 8; i++) o[i] = TR::fromFloat((v[i] * sc[i] + bi[i]) * maskVal);
+        }
+        if(ABL & ABL_EPI_NOSTORE) asm volatile("" ::"v"(o)); else
         *(V8*)((T*)a.actOut + gcell * a.actC + (c8 - a.actBegin)) = o;
       }
     }

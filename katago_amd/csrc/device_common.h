@@ -43,14 +43,19 @@ struct TraitsBF16 {
 // Activations in fp32. Mish follows the reference's form x*tanh(softplus(x)) with softplus linearised
 // above 20 (eigenbackend.cpp:754): tanh(log1p(e)) = (e^2+2e)/(e^2+2e+2), e = exp(min(x,20)); for x > 20
 // the tanh argument exceeds 20 and tanh saturates to exactly 1 in fp32, as does this rational form.
+__device__ __forceinline__ float actMish(float x) {
+  // e = exp(min(x,20)) through the hardware base-2 exponential; n = e^2 + 2e; mish = x * n / (n + 2)
+  const float e = __builtin_amdgcn_exp2f(fminf(x, 20.0f) * 1.4426950408889634f);
+  const float n = e * (e + 2.0f);
+  return x * n * __builtin_amdgcn_rcpf(n + 2.0f);  // v_rcp_f32 (1 ulp): outputs are rounded to 16 bits anyway
+}
+__device__ __forceinline__ float actSilu(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-x * 1.4426950408889634f));
+}
 __device__ __forceinline__ float actApply(float x, int kind) {
   if(kind == KMX_ACT_RELU) return fmaxf(x, 0.0f);
-  if(kind == KMX_ACT_MISH) {
-    float e = __expf(fminf(x, 20.0f));
-    float n = e * (e + 2.0f);
-    return x * n * __builtin_amdgcn_rcpf(n + 2.0f);  // v_rcp_f32 (1 ulp): outputs are rounded to 16 bits anyway
-  }
-  if(kind == KMX_ACT_SILU) return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+  if(kind == KMX_ACT_MISH) return actMish(x);
+  if(kind == KMX_ACT_SILU) return actSilu(x);
   return x;
 }
 

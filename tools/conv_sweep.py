@@ -35,16 +35,17 @@ def main():
     for mode in (0, 1):
         for var in (1000, 2000, 3000):
             run(3, 3, var, 192, 192, mode)
-    for var in (2032, 2001, 2002, 2004, 2005, 2012, 2013, 2016):
+    for var in (2032, 2001, 2002, 2004, 2005, 2012, 2013, 2016, 2064, 2256, 2257, 3256):
         run(3, 3, var, 192, 192, 1)
     run(3, 3, 2032, 192, 192, 0)
+    run(3, 3, 2256, 192, 192, 0)
     print("== tile width ==")
     run(3, 2, 2000, 192, 128, 1)
     run(3, 1, 2000, 192, 192, 1)
     run(3, 1, 3000, 192, 192, 1)
     run(3, 3, 2000, 128, 192, 1)
     print("== 1x1 384->192 (pre) and 192->384 (post) ==")
-    for var in (1000, 2000, 2032, 2001, 2002, 2004, 2005):
+    for var in (1000, 2000, 2032, 2001, 2002, 2004, 2005, 2256, 2257):
         run(1, 3, var, 384, 192, 1)
     for var in (2000, 3000):
         run(1, 1, var, 384, 192, 1)
