@@ -175,6 +175,10 @@ int kmx_handle_get_profile(kmx_handle* handle, kmx_profile_entry* entries, int m
  * epilogue_mode 0 = BN+act output, 1 = residual + raw + BN+act outputs. Kernel tuning instrumentation. */
 int kmx_bench_conv(int ks, int wn, int variant, int cin, int cout, int batch, int nn_x_len, int nn_y_len,
                    int epilogue_mode, int iters, double* avg_ms);
+/* MFMA issue-rate microbenchmark (v_mfma_f32_32x32x16_bf16, 18 per step as in the convolution): mode bit 1 adds an
+ * s_barrier per step, bit 2 adds the step's 12 ds_read_b128. Reports the rate and the shader clock it ran at: the
+ * practical ceiling the convolution is measured against. Kernel tuning instrumentation. */
+int kmx_bench_mfma(int waves_per_wg, int wgs, int mode, int steps, int iters, double* avg_ms, double* tflops, double* core_mhz);
 
 /* ---- layer test hooks -------------------------------------------------------------- */
 /* NeuralNet::testEvaluateConv / BatchNorm / ResidualBlock / GlobalPoolingResidualBlock

@@ -11,23 +11,27 @@ namespace kmx {
 namespace {
 using namespace convk;
 
-// variant = D * 1000 + ABL
-hipError_t launchVariant(int ks, int wn, int variant, const ConvArgs& a, hipStream_t st) {
+// variant = D * 1000 + ABL; cfg = 10*WNW + WN as in launchConv
+hipError_t launchVariant(int ks, int cfg, int variant, const ConvArgs& a, hipStream_t st) {
   typedef TraitsBF16 TR;
-#define V(KS_, WN_, D_, ABL_) \
-  if(ks == KS_ && wn == WN_ && variant == D_ * 1000 + ABL_) return launchOne<TR, KS_, WN_, D_, ABL_>(a, st);
-  V(3, 3, 1, 0) V(3, 3, 2, 0) V(3, 3, 3, 0)
-  V(3, 3, 2, 1) V(3, 3, 2, 2) V(3, 3, 2, 4) V(3, 3, 2, 5) V(3, 3, 2, 12) V(3, 3, 2, 13) V(3, 3, 2, 16) V(3, 3, 2, 32) V(3, 3, 2, 64) V(3, 3, 2, 192) V(3, 3, 2, 65) V(3, 3, 2, 193) V(3, 3, 2, 80) V(3, 3, 2, 256) V(3, 3, 2, 512) V(3, 3, 2, 1024) V(3, 3, 2, 1536)
-  V(3, 2, 2, 0) V(3, 1, 2, 0) V(3, 1, 3, 0)
-  V(1, 3, 1, 0) V(1, 3, 2, 0) V(1, 3, 2, 1) V(1, 3, 2, 2) V(1, 3, 2, 4) V(1, 3, 2, 5) V(1, 3, 2, 32) V(1, 3, 2, 256) V(1, 3, 2, 257)
-  V(1, 1, 2, 0) V(1, 1, 3, 0) V(1, 2, 2, 0)
+#define V(KS_, WNW_, WN_, D_, ABL_) \
+  if(ks == KS_ && cfg == 10 * WNW_ + WN_ && variant == D_ * 1000 + ABL_) return launchOne<TR, KS_, WN_, WNW_, D_, ABL_>(a, st);
+  V(3, 1, 3, 2, 0) V(3, 2, 3, 2, 0) V(3, 2, 3, 3, 0) V(3, 2, 3, 4, 0)
+  V(3, 1, 3, 2, 1) V(3, 1, 3, 2, 2) V(3, 1, 3, 2, 4) V(3, 1, 3, 2, 5) V(3, 1, 3, 2, 8) V(3, 1, 3, 2, 512) V(3, 1, 3, 2, 1024)
+  V(3, 2, 3, 3, 13) V(3, 2, 3, 3, 7) V(3, 2, 3, 3, 9) V(3, 2, 3, 3, 12) V(3, 2, 3, 3, 3) V(3, 2, 3, 3, 6) V(3, 2, 3, 3, 1) V(3, 2, 3, 3, 2) V(3, 2, 3, 3, 4) V(3, 2, 3, 3, 5) V(3, 2, 3, 3, 8)
+  V(3, 2, 3, 2, 13) V(3, 2, 3, 2, 7) V(3, 2, 3, 2, 9) V(3, 2, 3, 2, 12) V(3, 2, 3, 2, 3) V(3, 2, 3, 2, 6)
+  V(3, 2, 3, 2, 1) V(3, 2, 3, 2, 2) V(3, 2, 3, 2, 4) V(3, 2, 3, 2, 5) V(3, 2, 3, 2, 8) V(3, 2, 3, 2, 512) V(3, 2, 3, 2, 1024)
+  V(3, 1, 2, 2, 0) V(3, 2, 2, 2, 0) V(3, 2, 2, 3, 0)
+  V(1, 1, 3, 2, 0) V(1, 2, 3, 2, 0) V(1, 2, 3, 3, 0)
+  V(1, 1, 3, 2, 1) V(1, 1, 3, 2, 2) V(1, 1, 3, 2, 4) V(1, 1, 3, 2, 5)
+  V(1, 2, 3, 2, 1) V(1, 2, 3, 2, 2) V(1, 2, 3, 2, 4) V(1, 2, 3, 2, 5)
 #undef V
   return hipErrorInvalidValue;
 }
 }  // namespace
 
 // epilogueMode: 0 = BN+act output only; 1 = residual in, raw out + BN+act out
-double benchConv(int ks, int wn, int variant, int cin, int cout, int batch, int X, int Y, int epilogueMode, int iters) {
+double benchConv(int ks, int cfg, int variant, int cin, int cout, int batch, int X, int Y, int epilogueMode, int iters) {
   const int dtype = DT_BF16;
   const int S = X * Y;
   const size_t cells = (size_t)batch * S;
@@ -52,7 +56,7 @@ double benchConv(int ks, int wn, int variant, int cin, int cout, int batch, int 
   FusedConv fc = buildFusedConv(dtype, {{&c, &bn}}, nullptr);
   std::vector<uint16_t> hin(cells * inStride);
   for(uint16_t& v : hin) v = floatToBf16Bits(rnd());
-  DevBuf in(hin.size() * 2, false), resid(cells * outStride * 2), raw(cells * outStride * 2), act(cells * outStride * 2), zero(4096);
+  DevBuf in(hin.size() * 2, false), resid(cells * outStride * 2), raw(cells * outStride * 2), act(cells * outStride * 2), zero(ZERO_PAGE_BYTES);
   in.upload(hin.data(), hin.size() * 2);
   std::vector<float> ones(cells, 1.0f);
   DevBuf mask(cells * sizeof(float), false);
@@ -69,7 +73,7 @@ double benchConv(int ks, int wn, int variant, int cin, int cout, int batch, int 
   a.scale = fc.scale.as<float>(); a.bias = fc.bias.as<float>(); a.actKind = KMX_ACT_MISH; a.mask = mask.as<float>();
   hipStream_t st = nullptr;
   auto launch = [&]() {
-    hipError_t e = variant == 0 ? launchConv(dtype, ks, wn, a, st) : launchVariant(ks, wn, variant, a, st);
+    hipError_t e = variant == 0 ? launchConv(dtype, ks, cfg, a, st) : launchVariant(ks, cfg, variant, a, st);
     hipCheck(e, "bench conv launch");
   };
   for(int i = 0; i < 3; i++) launch();
@@ -86,6 +90,115 @@ double benchConv(int ks, int wn, int variant, int cin, int cout, int batch, int 
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return (double)ms / iters;
+}
+
+
+// ---- MFMA issue-rate microbenchmark: the practical ceiling the convolution's main loop is measured against ----
+// mode bit 1: s_barrier after every 18 MFMAs (the convolution's step); bit 2: 12 ds_read_b128 per step feeding the MFMAs.
+template <int MODE>
+__global__ __launch_bounds__(512) void mfmaPeakKernel(int steps, int barEvery, unsigned long long* clocks, float* sink) {
+  extern __shared__ __attribute__((aligned(256))) char smem[];
+  typedef TraitsBF16 TR;
+  typedef TR::V8 V8;
+  const int lane = threadIdx.x & 63;
+  f32x16 acc[9];
+#pragma unroll
+  for(int i = 0; i < 9; i++)
+#pragma unroll
+    for(int r = 0; r < 16; r++) acc[i][r] = 0.0f;
+  V8 wf[2][3], af[2][3];
+#pragma unroll
+  for(int kk = 0; kk < 2; kk++)
+#pragma unroll
+    for(int j = 0; j < 3; j++)
+#pragma unroll
+      for(int i = 0; i < 8; i++) {
+        wf[kk][j][i] = (TR::T)(0.001f * (float)(lane + j));
+        af[kk][j][i] = (TR::T)(0.002f * (float)(lane + kk));
+      }
+  if(MODE & 2) {
+    for(int i = threadIdx.x; i < 16384; i += blockDim.x) ((float*)smem)[i] = 0.001f * (float)(i & 255);
+    __syncthreads();
+  }
+  int v0 = lane, v1 = lane * 7, v2 = lane ^ 5, v3 = lane + steps;
+  const unsigned long long c0 = clock64(), w0 = wall_clock64();
+  for(int s = 0; s < steps; s++) {
+    if(MODE & 2) {
+      const char* base = smem + ((s & 3) * 8192) + (lane & 31) * 64 + ((((lane >> 5)) ^ ((lane >> 2) & 3)) << 4);
+#pragma unroll
+      for(int kk = 0; kk < 2; kk++)
+#pragma unroll
+        for(int j = 0; j < 3; j++) {
+          wf[kk][j] = *(const V8*)(base + j * 2048 + (kk * 32 ^ 0));
+          af[kk][j] = *(const V8*)(base + 6144 + j * 2048 + (kk * 32 ^ 0) % 2048);
+        }
+    }
+#pragma unroll
+    for(int kk = 0; kk < 2; kk++)
+#pragma unroll
+      for(int ct = 0; ct < 3; ct++)
+#pragma unroll
+        for(int pt = 0; pt < 3; pt++) acc[ct * 3 + pt] = TR::mfma(wf[kk][ct], af[kk][pt], acc[ct * 3 + pt]);
+    if(MODE & 4) {
+      // the convolution's per-step address arithmetic: ~64 VALU operations competing for the vector issue slot
+#pragma unroll
+      for(int i = 0; i < 16; i++) {
+        v0 = v0 * 3 + i; v1 = (v1 >> 1) ^ v0; v2 = v2 + v1; v3 = v3 ^ (v2 << 2);
+      }
+    }
+    if((MODE & 1) && (s % barEvery) == 0) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  }
+  if((MODE & 4) && (v0 + v1 + v2 + v3) == 0x12345) sink[lane + 64] = 1.0f;
+  const unsigned long long c1 = clock64(), w1 = wall_clock64();
+  float t = 0.0f;
+#pragma unroll
+  for(int i = 0; i < 9; i++)
+#pragma unroll
+    for(int r = 0; r < 16; r++) t += acc[i][r];
+  if(t == 12345.678f) sink[lane] = t;
+  if(blockIdx.x == 0 && threadIdx.x == 0) {
+    clocks[0] = c1 - c0;
+    clocks[1] = w1 - w0;
+  }
+}
+
+// returns avg ms per launch; *tflops = achieved rate; *coreMhz = shader clock during the kernel (clock64 vs the 100 MHz wall clock)
+double benchMfma(int wavesPerWg, int wgs, int mode, int steps, int iters, double* tflops, double* coreMhz) {
+  DevBuf clk(16), sink(1024);
+  hipStream_t st = nullptr;
+  const int barEvery = (mode >> 4) > 0 ? (mode >> 4) : 1;
+  auto launch = [&]() {
+    dim3 g(wgs), b(wavesPerWg * 64);
+#define KMX_PEAK(M_) \
+  case M_: hipLaunchKernelGGL(mfmaPeakKernel<M_>, g, b, 65536, st, steps, barEvery, clk.as<unsigned long long>(), sink.as<float>()); break;
+    switch(mode & 7) {
+      KMX_PEAK(0) KMX_PEAK(1) KMX_PEAK(2) KMX_PEAK(3) KMX_PEAK(4) KMX_PEAK(5) KMX_PEAK(6) KMX_PEAK(7)
+    }
+#undef KMX_PEAK
+    hipCheck(hipGetLastError(), "mfma bench launch");
+  };
+  for(int i = 0; i < 3; i++) launch();
+  hipCheck(hipStreamSynchronize(st), "sync");
+  hipEvent_t e0, e1;
+  hipCheck(hipEventCreate(&e0), "event");
+  hipCheck(hipEventCreate(&e1), "event");
+  hipCheck(hipEventRecord(e0, st), "record");
+  for(int i = 0; i < iters; i++) launch();
+  hipCheck(hipEventRecord(e1, st), "record");
+  hipCheck(hipStreamSynchronize(st), "sync");
+  float ms = 0;
+  hipCheck(hipEventElapsedTime(&ms, e0, e1), "elapsed");
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  unsigned long long h[2] = {0, 0};
+  hipCheck(hipMemcpy(h, clk.get(), 16, hipMemcpyDeviceToHost), "copy clocks");
+  const double avg = (double)ms / iters;
+  if(tflops) *tflops = 18.0 * 32768.0 * steps * wavesPerWg * (double)wgs / (avg * 1e-3) / 1e12;
+  if(coreMhz) *coreMhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
+  return avg;
 }
 
 }  // namespace kmx

@@ -6,24 +6,33 @@
 // BatchNorm+activation that follows it (eigenbackend.cpp:739-762), the per-board bias add
 // (:137-148) and the residual accumulate (:659-686).
 //
-// Decomposition (one work-group = one BOARD x (64*WN) output channels, 8 waves = 4(M) x 2(N)):
+// Decomposition: one work-group = one BOARD x NTILE output channels; 4 x WNW waves, wave (wm, wn) owns
+// 96 board cells x 32*WN channels (3 x WN MFMA tiles of 32x32):
 //   D[cout][cell] += sum_{tap, cin} W[tap][cout][cin] * X[cell + tap][cin]
 //   - MFMA v_mfma_f32_32x32x16_{f16,bf16}; the A operand is the WEIGHT tile (rows = cout), the B
 //     operand the ACTIVATION tile (cols = board cells), so each lane ends up holding 4 consecutive
-//     output channels of one cell (8-byte NHWC stores) instead of 16 cells of one channel.
+//     output channels of one cell.
 //   - K loop: input-channel chunks of 32 (outer) x filter taps (inner) = "steps". Per chunk the board's
-//     activations INCLUDING a zero halo live in LDS as [cell][32ch] rows of 80 bytes; every tap reads
-//     the same image at a constant byte offset — no im2col, no per-tap global traffic.
-//   - both LDS images are filled by global_load_lds (LDS-DMA, 16 B/lane): their layout is a plain
-//     linear copy of the HBM layout (weights are pre-tiled by the engine; halo cells and the 16 pad
-//     bytes of each row are sourced from a zero page), so no VGPR staging and no ds_write.
-//   - 80-byte rows: 16 consecutive rows x 16 B cover all 64 banks once -> ds_read_b128 conflict-free.
+//     activations INCLUDING a zero halo live in LDS as [cell][32ch] rows of 64 bytes; every tap reads
+//     the same image at a row offset — no im2col, no per-tap global traffic.
+//   - both LDS images are filled by global_load_lds (LDS-DMA, 16 B/lane), i.e. they are LINEAR copies of
+//     what the DMA lanes fetch: the weights are pre-tiled AND pre-swizzled in HBM by the engine, the
+//     board image is gathered by per-lane source offsets computed once per work-group (halo cells come
+//     from a zero page). No VGPR staging, no ds_write.
+//   - bank conflicts are avoided by an XOR swizzle of the four 16-byte slots of a row with bits 2-3 of the
+//     row index (16 consecutive rows x one logical slot cover all 64 banks once) rather than by padding:
+//     20 % fewer DMA bytes and LDS bytes than 80-byte rows, which is what lets TWO 4-wave work-groups share
+//     a CU (one's residual fetch / epilogue / pipeline fill hides under the other's MFMA loop).
 //   - software pipeline of depth D: the weight slab of step s+D is requested at the top of step s (ring of
-//     D+1 LDS slabs). For 3x3/5x5 the next chunk's board image is requested one DMA instruction per step
+//     D+1 slabs). For 3x3/5x5 the next chunk's board image is requested one DMA instruction per step
 //     into the second image buffer; for 1x1 (one step per chunk) whole images ride the same ring.
 //     Every wave issues the SAME number of DMA instructions per step (padding with dummies into a slack
 //     area), so that one compile-time s_waitcnt vmcnt(N) retires exactly the data of the current step
 //     while D-1 steps of requests stay in flight across the single s_barrier per step.
+//   - accumulators start from the residual stream, so the epilogue has no global loads (vmcnt counts
+//     stores too: an epilogue alternating loads and stores pays a memory round trip per row).
+//   - epilogue: each wave transposes its tiles through LDS (fp32) and walks them row-wise with 16-byte
+//     stores of whole NHWC runs; BN scale/bias, activation, mask, 16-bit rounding happen there.
 #ifndef KMX_CONV_KERNEL_H_
 #define KMX_CONV_KERNEL_H_
 
@@ -32,45 +41,42 @@
 namespace kmx {
 namespace convk {
 
-constexpr int ROWB = WROW_HALFS * 2;  // 80 bytes per LDS row
+constexpr int ROWB = WROW_HALFS * 2;  // 64 bytes per LDS row = 4 slots of 16 bytes
 constexpr int MT = 3;                 // board-cell tiles (of 32) per wave: 4 waves x 96 = 384 >= 361
-constexpr int NWAVES = 8;
-constexpr int NTHREADS = NWAVES * 64;
 constexpr int MAXLEN = 19;
-constexpr int SLACK_BYTES = NWAVES * 1024;
-constexpr int MASK_BYTES = NWAVES * 64 * 4;  // the board's mask (<= 361 floats) copied once per work-group
 
 // ablation switches (conv_bench.hip only; 0 in the product)
-enum { ABL_NO_EPILOGUE = 1, ABL_NO_COMPUTE = 2, ABL_NO_DMA = 4, ABL_NO_LDS_READ = 8, ABL_SETPRIO = 16, ABL_DIRECT_EPILOGUE = 32, ABL_ORDER2 = 64, ABL_SGB = 128, ABL_PINGPONG = 256, ABL_EPI_NOACT = 512, ABL_EPI_NOSTORE = 1024 };
+enum { ABL_NO_EPILOGUE = 1, ABL_NO_COMPUTE = 2, ABL_NO_DMA = 4, ABL_NO_LDS_READ = 8, ABL_EPI_NOACT = 512, ABL_EPI_NOSTORE = 1024 };
 
-template <int KS>
-struct ConvGeom {
+template <int KS, int WN, int WNW, int D>
+struct Geom {
+  static constexpr int NWAVES = 4 * WNW;
+  static constexpr int NTHREADS = NWAVES * 64;
   static constexpr int HALO = KS / 2;
   static constexpr int NT = KS * KS;
   static constexpr int HPMAX = (MAXLEN + 2 * HALO) * (MAXLEN + 2 * HALO);
-  static constexpr int NPA = (HPMAX * 5 + NTHREADS - 1) / NTHREADS;  // DMA instructions per wave per board image
-  static constexpr int ACT_BYTES = (HPMAX * ROWB + 1023) / 1024 * 1024;  // DMA instructions wholly past it go to the slack
-};
-template <int WN>
-struct WGeom {
-  static constexpr int NTILE = 64 * WN;
-  static constexpr int PIECES = NTILE * 5;
-  static constexpr int NPW = (PIECES + NTHREADS - 1) / NTHREADS;
-  static constexpr int W_BYTES = NPW * NWAVES * 1024;
-};
-template <int KS, int WN, int D>
-struct Pipe {
-  typedef ConvGeom<KS> G;
-  typedef WGeom<WN> WG;
-  static constexpr bool SPREAD = G::NT >= G::NPA + D;  // image pieces fit one per step within a chunk
+  static constexpr int NPA = (HPMAX * 4 + NTHREADS - 1) / NTHREADS;   // DMA instructions per wave per board image
+  static constexpr int ACT_BYTES = (HPMAX * ROWB + 1023) / 1024 * 1024;  // instructions wholly past it go to the slack
+  static constexpr int NTILE = 32 * WN * WNW;
+  static constexpr int WPIECES = NTILE * 4;
+  static constexpr int NPW = (WPIECES + NTHREADS - 1) / NTHREADS;
+  static constexpr int W_BYTES = (WPIECES * 16 + 1023) / 1024 * 1024;
+  static_assert(D >= 2, "the slab of step s+1 is published at the top of step s: at least two steps of requests in flight");
+  static constexpr bool SPREAD = NT >= NPA + D;  // image pieces fit one per step within a chunk
   static constexpr int NSA = SPREAD ? 2 : D + 1;
   static constexpr int NSW = D + 1;
-  static constexpr int PIPE_BYTES = NSA * G::ACT_BYTES + NSW * WG::W_BYTES + SLACK_BYTES;
-  static constexpr int MASK_OFFSET = (PIPE_BYTES > NWAVES * 32 * (32 * WN + 4) * 4) ? PIPE_BYTES : NWAVES * 32 * (32 * WN + 4) * 4;
-  static constexpr int STAGE_BYTES = NWAVES * 32 * (32 * WN + 4) * 4;  // epilogue transpose, reuses the same LDS
-  static constexpr int LDS_BYTES = MASK_OFFSET + MASK_BYTES;  // mask tile sits past everything the epilogue reuses
+  static constexpr int SLACK_BYTES = NWAVES * 1024;
+  static constexpr int NPM = (384 + NTHREADS - 1) / NTHREADS;          // 4-byte DMA instructions per wave for the mask
+  static constexpr int MASK_BYTES = NPM * NTHREADS * 4;
+  static constexpr int PIPE_BYTES = NSA * ACT_BYTES + NSW * W_BYTES + SLACK_BYTES;
+  static constexpr int STAGE_BYTES = NWAVES * 32 * (32 * WN + 4) * 4;  // epilogue transpose, reuses the pipeline LDS
+  static constexpr int MASK_OFFSET = PIPE_BYTES > STAGE_BYTES ? PIPE_BYTES : STAGE_BYTES;
+  static constexpr int LDS_BYTES = MASK_OFFSET + MASK_BYTES;
   // DMA instructions younger than the data of the current step when it is waited for
-  static constexpr int VMCNT = SPREAD ? 1 + (D - 1) * (WG::NPW + 1) : (D - 1) * (WG::NPW + G::NPA);
+  // top of step s: everything up to slab s+1 has landed (requested in step s+1-D, followed there by its image piece)
+  static constexpr int VMCNT = SPREAD ? 1 + (D - 2) * (NPW + 1) : (D - 2) * (NPW + NPA);
+  // before the loop: slab 0 and image 0
+  static constexpr int VMCNT_PRO = SPREAD ? 1 + (D - 1) * (NPW + 1) : (D - 1) * (NPW + NPA);
 };
 
 template <int N>
@@ -82,141 +88,178 @@ __device__ __forceinline__ void dma16(const void* gsrc, char* ldsWaveBase) {
     (const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)ldsWaveBase, 16, 0, 0);
 }
 
-template <class TR, int KS, int WN, int D, int ABL>
-__global__ __launch_bounds__(NTHREADS) void convMfmaKernel(const ConvArgs a) {
+template <class TR, int KS, int WN, int WNW, int D, int ABL>
+__global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2))) void convMfmaKernel(const ConvArgs a) {
   typedef typename TR::T T;
   typedef typename TR::V8 V8;
   typedef typename TR::V4 V4;
-  typedef ConvGeom<KS> G;
-  typedef WGeom<WN> WG;
-  typedef Pipe<KS, WN, D> P;
-  constexpr int HALO = G::HALO, NT = G::NT, NPA = G::NPA, NPW = WG::NPW;
-  constexpr bool SPREAD = P::SPREAD;
+  typedef Geom<KS, WN, WNW, D> G;
+  constexpr int HALO = G::HALO, NT = G::NT, NPA = G::NPA, NPW = G::NPW, NWAVES = G::NWAVES;
+  constexpr bool SPREAD = G::SPREAD;
 
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(256))) char smem[];
   char* const bufA = smem;
-  char* const bufW = smem + P::NSA * G::ACT_BYTES;
-  char* const slack = bufW + P::NSW * WG::W_BYTES;
+  char* const bufW = smem + G::NSA * G::ACT_BYTES;
+  char* const slack = bufW + G::NSW * G::W_BYTES;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WNW, wn = wave % WNW;
   const int n = blockIdx.y;
-  const int cout0 = blockIdx.x * WG::NTILE;
+  const int cout0 = blockIdx.x * G::NTILE;
   const int X = a.X, Y = a.Y, S = X * Y;
   const int W2 = X + 2 * HALO, HP = W2 * (Y + 2 * HALO);
   const int inC = a.inC;
 
-  const T* const inBoard = (const T*)a.in + (size_t)n * S * inC;
+  const char* const inBoard = (const char*)a.in + (size_t)n * S * inC * sizeof(T);
   const char* const zero = (const char*)a.zeroPage;
   char* const mySlack = slack + wave * 1024;
 
-  // ---- per-lane DMA source offsets of the board image (in T elements; -1 = zero page) ----
-  int srcOff[NPA];
+  // ---- per-lane DMA source POINTERS of the board image (halo and out-of-image lanes point into the zero page) ----
+  // LDS piece p = row p/4, PHYSICAL slot p%4; it holds logical slot (p%4) ^ ((row>>2)&3) of that row. The pointers
+  // advance by one 32-channel chunk (64 bytes) each time they are used, so the main loop spends no vector ALU
+  // work on DMA addresses (vector ALU instructions compete with the MFMAs for the issue slot).
+  const char* srcPtr[NPA];
 #pragma unroll
   for(int j = 0; j < NPA; j++) {
     int p = (j * NWAVES + wave) * 64 + lane;
-    int hp = p / 5;
-    int slot = p - hp * 5;
-    int off = -1;
-    if(hp < HP && slot < 4) {
+    int hp = p >> 2;
+    int slot = (p & 3) ^ ((hp >> 2) & 3);
+    const char* ptr = zero;
+    if(hp < HP) {
       int hy = hp / W2;
       int hx = hp - hy * W2;
       int y = hy - HALO, x = hx - HALO;
-      if(y >= 0 && y < Y && x >= 0 && x < X) off = (y * X + x) * inC + slot * 8;
+      if(y >= 0 && y < Y && x >= 0 && x < X) ptr = inBoard + ((size_t)(y * X + x) * inC + slot * 8) * sizeof(T);
     }
-    srcOff[j] = off;
+    srcPtr[j] = ptr;
   }
   const char* const wBase = (const char*)a.w + (size_t)cout0 * ROWB;
   const size_t wSlabStride = (size_t)a.coutPad * ROWB;
   const int nChunks = a.nChunks;
   const int nSteps = nChunks * NT;
+  unsigned wOff[NPW];  // per-lane byte offset inside a weight slab; the slab address itself is wave-uniform (SGPR base)
+#pragma unroll
+  for(int j = 0; j < NPW; j++) {
+    const int p = (j * NWAVES + wave) * 64 + lane;
+    wOff[j] = (unsigned)(p < G::WPIECES ? p : lane) * 16u;
+  }
 
-  // Every call issues exactly NPW instructions (a dummy slab when `step` is past the end).
+  // Every call issues exactly NPW instructions (into the slack area when `step` is past the end).
   auto issueW = [&](int step) {
     if(ABL & ABL_NO_DMA) return;
     const bool live = step < nSteps;
-    const char* slab = wBase + (size_t)step * wSlabStride;
-    char* dst = bufW + (step % P::NSW) * WG::W_BYTES;
+    const char* slab = wBase + (size_t)(live ? step : 0) * wSlabStride;
+    char* dst = bufW + (step % G::NSW) * G::W_BYTES;
 #pragma unroll
     for(int j = 0; j < NPW; j++) {
-      int pbase = (j * NWAVES + wave) * 64;
-      int p = pbase + lane;
-      const char* src = (live && p < WG::PIECES) ? slab + (size_t)p * 16 : zero;
-      dma16(src, live ? dst + pbase * 16 : mySlack);
+      const int pbase = (j * NWAVES + wave) * 64;
+      const bool inRange = live && pbase < G::WPIECES;
+      dma16(slab + wOff[j], inRange ? dst + pbase * 16 : mySlack);
     }
   };
-  // One instruction of the board image of `chunk` (piece j), or a dummy when chunk is past the end / j >= NPA.
-  auto issueA = [&](int chunk, int j, int off) {
+  // One instruction of the board image of `chunk` (piece j; its pointer then moves on to the next chunk), or a
+  // dummy into the slack area when j < 0.
+  auto issueA = [&](int chunk, int j) {
     if(ABL & ABL_NO_DMA) return;
-    int pbase = (j * NWAVES + wave) * 64;
-    const bool live = chunk < nChunks && j < NPA && pbase * 16 < G::ACT_BYTES;
-    const char* src = (live && off >= 0) ? (const char*)(inBoard + off + chunk * KCHUNK) : zero;
-    dma16(src, live ? bufA + (chunk % P::NSA) * G::ACT_BYTES + pbase * 16 : mySlack);
+    const int jj = j < 0 ? 0 : j;
+    const int pbase = (jj * NWAVES + wave) * 64;
+    const bool live = j >= 0 && chunk < nChunks && pbase * 16 < G::ACT_BYTES;
+    dma16(srcPtr[jj], live ? bufA + (chunk % G::NSA) * G::ACT_BYTES + pbase * 16 : mySlack);
+    if(j >= 0) srcPtr[jj] += KCHUNK * sizeof(T);
   };
 
-  // ---- per-lane LDS read offsets ----
-  const int khalf = (lane >> 5) * 16;
-  const int wOff = (wn * (32 * WN) + (lane & 31)) * ROWB + khalf;
-  int aOff[MT];
+  // ---- per-lane LDS read addressing (32-bit LDS byte addresses; kept to 3-4 vector ALU operations per fragment) ----
+  const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned khalf = lane >> 5;  // which 8 of the 16 k-values of an MFMA this lane feeds
+  // weights: row r = wn*32*WN + ct*32 + (lane&31); (r>>2)&3 does not depend on ct or wn (both multiples of 32 rows)
+  const unsigned wXor = (lane >> 2) & 3;
+  unsigned wLane[2];  // lane part of a weight fragment address, per k half
+#pragma unroll
+  for(int kk = 0; kk < 2; kk++)
+    wLane[kk] = ldsBase + G::NSA * G::ACT_BYTES + (wn * (32 * WN) + (lane & 31)) * ROWB + (((kk * 2 + khalf) ^ wXor) << 4);
+  // activations: 4 x (halo-image row) of this lane's cell in each of its MT tiles; row q lives at byte q*64 and its
+  // logical 16-byte slot c at physical slot c ^ ((q>>2)&3):  address = (4q << 4) | ((4q ^ (c<<4)) & 0x30)
+  unsigned aRow4[MT];
 #pragma unroll
   for(int pt = 0; pt < MT; pt++) {
     int j = wm * (32 * MT) + pt * 32 + (lane & 31);
     j = j < S ? j : S - 1;  // rows beyond the board recompute the last cell; never stored
     int y = j / X;
     int x = j - y * X;
-    aOff[pt] = ((y + HALO) * W2 + (x + HALO)) * ROWB + khalf;
+    aRow4[pt] = (unsigned)((y + HALO) * W2 + (x + HALO)) << 2;
   }
+  const unsigned c40 = khalf << 4;
   const bool waveActive = wm * (32 * MT) < S;
 
-  // Accumulators start from the residual stream (trunk += conv(...), eigenbackend.cpp:659-686) instead of zero:
-  // the only global LOADS of the kernel besides the DMA are issued here, underneath the pipeline fill, so that the
-  // epilogue consists of stores alone. (vmcnt counts stores as well as loads: an epilogue that alternates residual
-  // loads and stores pays one full memory round trip per row; measured 2-5x the K loop.)
-  f32x16 acc[WN][MT];
+  // Fragment readers. A step's 16 k-values per MFMA come as two halves kk = 0, 1 (register sets F0, F1).
+  V8 wf[2][WN];
+  V8 af[2][MT];
+  unsigned aAddr[MT];  // kk=0 addresses of the tap last prepared; the kk=1 fragments sit 32 bytes away (slot ^ 2)
+  auto ldsV8 = [&](unsigned addr) { return *(const __attribute__((address_space(3))) V8*)addr; };
+  auto readW = [&](int kk, int stepIdx) {
+    if(ABL & (ABL_NO_LDS_READ | ABL_NO_COMPUTE)) return;
+    const unsigned base = wLane[kk] + (unsigned)(stepIdx % G::NSW) * G::W_BYTES;
 #pragma unroll
-  for(int ct = 0; ct < WN; ct++)
+    for(int ct = 0; ct < WN; ct++) wf[kk][ct] = ldsV8(base + ct * 32 * ROWB);
+  };
+  // kk=0 fragments of tap t from the image buffer at byte offset imgOff (a multiple of 1024)
+  auto readA0 = [&](unsigned imgOff, int t) {
+    if(ABL & (ABL_NO_LDS_READ | ABL_NO_COMPUTE)) return;
+    // 4 x (row offset of the tap) plus the buffer offset, both wave-uniform; opaque to the optimiser on purpose:
+    // hoisted out of the chunk loop the NT*MT addresses cost more registers than the two-wave-per-SIMD budget has
+    unsigned sTap = (unsigned)(((t / KS - HALO) * W2 + (t % KS - HALO)) * 4) + ((ldsBase + imgOff) >> 4);
+    asm volatile("" : "+s"(sTap));
+#pragma unroll
+    for(int pt = 0; pt < MT; pt++) {
+      const unsigned q4 = aRow4[pt] + sTap;
+      aAddr[pt] = (q4 << 4) | ((q4 ^ c40) & 0x30u);
+      af[0][pt] = ldsV8(aAddr[pt]);
+    }
+  };
+  auto readA1 = [&]() {
+    if(ABL & (ABL_NO_LDS_READ | ABL_NO_COMPUTE)) return;
+#pragma unroll
+    for(int pt = 0; pt < MT; pt++) af[1][pt] = ldsV8(aAddr[pt] ^ 0x20u);
+  };
+  // MFMAs [first, last) of the WN*MT that consume fragment set kk
+  auto mfmaPart = [&](int kk, int first, int last, f32x16 (&acc)[WN][MT]) {
+    if(ABL & ABL_NO_COMPUTE) return;
+#pragma unroll
+    for(int ct = 0; ct < WN; ct++)
+#pragma unroll
+      for(int pt = 0; pt < MT; pt++)
+        if(ct * MT + pt >= first && ct * MT + pt < last) acc[ct][pt] = TR::mfma(wf[kk][ct], af[kk][pt], acc[ct][pt]);
+  };
+#pragma unroll
+  for(int kk = 0; kk < 2; kk++) {
+#pragma unroll
+    for(int ct = 0; ct < WN; ct++)
+#pragma unroll
+      for(int i = 0; i < 8; i++) wf[kk][ct][i] = (T)(0.001f * (float)(lane + ct));
 #pragma unroll
     for(int pt = 0; pt < MT; pt++)
 #pragma unroll
-      for(int r = 0; r < 16; r++) acc[ct][pt][r] = 0.0f;
-  if(a.resid != nullptr && waveActive && !(ABL & ABL_DIRECT_EPILOGUE)) {
-#pragma unroll
-    for(int pt = 0; pt < MT; pt++) {
-      const int cell = wm * (32 * MT) + pt * 32 + (lane & 31);
-      if(cell < S) {
-        const T* rrow = (const T*)a.resid + ((size_t)n * S + cell) * a.residC;
-#pragma unroll
-        for(int ct = 0; ct < WN; ct++)
-#pragma unroll
-          for(int g = 0; g < 4; g++) {
-            const int c = cout0 + wn * (32 * WN) + ct * 32 + 8 * g + 4 * (lane >> 5);
-            if(c >= a.rawBegin && c < a.rawEnd) {
-              const V4 rr = *(const V4*)(rrow + (c - a.rawBegin));
-#pragma unroll
-              for(int i = 0; i < 4; i++) acc[ct][pt][4 * g + i] = TR::toFloat(rr[i]);
-            }
-          }
-      }
-    }
+      for(int i = 0; i < 8; i++) af[kk][pt][i] = (T)(0.002f * (float)(lane + pt));
   }
 
-  // ---- prologue: fill the pipeline with the same per-step instruction pattern the loop uses ----
-  // first (oldest) request: this board's mask, 4 bytes per lane, read back from LDS by the epilogue
-  {
-    const int cellIdx = wave * 64 + lane;
+  // ---- prologue, part 1: the oldest requests are this board's mask (4 bytes per lane) ----
+#pragma unroll
+  for(int j = 0; j < G::NPM; j++) {
+    const int cellIdx = (j * NWAVES + wave) * 64 + lane;
     const float* msrc = cellIdx < S ? a.mask + (size_t)n * S + cellIdx : (const float*)zero;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)msrc,
-                                     (__attribute__((address_space(3))) void*)(smem + P::MASK_OFFSET + wave * 256), 4, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(smem + G::MASK_OFFSET + (j * NWAVES + wave) * 256), 4, 0, 0);
   }
+  // ---- prologue, part 2: fill the pipeline with the same per-step instruction pattern the loop uses ----
   if(SPREAD) {
 #pragma unroll
-    for(int j = 0; j < NPA; j++) issueA(0, j, srcOff[j]);
+    for(int j = 0; j < NPA; j++) issueA(0, j);
 #pragma unroll
     for(int s = 0; s < D; s++) {
       issueW(s);
-      issueA(nChunks, 0, -1);  // dummy: keeps the per-step DMA count constant
+      issueA(0, -1);  // dummy: keeps the per-step DMA count constant
     }
   }
   else {
@@ -224,172 +267,100 @@ __global__ __launch_bounds__(NTHREADS) void convMfmaKernel(const ConvArgs a) {
     for(int s = 0; s < D; s++) {
       issueW(s);
 #pragma unroll
-      for(int j = 0; j < NPA; j++) issueA(s, j, srcOff[j]);
+      for(int j = 0; j < NPA; j++) issueA(s, j);
     }
   }
 
-  // ---- ping-pong schedule (ABL_PINGPONG) --------------------------------------------------------------------------
-  // With one barrier per step all eight waves run [requests, fragment reads, 18 MFMAs] in phase, and the matrix pipe
-  // idles while both waves of a SIMD sit in their load segment (measured: MFMA busy 29 %, 44 % of wave time in waits).
-  // Ping-pong keeps ONE instruction stream but splits every step in two segments, [requests + fragment reads] and
-  // [MFMAs], each behind its own barrier, and lets waves 4-7 (the SIMD partners of waves 0-3) enter the loop one
-  // barrier late: whenever one wave of a SIMD is in a load segment its partner is in an MFMA segment. The waits
-  // precede BOTH barriers because the late group must have its share of slab s landed by the barrier that releases the
-  // early group's reads of slab s, which is the late group's pre-MFMA barrier; this needs D >= 2.
-  constexpr bool PP = (ABL & ABL_PINGPONG) != 0;
-  static_assert(!PP || D >= 2, "ping-pong needs a pipeline depth of at least 2");
-  const int grp = wave >> 2;
-  if(PP && grp == 1) __builtin_amdgcn_s_barrier();
-  {
+  // Accumulators start from the residual stream (trunk += conv(...), eigenbackend.cpp:659-686) instead of zero:
+  // the only global LOADS of the kernel besides the DMA are issued here, underneath the pipeline fill. Branch-free
+  // (out-of-range pieces read the zero page) so that a whole tile row of loads is in flight at once.
+  f32x16 acc[WN][MT];
+  if(a.resid != nullptr) {
+#pragma unroll
+    for(int pt = 0; pt < MT; pt++) {
+      int cell = wm * (32 * MT) + pt * 32 + (lane & 31);
+      cell = cell < S ? cell : S - 1;
+      const T* const rrow = (const T*)a.resid + ((size_t)n * S + cell) * a.residC - a.rawBegin;
+      V4 rr[WN][4];
+#pragma unroll
+      for(int ct = 0; ct < WN; ct++)
+#pragma unroll
+        for(int g = 0; g < 4; g++) {
+          const int c = cout0 + wn * (32 * WN) + ct * 32 + 8 * g + 4 * khalf;
+          const T* src = (c >= a.rawBegin && c < a.rawEnd) ? rrow + c : (const T*)zero;
+          rr[ct][g] = *(const V4*)src;
+        }
+#pragma unroll
+      for(int ct = 0; ct < WN; ct++)
+#pragma unroll
+        for(int g = 0; g < 4; g++)
+#pragma unroll
+          for(int i = 0; i < 4; i++) acc[ct][pt][4 * g + i] = TR::toFloat(rr[ct][g][i]);
+    }
+  }
+  else {
+#pragma unroll
+    for(int ct = 0; ct < WN; ct++)
+#pragma unroll
+      for(int pt = 0; pt < MT; pt++)
+#pragma unroll
+        for(int r = 0; r < 16; r++) acc[ct][pt][r] = 0.0f;
+  }
+
+  // ---- main loop ----
+  // Invariant at the top of step s: slab s (and its board image) landed and was barrier-published one step EARLIER, and
+  // the kk=0 fragments of step s are already in registers (or in flight). The step then runs
+  //     wait+barrier (publishes slab s+1) | read F1(s) | MFMA F0(s) | DMA for step s+D | read F0(s+1) | MFMA F1(s)
+  // so every LDS read has eight MFMAs (256 matrix-core cycles) to land in, and the matrix core only idles for the
+  // barrier skew between waves.
+  if(!(ABL & ABL_NO_DMA)) waitVm<G::VMCNT_PRO>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  readW(0, 0);
+  readA0(0, 0);
   int step = 0;
   for(int chunk = 0; chunk < nChunks; chunk++) {
-    const char* const curA = bufA + (chunk % P::NSA) * G::ACT_BYTES;
+    const unsigned curA = (unsigned)(chunk % G::NSA) * G::ACT_BYTES;
+    const unsigned nextA = (unsigned)((chunk + 1) % G::NSA) * G::ACT_BYTES;
 #pragma unroll
     for(int t = 0; t < NT; t++, step++) {
-      // (1) this step's slab (and image) has landed: own DMAs by counted vmcnt, everybody's by the barrier
-      if(!(ABL & ABL_NO_DMA)) waitVm<P::VMCNT>();
+      if(!(ABL & ABL_NO_DMA)) waitVm<G::VMCNT>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-
-      // (2) requests for step + D   (3) MFMA over the 32 input channels of this (chunk, tap)
-      auto requests = [&]() {
-        issueW(step + D);
-        if(SPREAD) {
-          issueA(t < NPA ? chunk + 1 : nChunks, t < NPA ? t : 0, srcOff[t < NPA ? t : 0]);
-        }
-        else {
-#pragma unroll
-          for(int j = 0; j < NPA; j++) issueA(chunk + D, j, srcOff[j]);
-        }
-      };
-      if(waveActive && !(ABL & ABL_NO_COMPUTE)) {
-        if(!(ABL & ABL_ORDER2)) requests();
-        const int dy = t / KS - HALO, dx = t % KS - HALO;
-        const char* const aTap = curA + (dy * W2 + dx) * ROWB;
-        const char* const wCur = bufW + (step % P::NSW) * WG::W_BYTES + wOff;
-        // all fragments of the step are requested up front: LDS returns in order, so the second k-half's reads
-        // complete underneath the first half's MFMAs (counted lgkmcnt) instead of stalling the matrix pipe twice
-        V8 wf[2][WN];
-        V8 af[2][MT];
-#pragma unroll
-        for(int kk = 0; kk < 2; kk++) {
-          if(ABL & ABL_NO_LDS_READ) {
-#pragma unroll
-            for(int ct = 0; ct < WN; ct++)
-#pragma unroll
-              for(int i = 0; i < 8; i++) wf[kk][ct][i] = (T)(0.001f * (float)(lane + ct));
-#pragma unroll
-            for(int pt = 0; pt < MT; pt++)
-#pragma unroll
-              for(int i = 0; i < 8; i++) af[kk][pt][i] = (T)(0.002f * (float)(lane + pt));
-          }
-          else {
-#pragma unroll
-            for(int ct = 0; ct < WN; ct++) wf[kk][ct] = *(const V8*)(wCur + ct * 32 * ROWB + kk * 32);
-#pragma unroll
-            for(int pt = 0; pt < MT; pt++) af[kk][pt] = *(const V8*)(aTap + aOff[pt] + kk * 32);
-          }
-        }
-        // ORDER2: the DMA requests come after the fragment reads in program order (they never touch the buffers
-        // being read), so the scheduler may sink their address arithmetic and issue slots underneath the MFMAs
-        if(ABL & ABL_ORDER2) requests();
-        if(PP) {
-          waitVm<P::VMCNT>();
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragment reads retire in the load segment, not the MFMA one
-          __builtin_amdgcn_s_barrier();
-          asm volatile("" ::: "memory");
-        }
-        if(ABL & (ABL_SETPRIO | ABL_PINGPONG)) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for(int kk = 0; kk < 2; kk++)
-#pragma unroll
-          for(int ct = 0; ct < WN; ct++)
-#pragma unroll
-            for(int pt = 0; pt < MT; pt++) acc[ct][pt] = TR::mfma(wf[kk][ct], af[kk][pt], acc[ct][pt]);
-        if(ABL & (ABL_SETPRIO | ABL_PINGPONG)) __builtin_amdgcn_s_setprio(0);
-        if(ABL & ABL_SGB) {
-          // one MFMA, then a slice of the request code, repeated; the tail of the MFMAs follows
-#pragma unroll
-          for(int r = 0; r < 3; r++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);  // VALU
-            __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);  // SALU
-            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // VMEM
-          }
-          __builtin_amdgcn_sched_group_barrier(0x008, 2 * WN * MT - 3, 0);
-        }
+      // The compiler's own s_waitcnt before an MFMA drains ALL outstanding LDS reads (lgkmcnt(0)), so each batch of
+      // reads is issued right AFTER the first MFMA of the other fragment set: the wait it causes then only covers
+      // reads that had eight MFMAs to land.
+      mfmaPart(0, 0, 1, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      readW(1, step);
+      readA1();
+      __builtin_amdgcn_sched_barrier(0);
+      mfmaPart(0, 1, WN * MT, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      issueW(step + D);
+      if(SPREAD) {
+        issueA(chunk + 1, t < NPA ? t : -1);
       }
       else {
-        requests();
-        if(PP) {
-          waitVm<P::VMCNT>();
-          __builtin_amdgcn_s_barrier();
-          asm volatile("" ::: "memory");
-        }
+#pragma unroll
+        for(int j = 0; j < NPA; j++) issueA(chunk + D, j);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      mfmaPart(1, 0, 1, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      readW(0, step + 1);
+      readA0(t + 1 < NT ? curA : nextA, t + 1 < NT ? t + 1 : 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmaPart(1, 1, WN * MT, acc);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
-  }  // schedule
-  if(PP && grp == 0) __builtin_amdgcn_s_barrier();
   if(!(ABL & ABL_NO_DMA)) waitVm<0>();  // retire the trailing dummies before the LDS is reused / the wave exits
 
   // ---- epilogue ----
-  // After the MFMA chain a lane holds, per (ct,pt) tile, 4 consecutive channels of one cell — 8-byte pieces
-  // scattered over 64 cache lines per instruction, which measured 2-5x the duration of the whole K loop. Instead each
-  // wave transposes one 32-cell tile at a time through its private slice of the (now idle) LDS in fp32 and then
-  // walks it row-wise: 16-byte loads/stores, 4*WN consecutive lanes per cell, i.e. whole contiguous runs of the
-  // NHWC rows, for the residual read and for both outputs.
-  const float* const maskBoard = (const float*)(smem + P::MASK_OFFSET);
-  if(ABL & ABL_DIRECT_EPILOGUE) {
-    if(!waveActive) return;
-#pragma unroll
-    for(int pt = 0; pt < MT; pt++) {
-      const int cell = wm * (32 * MT) + pt * 32 + (lane & 31);
-      if(cell >= S) continue;
-      const size_t gcell = (size_t)n * S + cell;
-      const float maskVal = maskBoard[cell];
-#pragma unroll
-      for(int ct = 0; ct < WN; ct++) {
-#pragma unroll
-        for(int g = 0; g < 4; g++) {
-          const int c = cout0 + wn * (32 * WN) + ct * 32 + 8 * g + 4 * (lane >> 5);
-          float v[4];
-#pragma unroll
-          for(int i = 0; i < 4; i++) v[i] = acc[ct][pt][4 * g + i];
-          if(a.ncBias != nullptr) {
-            const float4 b = *(const float4*)(a.ncBias + (size_t)n * a.ncBiasStride + c);
-            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-          }
-          if(c >= a.rawBegin && c < a.rawEnd) {
-            if(a.resid != nullptr) {
-              const V4 rr = *(const V4*)((const T*)a.resid + gcell * a.residC + (c - a.rawBegin));
-#pragma unroll
-              for(int i = 0; i < 4; i++) v[i] += TR::toFloat(rr[i]);
-            }
-            V4 o;
-#pragma unroll
-            for(int i = 0; i < 4; i++) o[i] = TR::fromFloat(v[i]);
-            *(V4*)((T*)a.rawOut + gcell * a.rawC + (c - a.rawBegin)) = o;
-          }
-          if(c >= a.actBegin && c < a.actEnd) {
-            const float4 sc = *(const float4*)(a.scale + c);
-            const float4 bi = *(const float4*)(a.bias + c);
-            V4 o;
-            o[0] = TR::fromFloat(actApply(v[0] * sc.x + bi.x, a.actKind) * maskVal);
-            o[1] = TR::fromFloat(actApply(v[1] * sc.y + bi.y, a.actKind) * maskVal);
-            o[2] = TR::fromFloat(actApply(v[2] * sc.z + bi.z, a.actKind) * maskVal);
-            o[3] = TR::fromFloat(actApply(v[3] * sc.w + bi.w, a.actKind) * maskVal);
-            *(V4*)((T*)a.actOut + gcell * a.actC + (c - a.actBegin)) = o;
-          }
-        }
-      }
-    }
-    return;
-  }
-
+  const float* const maskBoard = (const float*)(smem + G::MASK_OFFSET);
   constexpr int ROWF = 32 * WN + 4;         // floats per staged row (+16 B: rows 16 B apart mod 128 -> conflict-free b128 writes)
   constexpr int STAGE_FLOATS = 32 * ROWF;   // one 32-cell x (32*WN)-channel tile per wave
-  static_assert(NWAVES * STAGE_FLOATS * 4 <= P::LDS_BYTES, "epilogue staging does not fit the LDS");
   constexpr int PPC = 4 * WN;               // 8-channel pieces per cell
   constexpr int CPI = 64 / PPC;             // cells covered by one wave-wide access
   constexpr int NIT = (32 + CPI - 1) / CPI;
@@ -429,7 +400,7 @@ __global__ __launch_bounds__(NTHREADS) void convMfmaKernel(const ConvArgs a) {
         f32x4 v;
 #pragma unroll
         for(int i = 0; i < 4; i++) v[i] = acc[ct][pt][4 * g + i];
-        *(f32x4*)(stage + (lane & 31) * ROWF + ct * 32 + 8 * g + 4 * (lane >> 5)) = v;
+        *(f32x4*)(stage + (lane & 31) * ROWF + ct * 32 + 8 * g + 4 * khalf) = v;
       }
     if(ABL & ABL_NO_EPILOGUE) continue;
     // (b) row-wise walk: lane -> (cell pc of this group, 8 channels pk)
@@ -451,14 +422,13 @@ __global__ __launch_bounds__(NTHREADS) void convMfmaKernel(const ConvArgs a) {
         V8 o;
 #pragma unroll
         for(int i = 0; i < 8; i++) o[i] = TR::fromFloat(v[i]);
-        if(ABL & ABL_EPI_NOSTORE) asm volatile("" ::"v"(o)); else
-        *(V8*)((T*)a.rawOut + gcell * a.rawC + (c8 - a.rawBegin)) = o;
+        if(ABL & ABL_EPI_NOSTORE) asm volatile("" ::"v"(o));
+        else *(V8*)((T*)a.rawOut + gcell * a.rawC + (c8 - a.rawBegin)) = o;
       }
       if(inAct) {
         const float maskVal = maskBoard[cell];
         V8 o;
-        // the activation kind is uniform for the launch: branch ONCE per row, not per element (a per-element switch
-        // compiles to every activation being evaluated and selected - measured 12 us of a 20 us epilogue)
+        // the activation kind is uniform for the launch: branch ONCE per row, not per element
         const int kind = (ABL & ABL_EPI_NOACT) ? KMX_ACT_IDENTITY : a.actKind;
         if(kind == KMX_ACT_MISH) {
 #pragma unroll
@@ -476,8 +446,8 @@ __global__ __launch_bounds__(NTHREADS) void convMfmaKernel(const ConvArgs a) {
 #pragma unroll
           for(int i = 0; i < 8; i++) o[i] = TR::fromFloat((v[i] * sc[i] + bi[i]) * maskVal);
         }
-        if(ABL & ABL_EPI_NOSTORE) asm volatile("" ::"v"(o)); else
-        *(V8*)((T*)a.actOut + gcell * a.actC + (c8 - a.actBegin)) = o;
+        if(ABL & ABL_EPI_NOSTORE) asm volatile("" ::"v"(o));
+        else *(V8*)((T*)a.actOut + gcell * a.actC + (c8 - a.actBegin)) = o;
       }
     }
   }
@@ -487,23 +457,23 @@ __global__ __launch_bounds__(NTHREADS) void convMfmaKernel(const ConvArgs a) {
   }
 }
 
-template <class TR, int KS, int WN, int D, int ABL>
+template <class TR, int KS, int WN, int WNW, int D, int ABL>
 hipError_t launchOne(const ConvArgs& a, hipStream_t stream) {
-  typedef WGeom<WN> WG;
-  typedef Pipe<KS, WN, D> P;
-  constexpr int ldsBytes = P::LDS_BYTES;
+  typedef Geom<KS, WN, WNW, D> G;
+  constexpr int ldsBytes = G::LDS_BYTES;
   static_assert(ldsBytes <= 160 * 1024, "LDS budget exceeded");
-  static_assert(!P::SPREAD || ConvGeom<KS>::NPA + D <= ConvGeom<KS>::NT, "image pieces must land within their chunk");
-  auto kern = convMfmaKernel<TR, KS, WN, D, ABL>;
+  static_assert(!G::SPREAD || G::NPA + D <= G::NT, "image pieces must land within their chunk");
+  static_assert(G::STAGE_BYTES <= G::MASK_OFFSET, "epilogue staging overlaps the mask tile");
+  auto kern = convMfmaKernel<TR, KS, WN, WNW, D, ABL>;
   static bool attrSet = false;  // per instantiation; idempotent
   if(!attrSet) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes);
     if(e != hipSuccess) return e;
     attrSet = true;
   }
-  if(a.coutPad % WG::NTILE != 0) return hipErrorInvalidValue;
-  dim3 grid(a.coutPad / WG::NTILE, a.N, 1);
-  hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), ldsBytes, stream, a);
+  if(a.coutPad % G::NTILE != 0) return hipErrorInvalidValue;
+  dim3 grid(a.coutPad / G::NTILE, a.N, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(G::NTHREADS), ldsBytes, stream, a);
   return hipGetLastError();
 }
 

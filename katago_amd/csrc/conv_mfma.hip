@@ -6,44 +6,52 @@ namespace kmx {
 namespace {
 using namespace convk;
 
-constexpr int DEPTH = 2;  // software-pipeline depth used by the engine (see conv_kernel.h; tuned in profiles/)
-
+// cfg = 10*WNW + WN : WNW = waves along the channel dimension (1: 4-wave work-group, 2: 8-wave), WN = 32-channel
+// tiles per wave; a work-group covers 32*WN*WNW output channels of one board.
 template <class TR>
-hipError_t launchT(int ks, int wn, const ConvArgs& a, hipStream_t stream) {
-  if(ks == 3) {
-    if(wn == 1) return launchOne<TR, 3, 1, DEPTH, 0>(a, stream);
-    if(wn == 2) return launchOne<TR, 3, 2, DEPTH, 0>(a, stream);
-    if(wn == 3) return launchOne<TR, 3, 3, DEPTH, 0>(a, stream);
-  }
-  else if(ks == 1) {
-    if(wn == 1) return launchOne<TR, 1, 1, DEPTH, 0>(a, stream);
-    if(wn == 2) return launchOne<TR, 1, 2, DEPTH, 0>(a, stream);
-    if(wn == 3) return launchOne<TR, 1, 3, DEPTH, 0>(a, stream);
-  }
-  else if(ks == 5) {
-    if(wn == 1) return launchOne<TR, 5, 1, DEPTH, 0>(a, stream);
-    if(wn == 2) return launchOne<TR, 5, 2, DEPTH, 0>(a, stream);
-  }
+hipError_t launchT(int ks, int cfg, const ConvArgs& a, hipStream_t stream) {
+#define KMX_CFG(KS_, WNW_, WN_, D_) \
+  if(ks == KS_ && cfg == 10 * WNW_ + WN_) return launchOne<TR, KS_, WN_, WNW_, D_, 0>(a, stream);
+  KMX_CFG(3, 1, 1, 2) KMX_CFG(3, 1, 2, 2) KMX_CFG(3, 1, 3, 2)
+  KMX_CFG(3, 2, 2, 3) KMX_CFG(3, 2, 3, 3)
+  KMX_CFG(1, 1, 1, 2) KMX_CFG(1, 1, 2, 2) KMX_CFG(1, 1, 3, 2)
+  KMX_CFG(1, 2, 2, 3) KMX_CFG(1, 2, 3, 3)
+  KMX_CFG(5, 1, 1, 2) KMX_CFG(5, 1, 2, 2) KMX_CFG(5, 1, 3, 2)
+  KMX_CFG(5, 2, 2, 2)
+#undef KMX_CFG
   return hipErrorInvalidValue;
 }
 
 }  // namespace
 
-hipError_t launchConv(int dtype, int ks, int wn, const ConvArgs& a, hipStream_t stream) {
+hipError_t launchConv(int dtype, int ks, int cfg, const ConvArgs& a, hipStream_t stream) {
   if(a.X < 2 || a.Y < 2 || a.X > MAXLEN || a.Y > MAXLEN || a.N <= 0) return hipErrorInvalidValue;
-  if(a.inC % 8 != 0 || a.coutPad % 64 != 0) return hipErrorInvalidValue;
-  if(dtype == DT_F16) return launchT<TraitsF16>(ks, wn, a, stream);
-  if(dtype == DT_BF16) return launchT<TraitsBF16>(ks, wn, a, stream);
+  if(a.inC % 8 != 0 || a.coutPad % 32 != 0 || (a.nChunks + 4) * 64 > ZERO_PAGE_BYTES) return hipErrorInvalidValue;
+  if(dtype == DT_F16) return launchT<TraitsF16>(ks, cfg, a, stream);
+  if(dtype == DT_BF16) return launchT<TraitsBF16>(ks, cfg, a, stream);
   return hipErrorInvalidValue;
 }
 
-int chooseConvWN(int ks, int coutPad, int batch) {
-  const int tiles = coutPad / 64;
-  const int maxWN = ks == 5 ? 2 : 3;
-  // the widest tile (fewest re-reads of the board image) that still gives every CU a work-group
-  for(int wn = maxWN; wn > 1; wn--)
-    if(tiles % wn == 0 && (tiles / wn) * batch >= 200) return wn;
-  return 1;
+// Work-group shape for a convolution with coutPad (a multiple of 32) output channels on `batch` boards.
+// 4-wave work-groups of 96 channels leave LDS and registers for a second work-group on the same CU; 8-wave
+// work-groups read the board image once for up to 192 channels. See profiles/ for the measurements behind the order.
+int chooseConvCfg(int ks, int coutPad, int batch) {
+  (void)batch;
+  const int tiles = coutPad / 32;
+  static const int order4[] = {13, 12, 11};
+  static const int order8[] = {23, 22};
+  const bool prefer8 = false;
+  for(int pass = 0; pass < 2; pass++) {
+    const bool use8 = (pass == 0) == prefer8;
+    const int* order = use8 ? order8 : order4;
+    const int cnt = use8 ? 2 : 3;
+    for(int i = 0; i < cnt; i++) {
+      const int wnw = order[i] / 10, wn = order[i] % 10;
+      if(ks == 5 && use8 && wn == 3) continue;
+      if(tiles % (wn * wnw) == 0) return order[i];
+    }
+  }
+  return 11;
 }
 
 }  // namespace kmx

@@ -12,8 +12,10 @@ void hipCheck(hipError_t e, const char* what) {
 
 DevBuf::DevBuf(size_t bytes, bool zero) : p_(nullptr), bytes_(bytes) {
   if(bytes == 0) return;
-  hipCheck(hipMalloc(&p_, bytes), "hipMalloc");
-  if(zero) hipCheck(hipMemset(p_, 0, bytes), "hipMemset");
+  // DEVBUF_TAIL readable bytes follow every allocation: the convolution's DMA pointers run up to D chunks (64 bytes
+  // each) past the last channel chunk of the last cell; those requests land in a scratch area and are never used.
+  hipCheck(hipMalloc(&p_, bytes + DEVBUF_TAIL), "hipMalloc");
+  if(zero) hipCheck(hipMemset(p_, 0, bytes + DEVBUF_TAIL), "hipMemset");
 }
 DevBuf::~DevBuf() {
   if(p_) (void)hipFree(p_);
@@ -35,7 +37,7 @@ void DevBuf::upload(const void* src, size_t bytes) {
 
 // ------------------------------------------------------------------------------------------------
 // Weight re-tiling. Reference layouts: conv weights in the file are [ky][kx][ic][oc] (desc.cpp:130);
-// the kernel wants, per (chunk of 32 ic, tap), rows of one output channel: T[chunk][tap][oc][40].
+// the kernel wants, per (chunk of 32 ic, tap), rows of one output channel: T[chunk][tap][oc][32], slots swizzled.
 FusedConv buildFusedConv(int dtype, const std::vector<ConvSegment>& segs, std::vector<int>* segOffsets) {
   if(segs.empty()) throw Error(KMX_ERR_INTERNAL, "buildFusedConv: no segments");
   FusedConv fc;
@@ -59,7 +61,7 @@ FusedConv buildFusedConv(int dtype, const std::vector<ConvSegment>& segs, std::v
     cout += roundUp(s.conv->outC, 8);  // segment starts on 8-channel boundaries: the epilogue moves 16-byte pieces
   }
   fc.cout = cout;
-  fc.coutPad = roundUp(cout, 64);
+  fc.coutPad = roundUp(cout, 64);  // every work-group shape (32..192 channels) that divides it is launchable
   fc.nChunks = (fc.cin + KCHUNK - 1) / KCHUNK;
   const int nt = fc.ks * fc.ks;
   std::vector<uint16_t> w((size_t)fc.nChunks * nt * fc.coutPad * WROW_HALFS, 0);
@@ -73,10 +75,12 @@ FusedConv buildFusedConv(int dtype, const std::vector<ConvSegment>& segs, std::v
         const int ky = t / fc.ks - d, kx = t % fc.ks - d;
         if(ky < 0 || ky >= c.ky || kx < 0 || kx >= c.kx) continue;  // zero tap of an embedded smaller kernel
         for(int oc = 0; oc < c.outC; oc++) {
-          uint16_t* row = &w[(((size_t)chunk * nt + t) * fc.coutPad + offs[si] + oc) * WROW_HALFS];
+          const int co = offs[si] + oc;
+          uint16_t* row = &w[(((size_t)chunk * nt + t) * fc.coutPad + co) * WROW_HALFS];
           for(int k = 0; k < KCHUNK; k++) {
             const int ic = chunk * KCHUNK + k;
-            if(ic < c.inC) row[k] = floatToTBits(dtype, c.at(ky, kx, ic, oc));
+            const int slot = (k >> 3) ^ ((co >> 2) & 3);  // the kernel's LDS swizzle, applied here so the DMA copy is linear
+            if(ic < c.inC) row[slot * 8 + (k & 7)] = floatToTBits(dtype, c.at(ky, kx, ic, oc));
           }
         }
       }
@@ -130,7 +134,7 @@ Engine::Engine(const ModelDesc& model, int nnXLen, int nnYLen, int maxBatch, int
   cin_ = model.numInputChannels;
   gin_ = model.numInputGlobalChannels;
   const size_t NS = (size_t)maxBatch_ * S_;
-  zeroPage_ = DevBuf(4096);
+  zeroPage_ = DevBuf(ZERO_PAGE_BYTES);
   inputT_ = DevBuf(NS * KCHUNK * 2);
   mask_ = DevBuf(NS * sizeof(float));
   maskSum_ = DevBuf((size_t)maxBatch_ * sizeof(float));
@@ -224,7 +228,7 @@ void Engine::addConv(const FusedConv* fc, const void* in, int inStride, const fl
   addOp(ks == 1 ? "conv1x1" : ks == 3 ? "conv3x3" : "conv5x5", 2.0 * fc->macPerCell * S_, bytes, [=](int n, hipStream_t st) {
     ConvArgs b = a;
     b.N = n;
-    hipCheck(launchConv(dtype, ks, chooseConvWN(ks, coutPad, n), b, st), "convolution launch");
+    hipCheck(launchConv(dtype, ks, chooseConvCfg(ks, coutPad, n), b, st), "convolution launch");
   });
 }
 
@@ -593,7 +597,7 @@ struct HookCtx {
   DevBuf zero, mask;
   HookCtx(int dt, int n, int x, int y, const float* hostMask) : dtype(dt), N(n), X(x), Y(y), S(x * y), st(nullptr) {
     if(x < 2 || y < 2 || x > 19 || y > 19 || n < 1) throw Error(KMX_ERR_INVALID_ARG, "test hook: bad sizes");
-    zero = DevBuf(4096);
+    zero = DevBuf(ZERO_PAGE_BYTES);
     std::vector<float> ones((size_t)n * S, 1.0f);
     mask = DevBuf((size_t)n * S * sizeof(float), false);
     mask.upload(hostMask ? hostMask : ones.data(), (size_t)n * S * sizeof(float));
@@ -627,7 +631,7 @@ struct HookCtx {
     a.actOut = actOut; a.actC = actStride; a.actBegin = actBegin; a.actEnd = std::min(actEnd, actBegin + actStride);
     a.scale = fc.scale.as<float>(); a.bias = fc.bias.as<float>(); a.actKind = actKind;
     a.mask = mask.as<float>();
-    hipCheck(launchConv(dtype, fc.ks, chooseConvWN(fc.ks, fc.coutPad, N), a, st), "test conv launch");
+    hipCheck(launchConv(dtype, fc.ks, chooseConvCfg(fc.ks, fc.coutPad, N), a, st), "test conv launch");
   }
 };
 

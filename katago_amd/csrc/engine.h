@@ -27,6 +27,8 @@ struct Error : std::runtime_error {
 };
 void hipCheck(hipError_t e, const char* what);
 
+constexpr size_t DEVBUF_TAIL = 512;
+
 // RAII device allocation
 class DevBuf {
  public:

@@ -3,9 +3,9 @@
 // Data layout in HBM:
 //   activations : T[N][S][Cs]   "NHWC", S = nnY*nnX, Cs = channel stride, a multiple of 32;
 //                 channels beyond the real count are zero; cells off the board are zero.
-//   conv weights: T[chunk][tap][coutPad][40]  chunk = 32 input channels, tap = ky*KS+kx,
-//                 40 = 32 k-values + 8 pad halfs (80-byte rows: conflict-free ds_read_b128 and an
-//                 LDS image that is a plain linear copy for global_load_lds).
+//   conv weights: T[chunk][tap][coutPad][32]  chunk = 32 input channels, tap = ky*KS+kx; within a row the four
+//                 8-value slots are stored at slot ^ ((cout>>2)&3): the LDS image the kernel wants (conflict-free
+//                 ds_read_b128) is then a plain linear copy for global_load_lds.
 //   T is fp16 or bf16 (KMX_PREC_FP16 / KMX_PREC_BF16); all accumulation and epilogue math is fp32.
 #ifndef KMX_KERNELS_H_
 #define KMX_KERNELS_H_
@@ -18,7 +18,8 @@ namespace kmx {
 enum { DT_F16 = 0, DT_BF16 = 1 };
 
 constexpr int KCHUNK = 32;      // input channels per K chunk
-constexpr int WROW_HALFS = 40;  // halfs per weight/activation LDS row (32 + 8 pad)
+constexpr int ZERO_PAGE_BYTES = 16384;  // >= (inC/32 + 4) * 64
+constexpr int WROW_HALFS = 32;  // halfs per weight/activation LDS row (64 bytes = four 16-byte slots, XOR-swizzled)
 
 // One fused convolution: out = epilogue( conv(in, w) ).
 // Epilogue per output channel c in [0, coutPad) and board cell p:
@@ -30,10 +31,10 @@ constexpr int WROW_HALFS = 40;  // halfs per weight/activation LDS row (32 + 8 p
 struct ConvArgs {
   const void* in;
   const void* w;
-  const void* zeroPage;  // >= 64 bytes of zeros
+  const void* zeroPage;  // ZERO_PAGE_BYTES of zeros (halo lanes walk it 64 bytes per input-channel chunk)
   int inC;               // channel stride of `in`
   int nChunks;           // ceil(real Cin / 32)
-  int coutPad;           // multiple of 64
+  int coutPad;           // multiple of 32
   int N, X, Y;
   const float* ncBias;
   int ncBiasStride;
@@ -49,12 +50,10 @@ struct ConvArgs {
   const float* mask;  // [N][S]
 };
 
-// KS in {1,3,5}; wn = output-channel tiles of 32 per wave (work-group covers 64*wn channels).
-// Returns hipSuccess or an error (unsupported combination -> hipErrorInvalidValue).
-hipError_t launchConv(int dtype, int ks, int wn, const ConvArgs& a, hipStream_t stream);
-// Allowed wn values for a given (ks, coutPad); picks the largest that divides coutPad/64 unless
-// the batch is too small to fill the chip.
-int chooseConvWN(int ks, int coutPad, int batch);
+// KS in {1,3,5}; cfg = 10*WNW + WN (WNW waves along channels: 1 = 4-wave, 2 = 8-wave work-group; WN = 32-channel
+// tiles per wave). Returns hipSuccess or an error (unsupported combination -> hipErrorInvalidValue).
+hipError_t launchConv(int dtype, int ks, int cfg, const ConvArgs& a, hipStream_t stream);
+int chooseConvCfg(int ks, int coutPad, int batch);
 
 // Input staging: fp32 NHWC rows (not symmetrised) -> T[N][S][32] symmetrised + mask + maskSum +
 // ncBias[n][C] = W_global^T * global[n]   (copyInputsWithSymmetry nninputs.cpp:529-597, Model::apply

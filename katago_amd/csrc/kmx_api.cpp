@@ -14,6 +14,7 @@ using namespace kmx;
 
 namespace kmx {
 double benchConv(int ks, int wn, int variant, int cin, int cout, int batch, int X, int Y, int epilogueMode, int iters);  // conv_bench.hip
+double benchMfma(int wavesPerWg, int wgs, int mode, int steps, int iters, double* tflops, double* coreMhz);       // conv_bench.hip
 }
 
 struct kmx_model {
@@ -243,6 +244,15 @@ int kmx_bench_conv(int ks, int wn, int variant, int cin, int cout, int batch, in
     if(!avg_ms || iters < 1 || batch < 1 || cin < 1 || cout < 1) throw Error(KMX_ERR_INVALID_ARG, "kmx_bench_conv: bad argument");
     (void)deviceCountOrThrow();
     *avg_ms = benchConv(ks, wn, variant, cin, cout, batch, nn_x_len, nn_y_len, epilogue_mode, iters);
+  });
+}
+
+int kmx_bench_mfma(int waves_per_wg, int wgs, int mode, int steps, int iters, double* avg_ms, double* tflops, double* core_mhz) {
+  return guarded([&] {
+    if(!avg_ms || iters < 1 || steps < 1 || wgs < 1 || waves_per_wg < 1 || waves_per_wg > 8)
+      throw Error(KMX_ERR_INVALID_ARG, "kmx_bench_mfma: bad argument");
+    (void)deviceCountOrThrow();
+    *avg_ms = benchMfma(waves_per_wg, wgs, mode, steps, iters, tflops, core_mhz);
   });
 }
 

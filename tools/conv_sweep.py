@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Times single launches of the MFMA convolution (product kernel and ablated variants) with kmx_bench_conv.
     python tools/conv_sweep.py [--batch 256] [--iters 20]
-variant = depth*1000 + ablation mask (1 no epilogue, 2 no MFMA/LDS reads, 4 no DMA, 8 no LDS reads, 16 setprio)."""
+variant = depth*1000 + ablation mask (1 no epilogue, 2 no MFMA/LDS reads, 4 no DMA, 8 no LDS reads, 512 no activation, 1024 no stores)."""
 import argparse
 import ctypes
 import os
@@ -31,31 +31,25 @@ def main():
         print("ks%d wn%d var%-5d %3d->%3d mode%d batch%-4d: %8.4f ms  %7.1f TFLOP/s (%4.1f%% of 2.5PF)" % (
             ks, wn, variant, cin, cout, mode, b, ms.value, flops / ms.value / 1e9, flops / ms.value / 1e9 / 25.0), flush=True)
 
+    # cfg = 10*WNW + WN: 13 = 4-wave work-group of 96 channels, 23 = 8-wave work-group of 192 channels
     print("== 3x3 192->192 (the dominant shape of b18c384nbt) ==")
     for mode in (0, 1):
-        for var in (1000, 2000, 3000):
-            run(3, 3, var, 192, 192, mode)
-    for var in (2032, 2001, 2002, 2004, 2005, 2012, 2013, 2016, 2064, 2256, 2257, 3256):
-        run(3, 3, var, 192, 192, 1)
-    run(3, 3, 2032, 192, 192, 0)
-    run(3, 3, 2256, 192, 192, 0)
-    print("== tile width ==")
-    run(3, 2, 2000, 192, 128, 1)
-    run(3, 1, 2000, 192, 192, 1)
-    run(3, 1, 3000, 192, 192, 1)
-    run(3, 3, 2000, 128, 192, 1)
+        for cfg, var in ((13, 2000), (23, 2000), (23, 3000), (23, 4000), (12, 2000), (22, 2000), (22, 3000)):
+            run(3, cfg, var, 192, 192 if cfg % 10 == 3 else 128, mode)
+    for cfg, d in ((13, 2000), (23, 2000)):
+        for abl in (1, 2, 4, 5, 8, 512, 1024):
+            run(3, cfg, d + abl, 192, 192, 1)
     print("== 1x1 384->192 (pre) and 192->384 (post) ==")
-    for var in (1000, 2000, 2032, 2001, 2002, 2004, 2005, 2256, 2257):
-        run(1, 3, var, 384, 192, 1)
-    for var in (2000, 3000):
-        run(1, 1, var, 384, 192, 1)
-    run(1, 2, 2000, 384, 128, 1)
-    for var in (1000, 2000, 2032, 2001):
-        run(1, 3, var, 192, 384, 1)
-    print("== batch scaling (product kernel) ==")
-    for b in (32, 64, 128, 512):
-        run(3, 3, 0, 192, 192, 1, b)
-        run(3, 1, 0, 192, 192, 1, b)
+    for cfg, var in ((13, 2000), (23, 2000), (23, 3000)):
+        run(1, cfg, var, 384, 192, 1)
+        run(1, cfg, var, 192, 384, 1)
+    for cfg, d in ((13, 2000), (23, 2000)):
+        for abl in (1, 2, 4, 5):
+            run(1, cfg, d + abl, 192, 384, 1)
+    print("== batch scaling (product dispatch) ==")
+    for b in (16, 32, 64, 128, 512):
+        run(3, 13, 0, 192, 192, 1, b)
+        run(3, 23, 0, 192, 192, 1, b)
 
 
 if __name__ == "__main__":
