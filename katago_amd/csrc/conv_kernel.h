@@ -46,7 +46,8 @@ constexpr int MT = 3;                 // board-cell tiles (of 32) per wave: 4 wa
 constexpr int MAXLEN = 19;
 
 // ablation switches (conv_bench.hip only; 0 in the product)
-enum { ABL_NO_EPILOGUE = 1, ABL_NO_COMPUTE = 2, ABL_NO_DMA = 4, ABL_NO_LDS_READ = 8, ABL_EPI_NOACT = 512, ABL_EPI_NOSTORE = 1024 };
+enum { ABL_NO_EPILOGUE = 1, ABL_NO_COMPUTE = 2, ABL_NO_DMA = 4, ABL_NO_LDS_READ = 8, ABL_NO_VMWAIT = 16, ABL_NO_W_DMA = 32, ABL_NO_A_DMA = 64, ABL_NO_STAGGER = 128,
+       ABL_EPI_NOACT = 512, ABL_EPI_NOSTORE = 1024 };
 
 template <int KS, int WN, int WNW, int D>
 struct Geom {
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
 
   // Every call issues exactly NPW instructions (into the slack area when `step` is past the end).
   auto issueW = [&](int step) {
-    if(ABL & ABL_NO_DMA) return;
+    if(ABL & (ABL_NO_DMA | ABL_NO_W_DMA)) return;
     const bool live = step < nSteps;
     const char* slab = wBase + (size_t)(live ? step : 0) * wSlabStride;
     char* dst = bufW + (step % G::NSW) * G::W_BYTES;
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   // One instruction of the board image of `chunk` (piece j; its pointer then moves on to the next chunk), or a
   // dummy into the slack area when j < 0.
   auto issueA = [&](int chunk, int j) {
-    if(ABL & ABL_NO_DMA) return;
+    if(ABL & (ABL_NO_DMA | ABL_NO_A_DMA)) return;
     const int jj = j < 0 ? 0 : j;
     const int pbase = (jj * NWAVES + wave) * 64;
     const bool live = j >= 0 && chunk < nChunks && pbase * 16 < G::ACT_BYTES;
@@ -313,7 +314,22 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   //     wait+barrier (publishes slab s+1) | read F1(s) | MFMA F0(s) | DMA for step s+D | read F0(s+1) | MFMA F1(s)
   // so every LDS read has eight MFMAs (256 matrix-core cycles) to land in, and the matrix core only idles for the
   // barrier skew between waves.
-  if(!(ABL & ABL_NO_DMA)) waitVm<G::VMCNT_PRO>();
+  // An LDS-DMA instruction holds its wave at issue for ~100+ cycles. The two waves that share a SIMD therefore place
+  // their requests for step s+D at different points of the step (after the first / after the second MFMA block), so
+  // that one of them always has MFMAs to issue.
+  const bool lateDma = !(ABL & ABL_NO_STAGGER) && WNW == 2 && D >= 3 && wave >= NWAVES / 2;
+  auto issueStep = [&](int chunk, int t, int step) {
+    issueW(step + D);
+    if(SPREAD) {
+      issueA(chunk + 1, t < NPA ? t : -1);
+    }
+    else {
+#pragma unroll
+      for(int j = 0; j < NPA; j++) issueA(chunk + D, j);
+    }
+  };
+  if(!(ABL & (ABL_NO_DMA | ABL_NO_W_DMA | ABL_NO_A_DMA))) waitVm<G::VMCNT_PRO>();
+  else waitVm<0>();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   readW(0, 0);
@@ -324,7 +340,7 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
     const unsigned nextA = (unsigned)((chunk + 1) % G::NSA) * G::ACT_BYTES;
 #pragma unroll
     for(int t = 0; t < NT; t++, step++) {
-      if(!(ABL & ABL_NO_DMA)) waitVm<G::VMCNT>();
+      if(!(ABL & (ABL_NO_DMA | ABL_NO_VMWAIT | ABL_NO_W_DMA | ABL_NO_A_DMA))) waitVm<G::VMCNT>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       // The compiler's own s_waitcnt before an MFMA drains ALL outstanding LDS reads (lgkmcnt(0)), so each batch of
@@ -337,14 +353,7 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
       __builtin_amdgcn_sched_barrier(0);
       mfmaPart(0, 1, WN * MT, acc);
       __builtin_amdgcn_sched_barrier(0);
-      issueW(step + D);
-      if(SPREAD) {
-        issueA(chunk + 1, t < NPA ? t : -1);
-      }
-      else {
-#pragma unroll
-        for(int j = 0; j < NPA; j++) issueA(chunk + D, j);
-      }
+      if(!lateDma) issueStep(chunk, t, step);
       __builtin_amdgcn_sched_barrier(0);
       mfmaPart(1, 0, 1, acc);
       __builtin_amdgcn_sched_barrier(0);
@@ -352,6 +361,8 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
       readA0(t + 1 < NT ? curA : nextA, t + 1 < NT ? t + 1 : 0);
       __builtin_amdgcn_sched_barrier(0);
       mfmaPart(1, 1, WN * MT, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      if(lateDma) issueStep(chunk, t, step);
       __builtin_amdgcn_sched_barrier(0);
     }
   }

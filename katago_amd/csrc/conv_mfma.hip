@@ -36,20 +36,19 @@ hipError_t launchConv(int dtype, int ks, int cfg, const ConvArgs& a, hipStream_t
 // 4-wave work-groups of 96 channels leave LDS and registers for a second work-group on the same CU; 8-wave
 // work-groups read the board image once for up to 192 channels. See profiles/ for the measurements behind the order.
 int chooseConvCfg(int ks, int coutPad, int batch) {
-  (void)batch;
   const int tiles = coutPad / 32;
-  static const int order4[] = {13, 12, 11};
-  static const int order8[] = {23, 22};
-  const bool prefer8 = false;
-  for(int pass = 0; pass < 2; pass++) {
-    const bool use8 = (pass == 0) == prefer8;
-    const int* order = use8 ? order8 : order4;
-    const int cnt = use8 ? 2 : 3;
-    for(int i = 0; i < cnt; i++) {
-      const int wnw = order[i] / 10, wn = order[i] % 10;
-      if(ks == 5 && use8 && wn == 3) continue;
-      if(tiles % (wn * wnw) == 0) return order[i];
-    }
+  // 8-wave work-groups (up to 192 channels of a board) once they fill the 256 CUs; below that the 4-wave shape gives
+  // twice the work-groups (measured, profiles/r01_v5/sweep_v5.log: batch 128 3x3 54 us vs 71 us, batch 256 1x1 108 vs 78).
+  static const int order8[] = {23, 22, 13, 12, 11};
+  static const int order4[] = {13, 12, 23, 22, 11};
+  int wgs8 = 0;
+  for(int i = 0; i < 2 && wgs8 == 0; i++)
+    if(tiles % (2 * (order8[i] % 10)) == 0 && !(ks == 5 && order8[i] == 23)) wgs8 = batch * (tiles / (2 * (order8[i] % 10)));
+  const int* order = wgs8 >= 200 ? order8 : order4;
+  for(int i = 0; i < 5; i++) {
+    const int wnw = order[i] / 10, wn = order[i] % 10;
+    if(ks == 5 && order[i] == 23) continue;
+    if(tiles % (wn * wnw) == 0) return order[i];
   }
   return 11;
 }
