@@ -13,7 +13,12 @@ value = rows evaluated by all ranks / max-over-ranks time ("weak" scaling: per-G
 
 Rank 0 prints ONE JSON line, including
   roofline     : the dominant kernel (3x3 implicit-GEMM convolution) — algorithmic FLOPs per launch / average
-                 launch duration measured with hipEvents on the engine's own stream inside the timed region;
+                 launch duration measured live with hipEvents on the engine's own stream. The K timed steps that give
+                 `value` run WITHOUT per-launch events (recording ~130 event pairs per step costs ~10 % of the step and
+                 would understate `value`); the same K steps are then repeated with the events on and that pass gives
+                 `roofline` (its own ms_per_step is reported next to it). `traffic` = HBM bytes per launch from the
+                 rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, the gfx950 correction of
+                 MI355X_MICROARCH.md), or null when no committed measurement matches this kernel;
   cpu_baseline : the CPU oracle (a port of the reference's Eigen path; Eigen itself is not buildable offline)
                  timed on this host's cores on a bounded sample of the same workload. Reported, not optimised against.
 """
@@ -56,7 +61,9 @@ def cpu_baseline(model_path, batch_rows, min_seconds=10.0, max_seconds=30.0):
 
     om = oracle.loadModelFile(model_path)
     sp, gl = synthetic_rows(batch_rows, 4242)
-    cores = oracle.usable_cores()
+    # the GPU box reports 256 logical CPUs; the oracle's OpenMP loops (batch x channel tiles) do not scale that far
+    # (0.26 evals/s with 256 threads), so at most 32 threads are used and that is the number reported as `cores`.
+    cores = oracle.usable_cores(32)
     rows = 0
     t0 = time.time()
     while True:
@@ -70,6 +77,23 @@ def cpu_baseline(model_path, batch_rows, min_seconds=10.0, max_seconds=30.0):
             "sample": "%d b18c384nbt 19x19 evals in batches of %d, fp32 C oracle (OpenMP), %.1f s" % (rows, batch_rows, el)}
 
 
+def committed_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the newest profiles/*/traffic.json whose workload matches, else None."""
+    import glob
+
+    best = None
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*", "traffic.json"))):
+        try:
+            t = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if t.get("kernel") == kernel and t.get("model") == args.model and t.get("batch") == args.batch and t.get("dtype") == args.dtype:
+            best = t
+    return None if best is None else {"hbm_bytes_per_launch": best["hbm_bytes_per_launch"],
+                                       "algorithmic_bytes_per_launch": best.get("algorithmic_bytes_per_launch"),
+                                       "source": best.get("source")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,7 +103,9 @@ def main():
     ap.add_argument("--model", default="b18c384nbt")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents in the timed region")
+    ap.add_argument("--no-profile", action="store_true", help="skip the second, hipEvent-instrumented pass (no roofline object)")
+    ap.add_argument("--host-buffers", action="store_true",
+                    help="also time the host-pointer entry kmx_eval (PCIe-inclusive; reported beside, never as, value)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -127,16 +153,14 @@ def main():
         capi.check(lib.kmx_eval_device(handle._p, B, d_sp.data_ptr(), d_gl.data_ptr(), sym_p, opt_p, d_pol.data_ptr(),
                                        d_val.data_ptr(), d_sc.data_ptr(), d_own.data_ptr(), 1 if sync else 0), lib)
 
+    from katago_amd import replicas
+
     def barrier():
-        if world > 1:
-            dist.barrier()
         handle.sync()
-        torch.cuda.synchronize()
+        replicas.barrier(torch.device("cuda", local_rank))
 
     for _ in range(args.warmup):
         step(True)
-    if not args.no_profile:
-        capi.check(lib.kmx_handle_set_profiling(handle._p, 1), lib)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -145,12 +169,40 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
-    if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    profiled_elapsed = None
+    if not args.no_profile:
+        # second pass over the same K steps with a hipEvent pair around every launch (engine stream)
+        capi.check(lib.kmx_handle_set_profiling(handle._p, 1), lib)
+        handle.sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(False)
+        handle.sync()
+        torch.cuda.synchronize()
+        profiled_elapsed = time.perf_counter() - t1
+    total_rows, elapsed = replicas.whole_job(args.steps * B, elapsed, torch.device("cuda", local_rank))
 
     assert torch.isfinite(d_pol).all() and torch.isfinite(d_val).all(), "non-finite outputs"
+
+    host_rate = None
+    if args.host_buffers and rank == 0:
+        # the reference's getOutput hands over host rows: same batch through kmx_eval (H2D + pass + D2H, synchronous)
+        pol = np.empty((B, S + 1), dtype=np.float32)
+        val = np.empty((B, 3), dtype=np.float32)
+        sco = np.empty((B, 6), dtype=np.float32)
+        own = np.empty((B, S), dtype=np.float32)
+        FP = ctypes.POINTER(ctypes.c_float)
+        PT = FP * B
+        sp2, gl2 = sp.reshape(B, -1), gl.reshape(B, -1)
+        f = lambda a: a.ctypes.data_as(FP)
+        ptrs = (PT(*[f(sp2[i]) for i in range(B)]), PT(*[f(gl2[i]) for i in range(B)]), PT(*[f(pol[i]) for i in range(B)]),
+                PT(*[f(own[i]) for i in range(B)]))
+        call = lambda: capi.check(lib.kmx_eval(handle._p, B, ptrs[0], ptrs[1], sym_p, opt_p, ptrs[2], f(val), f(sco), ptrs[3]), lib)
+        call()
+        th = time.perf_counter()
+        for _ in range(args.steps):
+            call()
+        host_rate = args.steps * B / (time.perf_counter() - th)
 
     roofline = None
     if not args.no_profile:
@@ -163,13 +215,13 @@ def main():
         achieved = dom.flops / (dom.total_ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         roofline = {"bound": "mfma", "kernel": dom.name.decode(), "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": None,
+                    "frac": round(achieved / peak, 4), "traffic": committed_traffic(dom.name.decode(), args),
+                    "profiled_ms_per_step": round(profiled_elapsed / args.steps * 1e3, 4),
                     "avg_launch_ms": round(dom.total_ms / dom.launches, 5), "launches": int(dom.launches),
                     "flops_per_launch": dom.flops / dom.launches,
                     "kernel_time_share": {k: round(v.total_ms / sum(e.total_ms for e in prof.values()), 4) for k, v in prof.items()}}
 
     if rank == 0:
-        total_rows = world * args.steps * B
         value = total_rows / elapsed
         flops_eval = model.info.flops_per_position * S
         out = {
@@ -182,6 +234,8 @@ def main():
                        "whole_net_frac_of_mfma_peak": round(value * flops_eval / 1e12 / (MFMA_PEAK_TFLOPS[args.dtype] * world), 4)},
             "roofline": roofline,
         }
+        if host_rate is not None:
+            out["host_buffer_evals_per_s"] = round(host_rate, 1)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model_path, 8)
         print(json.dumps(out), flush=True)

@@ -46,7 +46,7 @@ constexpr int MT = 3;                 // board-cell tiles (of 32) per wave: 4 wa
 constexpr int MAXLEN = 19;
 
 // ablation switches (conv_bench.hip only; 0 in the product)
-enum { ABL_NO_EPILOGUE = 1, ABL_NO_COMPUTE = 2, ABL_NO_DMA = 4, ABL_NO_LDS_READ = 8, ABL_NO_VMWAIT = 16, ABL_NO_W_DMA = 32, ABL_NO_A_DMA = 64, ABL_NO_STAGGER = 128,
+enum { ABL_NO_EPILOGUE = 1, ABL_NO_COMPUTE = 2, ABL_NO_DMA = 4, ABL_NO_LDS_READ = 8, ABL_NO_VMWAIT = 16, ABL_NO_W_DMA = 32, ABL_NO_A_DMA = 64,
        ABL_EPI_NOACT = 512, ABL_EPI_NOSTORE = 1024 };
 
 template <int KS, int WN, int WNW, int D>
@@ -314,10 +314,6 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   //     wait+barrier (publishes slab s+1) | read F1(s) | MFMA F0(s) | DMA for step s+D | read F0(s+1) | MFMA F1(s)
   // so every LDS read has eight MFMAs (256 matrix-core cycles) to land in, and the matrix core only idles for the
   // barrier skew between waves.
-  // An LDS-DMA instruction holds its wave at issue for ~100+ cycles. The two waves that share a SIMD therefore place
-  // their requests for step s+D at different points of the step (after the first / after the second MFMA block), so
-  // that one of them always has MFMAs to issue.
-  const bool lateDma = !(ABL & ABL_NO_STAGGER) && WNW == 2 && D >= 3 && wave >= NWAVES / 2;
   auto issueStep = [&](int chunk, int t, int step) {
     issueW(step + D);
     if(SPREAD) {
@@ -353,7 +349,7 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
       __builtin_amdgcn_sched_barrier(0);
       mfmaPart(0, 1, WN * MT, acc);
       __builtin_amdgcn_sched_barrier(0);
-      if(!lateDma) issueStep(chunk, t, step);
+      issueStep(chunk, t, step);
       __builtin_amdgcn_sched_barrier(0);
       mfmaPart(1, 0, 1, acc);
       __builtin_amdgcn_sched_barrier(0);
@@ -361,8 +357,6 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
       readA0(t + 1 < NT ? curA : nextA, t + 1 < NT ? t + 1 : 0);
       __builtin_amdgcn_sched_barrier(0);
       mfmaPart(1, 1, WN * MT, acc);
-      __builtin_amdgcn_sched_barrier(0);
-      if(lateDma) issueStep(chunk, t, step);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
