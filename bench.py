@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — NN evals/s of the katamx HIP backend on the BASELINE.json workload.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 100 --warmup 10      (defaults; ~2 s of GPU time plus ~15 s of CPU baseline)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -15,7 +15,7 @@ Rank 0 prints ONE JSON line, including
   roofline     : the dominant kernel (3x3 implicit-GEMM convolution) — algorithmic FLOPs per launch / average
                  launch duration measured live with hipEvents on the engine's own stream. The K timed steps that give
                  `value` run WITHOUT per-launch events (recording ~130 event pairs per step costs ~10 % of the step and
-                 would understate `value`); the same K steps are then repeated with the events on and that pass gives
+                 would understate `value`); min(K, 20) of the same steps are then repeated with the events on and that pass gives
                  `roofline` (its own ms_per_step is reported next to it). `traffic` = HBM bytes per launch from the
                  rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, the gfx950 correction of
                  MI355X_MICROARCH.md), or null when no committed measurement matches this kernel;
@@ -89,16 +89,14 @@ def committed_traffic(kernel, args):
             continue
         if t.get("kernel") == kernel and t.get("model") == args.model and t.get("batch") == args.batch and t.get("dtype") == args.dtype:
             best = t
-    return None if best is None else {"hbm_bytes_per_launch": best["hbm_bytes_per_launch"],
-                                       "algorithmic_bytes_per_launch": best.get("algorithmic_bytes_per_launch"),
-                                       "source": best.get("source")}
+    return None if best is None else {"hbm_bytes_per_launch": best["hbm_bytes_per_launch"], "source": best.get("source")}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--model", default="b18c384nbt")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
@@ -172,17 +170,26 @@ def main():
     profiled_elapsed = None
     if not args.no_profile:
         # second pass over the same K steps with a hipEvent pair around every launch (engine stream)
+        prof_steps = min(args.steps, 20)  # ~130 event pairs per step are kept until they are read back
         capi.check(lib.kmx_handle_set_profiling(handle._p, 1), lib)
         handle.sync()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(prof_steps):
             step(False)
         handle.sync()
         torch.cuda.synchronize()
-        profiled_elapsed = time.perf_counter() - t1
+        profiled_elapsed = (time.perf_counter() - t1) / prof_steps * args.steps
     total_rows, elapsed = replicas.whole_job(args.steps * B, elapsed, torch.device("cuda", local_rank))
 
     assert torch.isfinite(d_pol).all() and torch.isfinite(d_val).all(), "non-finite outputs"
+
+    prof_entries = None
+    if not args.no_profile:
+        ent = (capi.ProfileEntry * 32)()
+        cnt = ctypes.c_int()
+        capi.check(lib.kmx_handle_get_profile(handle._p, ent, 32, ctypes.byref(cnt)), lib)
+        prof_entries = {ent[i].name.decode(): (ent[i].launches, ent[i].total_ms, ent[i].flops, ent[i].bytes) for i in range(cnt.value)}
+        capi.check(lib.kmx_handle_set_profiling(handle._p, 0), lib)
 
     host_rate = None
     if args.host_buffers and rank == 0:
@@ -205,21 +212,17 @@ def main():
         host_rate = args.steps * B / (time.perf_counter() - th)
 
     roofline = None
-    if not args.no_profile:
-        ent = (capi.ProfileEntry * 32)()
-        cnt = ctypes.c_int()
-        capi.check(lib.kmx_handle_get_profile(handle._p, ent, 32, ctypes.byref(cnt)), lib)
-        prof = {ent[i].name.decode(): ent[i] for i in range(cnt.value)}
-        capi.check(lib.kmx_handle_set_profiling(handle._p, 0), lib)
-        dom = max(prof.values(), key=lambda e: e.total_ms)
-        achieved = dom.flops / (dom.total_ms * 1e-3) / 1e12
+    if prof_entries:
+        total_ms = sum(v[1] for v in prof_entries.values())
+        name, (launches, ms, flops, nbytes) = max(prof_entries.items(), key=lambda kv: kv[1][1])
+        achieved = flops / (ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[args.dtype]
-        roofline = {"bound": "mfma", "kernel": dom.name.decode(), "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": committed_traffic(dom.name.decode(), args),
+        roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": committed_traffic(name, args),
                     "profiled_ms_per_step": round(profiled_elapsed / args.steps * 1e3, 4),
-                    "avg_launch_ms": round(dom.total_ms / dom.launches, 5), "launches": int(dom.launches),
-                    "flops_per_launch": dom.flops / dom.launches,
-                    "kernel_time_share": {k: round(v.total_ms / sum(e.total_ms for e in prof.values()), 4) for k, v in prof.items()}}
+                    "avg_launch_ms": round(ms / launches, 5), "launches": int(launches),
+                    "flops_per_launch": flops / launches, "algorithmic_bytes_per_launch": nbytes / launches,
+                    "kernel_time_share": {k: round(v[1] / total_ms, 4) for k, v in prof_entries.items()}}
 
     if rank == 0:
         value = total_rows / elapsed

@@ -12,9 +12,12 @@ import sys
 
 
 def short(name):
-    m = re.search(r"convMfmaKernel<kmx::(Traits\w+), (\d+), (\d+), (\d+), (\d+)>", name)
+    m = re.search(r"convMfmaKernel<kmx::(Traits\w+), (\d+), (\d+), (\d+), (\d+), (\d+)>", name)
     if m:
-        return "convMfmaKernel<%s,KS=%s,WN=%s,D=%s,ABL=%s>" % m.groups()
+        return "convMfmaKernel<%s,KS=%s,WN=%s,WNW=%s,D=%s,ABL=%s>" % m.groups()
+    m = re.search(r"convMfmaKernelINS_\d+(Traits\w+?)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)  # mangled form
+    if m:
+        return "convMfmaKernel<%s,KS=%s,WN=%s,WNW=%s,D=%s,ABL=%s>" % m.groups()
     return re.sub(r"\(.*", "", name)[:80]
 
 
