@@ -157,14 +157,28 @@ __global__ __launch_bounds__(GV_THREADS) void gpoolApplyVecKernel(const GPoolArg
 #pragma unroll
     for(int i = 0; i < 8; i++) { s[i] = 0.0f; m[i] = -1.0f; }
     if(grp < cellGroups) {
-      for(int p = grp; p < S; p += cellGroups) {
-        const V8 x = *(const V8*)((const T*)a.g + (cell0 + p) * a.gStride + a.gOffset + cg * 8);
-        const float mk = maskB[p] - 1.0f;
+      constexpr int UN1 = 6;  // a 19x19 board is 6 strides of 64 cell groups: all loads of a thread in flight at once
+      for(int p0 = grp; p0 < S; p0 += cellGroups * UN1) {
+        V8 xs[UN1];
+        float mk[UN1];
 #pragma unroll
-        for(int i = 0; i < 8; i++) {
-          const float v = TR::toFloat(x[i]);
-          s[i] += v;
-          m[i] = fmaxf(m[i], v + mk);
+        for(int u = 0; u < UN1; u++) {
+          const int p = p0 + u * cellGroups;
+          if(p < S) {
+            xs[u] = *(const V8*)((const T*)a.g + (cell0 + p) * a.gStride + a.gOffset + cg * 8);
+            mk[u] = maskB[p] - 1.0f;
+          }
+        }
+#pragma unroll
+        for(int u = 0; u < UN1; u++) {
+          if(p0 + u * cellGroups < S) {
+#pragma unroll
+            for(int i = 0; i < 8; i++) {
+              const float v = TR::toFloat(xs[u][i]);
+              s[i] += v;
+              m[i] = fmaxf(m[i], v + mk[u]);
+            }
+          }
         }
       }
 #pragma unroll
@@ -191,27 +205,57 @@ __global__ __launch_bounds__(GV_THREADS) void gpoolApplyVecKernel(const GPoolArg
   __syncthreads();
   if(a.featOut != nullptr)
     for(int i = tid; i < 3 * G; i += GV_THREADS) a.featOut[(size_t)n * 3 * G + i] = feat[i];
-  for(int r = tid; r < R; r += GV_THREADS) {
-    float s = 0.0f;
-    for(int k = 0; k < 3 * G; k++) s += feat[k] * a.w[(size_t)k * R + r];
-    biasv[r] = s;
+  // [3G] x [3G][R] with every thread busy: the k range is split over KG thread groups (partials in LDS). One thread per
+  // output looping over all 3G weights is a chain of ~200 L2 round trips and was a third of this kernel's 70 us.
+  {
+    const int KG = GV_THREADS / R > 0 ? (GV_THREADS / R < 8 ? GV_THREADS / R : 8) : 1;
+    const int K = 3 * G;
+    float* partial = partSum;  // [KG][R], the pooling partials are dead
+    for(int idx = tid; idx < KG * R; idx += GV_THREADS) {
+      const int kg = idx / R, r = idx - kg * R;
+      const int k0 = kg * K / KG, k1 = (kg + 1) * K / KG;
+      float acc = 0.0f;
+#pragma unroll 8
+      for(int k = k0; k < k1; k++) acc += feat[k] * a.w[(size_t)k * R + r];
+      partial[idx] = acc;
+    }
+    __syncthreads();
+    for(int r = tid; r < R; r += GV_THREADS) {
+      float acc = 0.0f;
+      for(int kg = 0; kg < KG; kg++) acc += partial[kg * R + r];
+      biasv[r] = acc;
+    }
   }
   __syncthreads();
   const int RV = R / 8;
   const int total = S * RV;
-  for(int i = tid; i < total; i += GV_THREADS) {
-    const int p = i / RV, rv = i - p * RV;
-    T* ptr = (T*)a.r + (cell0 + p) * a.rStride + a.rOffset + rv * 8;
-    V8 x = *(const V8*)ptr;
-    const bool on = maskB[p] == 1.0f;
-    V8 y;
+  constexpr int UN = 4;  // loads of UN iterations in flight before the first is consumed
+  for(int i0 = tid; i0 < total; i0 += GV_THREADS * UN) {
+    V8 x[UN];
 #pragma unroll
-    for(int k = 0; k < 8; k++) {
-      const int r = rv * 8 + k;
-      const float v = TR::toFloat(x[k]) + biasv[r];
-      y[k] = TR::fromFloat(on ? actApply(v * a.scale[r] + a.bias[r], a.actKind) : 0.0f);
+    for(int u = 0; u < UN; u++) {
+      const int i = i0 + u * GV_THREADS;
+      if(i < total) {
+        const int p = i / RV, rv = i - p * RV;
+        x[u] = *(const V8*)((const T*)a.r + (cell0 + p) * a.rStride + a.rOffset + rv * 8);
+      }
     }
-    *(V8*)ptr = y;
+#pragma unroll
+    for(int u = 0; u < UN; u++) {
+      const int i = i0 + u * GV_THREADS;
+      if(i < total) {
+        const int p = i / RV, rv = i - p * RV;
+        const bool on = maskB[p] == 1.0f;
+        V8 y;
+#pragma unroll
+        for(int k = 0; k < 8; k++) {
+          const int r = rv * 8 + k;
+          const float v = TR::toFloat(x[u][k]) + biasv[r];
+          y[k] = TR::fromFloat(on ? actApply(v * a.scale[r] + a.bias[r], a.actKind) : 0.0f);
+        }
+        *(V8*)((T*)a.r + (cell0 + p) * a.rStride + a.rOffset + rv * 8) = y;
+      }
+    }
   }
 }
 
@@ -334,6 +378,175 @@ __global__ __launch_bounds__(BT) void valueFinalKernel(const ValueArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Vectorised tails (channel counts, strides and offsets multiples of 8 — every real net; the scalar kernels above stay
+// as the general fallback). Same arithmetic, 16-byte loads, reductions spread over all threads: the scalar versions
+// were chains of dependent 2-byte loads and took 73 us (policy) and 110 us (value) per batch of 256.
+template <class TR>
+__global__ __launch_bounds__(BT) void policyFinalVecKernel(const PolicyArgs a) {
+  typedef typename TR::T T;
+  typedef typename TR::V8 V8;
+  extern __shared__ float sm[];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int S = a.X * a.Y, P = a.P, NP = a.NP, H = a.passHidden;
+  float* w2s = sm;               // [P][NP]
+  float* hidden = w2s + P * NP;  // [H]
+  float* partial = hidden + (H > 0 ? H : 1);  // [KG][H]
+  const int sym = a.symmetry ? a.symmetry[n] : 0;
+  const float opt = a.optimism ? a.optimism[n] : 0.0f;
+  const bool blend = (NP == 2 || NP == 4);  // channels 0,1 = policy, optimistic policy (eigenbackend.cpp:2553)
+  float* out = a.out + (size_t)n * (S + 1);
+  for(int i = tid; i < P * NP; i += BT) w2s[i] = a.w2[i];
+  __syncthreads();
+  const int PV = P / 8;
+  for(int p = tid; p < S; p += BT) {
+    const T* row = (const T*)a.p + ((size_t)n * S + p) * a.pStride + a.pOffset;
+    float l0 = 0.0f, l1 = 0.0f;
+    for(int cv = 0; cv < PV; cv++) {
+      const V8 x = *(const V8*)(row + cv * 8);
+#pragma unroll
+      for(int i = 0; i < 8; i++) {
+        const float xv = TR::toFloat(x[i]);
+        l0 += xv * w2s[(cv * 8 + i) * NP];
+        if(blend) l1 += xv * w2s[(cv * 8 + i) * NP + 1];
+      }
+    }
+    const float v = blend ? l0 + (l1 - l0) * opt : l0;
+    const int h = p / a.X, w = p - h * a.X;
+    out[symDst(h, w, a.Y, a.X, sym, true)] = v;
+  }
+  // pass logit
+  const float* feat = a.feat + (size_t)n * a.G3;
+  if(H > 0) {
+    const int KG = BT / H > 0 ? (BT / H < 8 ? BT / H : 8) : 1;
+    for(int idx = tid; idx < KG * H; idx += BT) {
+      const int kg = idx / H, j = idx - kg * H;
+      const int k0 = kg * a.G3 / KG, k1 = (kg + 1) * a.G3 / KG;
+      float acc = 0.0f;
+#pragma unroll 8
+      for(int k = k0; k < k1; k++) acc += feat[k] * a.wPass[(size_t)k * H + j];
+      partial[idx] = acc;
+    }
+    __syncthreads();
+    for(int j = tid; j < H; j += BT) {
+      float acc = 0.0f;
+      for(int kg = 0; kg < KG; kg++) acc += partial[kg * H + j];
+      hidden[j] = actApply(acc + a.bPass[j], a.passAct);
+    }
+    __syncthreads();
+    if(tid == 0) {
+      float p0 = 0.0f, p1 = 0.0f;
+      for(int j = 0; j < H; j++) {
+        p0 += hidden[j] * a.wPass2[(size_t)j * NP];
+        if(blend) p1 += hidden[j] * a.wPass2[(size_t)j * NP + 1];
+      }
+      out[S] = blend ? p0 + (p1 - p0) * opt : p0;
+    }
+  }
+  else if(tid == 0) {
+    float p0 = 0.0f, p1 = 0.0f;
+    for(int k = 0; k < a.G3; k++) {
+      p0 += feat[k] * a.wPass[(size_t)k * NP];
+      if(blend) p1 += feat[k] * a.wPass[(size_t)k * NP + 1];
+    }
+    out[S] = blend ? p0 + (p1 - p0) * opt : p0;
+  }
+}
+
+template <class TR>
+__global__ __launch_bounds__(BT) void valueFinalVecKernel(const ValueArgs a) {
+  typedef typename TR::T T;
+  typedef typename TR::V8 V8;
+  extern __shared__ float sm[];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int S = a.X * a.Y, V1 = a.V1, V2 = a.V2;
+  const int NG = V1 / 8;          // channel groups of 8
+  const int cellGroups = BT / NG;  // threads striding over the board per channel group
+  const int KG = BT / V2 > 0 ? (BT / V2 < 8 ? BT / V2 : 8) : 1;
+  // layout: feat[3*V1], hid[V2], wown[V1], part[max(cellGroups*V1, KG*V2)]
+  float* feat = sm;
+  float* hid = feat + 3 * V1;
+  float* wown = hid + V2;
+  float* part = wown + V1;
+  const int sym = a.symmetry ? a.symmetry[n] : 0;
+  const size_t cell0 = (size_t)n * S;
+  const T* vb = (const T*)a.v + cell0 * a.vStride + a.vOffset;
+  for(int i = tid; i < V1; i += BT) wown[i] = a.wOwn[i];
+  // pooling (poolRowsValueHead, eigenbackend.cpp:179-197)
+  {
+    const int cg = tid % NG, grp = tid / NG;
+    if(grp < cellGroups) {
+      float s[8];
+#pragma unroll
+      for(int i = 0; i < 8; i++) s[i] = 0.0f;
+      for(int p = grp; p < S; p += cellGroups) {
+        const V8 x = *(const V8*)(vb + (size_t)p * a.vStride + cg * 8);
+#pragma unroll
+        for(int i = 0; i < 8; i++) s[i] += TR::toFloat(x[i]);
+      }
+#pragma unroll
+      for(int i = 0; i < 8; i++) part[grp * V1 + cg * 8 + i] = s[i];
+    }
+  }
+  __syncthreads();
+  for(int c = tid; c < V1; c += BT) {
+    float ts = 0.0f;
+    for(int g = 0; g < cellGroups; g++) ts += part[g * V1 + c];
+    const float div = a.maskSum[n];
+    const float sqrtdiv = sqrtf(div);
+    const float mean = ts / div;
+    feat[c] = mean;
+    feat[V1 + c] = mean * (sqrtdiv - 14.0f) * 0.1f;
+    feat[2 * V1 + c] = mean * ((sqrtdiv - 14.0f) * (sqrtdiv - 14.0f) * 0.01f - 0.1f);
+  }
+  __syncthreads();
+  // v2: [3V1] x [3V1][V2], k range split over KG thread groups
+  for(int idx = tid; idx < KG * V2; idx += BT) {
+    const int kg = idx / V2, j = idx - kg * V2;
+    const int k0 = kg * 3 * V1 / KG, k1 = (kg + 1) * 3 * V1 / KG;
+    float acc = 0.0f;
+#pragma unroll 8
+    for(int k = k0; k < k1; k++) acc += feat[k] * a.w2[(size_t)k * V2 + j];
+    part[idx] = acc;
+  }
+  __syncthreads();
+  for(int j = tid; j < V2; j += BT) {
+    float acc = 0.0f;
+    for(int kg = 0; kg < KG; kg++) acc += part[kg * V2 + j];
+    hid[j] = actApply(acc + a.b2[j], a.v2Act);
+  }
+  __syncthreads();
+  if(tid < 3) {
+    float s = 0.0f;
+    for(int j = 0; j < V2; j++) s += hid[j] * a.w3[(size_t)j * 3 + tid];
+    a.value[(size_t)n * 3 + tid] = s + a.b3[tid];
+  }
+  else if(tid >= 32 && tid < 32 + 6) {
+    const int k = tid - 32;
+    float s = 0.0f;
+    if(k < a.NSV) {
+      for(int j = 0; j < V2; j++) s += hid[j] * a.wsv[(size_t)j * a.NSV + k];
+      s += a.bsv[k];
+    }
+    a.score[(size_t)n * 6 + k] = s;
+  }
+  // ownership: 1x1 conv V1 -> 1, then inverse symmetry
+  if(a.ownership != nullptr) {
+    float* own = a.ownership + (size_t)n * S;
+    for(int p = tid; p < S; p += BT) {
+      const T* row = vb + (size_t)p * a.vStride;
+      float s = 0.0f;
+      for(int cv = 0; cv < NG; cv++) {
+        const V8 x = *(const V8*)(row + cv * 8);
+#pragma unroll
+        for(int i = 0; i < 8; i++) s += TR::toFloat(x[i]) * wown[cv * 8 + i];
+      }
+      const int h = p / a.X, w = p - h * a.X;
+      own[symDst(h, w, a.Y, a.X, sym, true)] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 template <class TR>
 __global__ void bnActKernel(const BnActArgs a) {
   const size_t total = (size_t)a.N * a.S * a.C;
@@ -397,10 +610,21 @@ hipError_t launchGPoolApply(int dtype, const GPoolArgs& a, hipStream_t stream) {
   KMX_DISPATCH(dtype, gpoolApplyKernel, dim3(a.N), dim3(BT), lds, stream, a);
 }
 hipError_t launchPolicyFinal(int dtype, const PolicyArgs& a, hipStream_t stream) {
+  if(a.P % 8 == 0 && a.pStride % 8 == 0 && a.pOffset % 8 == 0 && a.passHidden <= BT) {
+    const int H = a.passHidden > 0 ? a.passHidden : 1;
+    size_t lds = sizeof(float) * ((size_t)a.P * a.NP + H + (size_t)8 * H);
+    KMX_DISPATCH(dtype, policyFinalVecKernel, dim3(a.N), dim3(BT), lds, stream, a);
+  }
   size_t lds = sizeof(float) * (a.passHidden > 0 ? a.passHidden : 1);
   KMX_DISPATCH(dtype, policyFinalKernel, dim3(a.N), dim3(BT), lds, stream, a);
 }
 hipError_t launchValueFinal(int dtype, const ValueArgs& a, hipStream_t stream) {
+  if(a.V1 % 8 == 0 && a.V1 / 8 <= BT && a.vStride % 8 == 0 && a.vOffset % 8 == 0 && a.V2 <= BT) {
+    const size_t cellGroups = BT / (a.V1 / 8);
+    const size_t partN = cellGroups * a.V1 > (size_t)8 * a.V2 ? cellGroups * a.V1 : (size_t)8 * a.V2;
+    size_t lds = sizeof(float) * ((size_t)3 * a.V1 + a.V2 + a.V1 + partN);
+    KMX_DISPATCH(dtype, valueFinalVecKernel, dim3(a.N), dim3(BT), lds, stream, a);
+  }
   size_t lds = sizeof(float) * (BT + 3 * a.V1 + a.V2);
   KMX_DISPATCH(dtype, valueFinalKernel, dim3(a.N), dim3(BT), lds, stream, a);
 }
