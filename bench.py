@@ -16,7 +16,9 @@ Rank 0 prints ONE JSON line, including
                  launch duration measured live with hipEvents on the engine's own stream. The K timed steps that give
                  `value` run WITHOUT per-launch events (recording ~130 event pairs per step costs ~10 % of the step and
                  would understate `value`); min(K, 20) of the same steps are then repeated with the events on and that pass gives
-                 `roofline` (its own ms_per_step is reported next to it). `traffic` = HBM bytes per launch from the
+                 `roofline` (its own ms_per_step is reported next to it); that pass runs the batch on ONE stream so that
+                 a launch has the chip to itself, whereas the timed pass uses the product default for batch 256 — two
+                 half-batches on two streams, whose kernels share the CUs (+6 % evals/s). `traffic` = HBM bytes per launch from the
                  rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, the gfx950 correction of
                  MI355X_MICROARCH.md), or null when no committed measurement matches this kernel;
   cpu_baseline : the CPU oracle (a port of the reference's Eigen path; Eigen itself is not buildable offline)
@@ -171,6 +173,9 @@ def main():
     if not args.no_profile:
         # second pass over the same K steps with a hipEvent pair around every launch (engine stream)
         prof_steps = min(args.steps, 20)  # ~130 event pairs per step are kept until they are read back
+        # the roofline is the kernel's with the chip to itself: one stream (the timed pass above runs the product
+        # default, two half-batches on two streams, where two launches share the CUs and each takes longer)
+        capi.check(lib.kmx_handle_set_split_min(handle._p, 0), lib)
         capi.check(lib.kmx_handle_set_profiling(handle._p, 1), lib)
         handle.sync()
         t1 = time.perf_counter()
@@ -190,6 +195,7 @@ def main():
         capi.check(lib.kmx_handle_get_profile(handle._p, ent, 32, ctypes.byref(cnt)), lib)
         prof_entries = {ent[i].name.decode(): (ent[i].launches, ent[i].total_ms, ent[i].flops, ent[i].bytes) for i in range(cnt.value)}
         capi.check(lib.kmx_handle_set_profiling(handle._p, 0), lib)
+        capi.check(lib.kmx_handle_set_split_min(handle._p, 224), lib)
 
     host_rate = None
     if args.host_buffers and rank == 0:
@@ -219,6 +225,7 @@ def main():
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": committed_traffic(name, args),
+                    "pass": "single stream, hipEvent pair per launch (the timed pass runs two half-batch streams)",
                     "profiled_ms_per_step": round(profiled_elapsed / args.steps * 1e3, 4),
                     "avg_launch_ms": round(ms / launches, 5), "launches": int(launches),
                     "flops_per_launch": flops / launches, "algorithmic_bytes_per_launch": nbytes / launches,

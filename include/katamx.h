@@ -168,6 +168,11 @@ typedef struct kmx_profile_entry {
   double flops;
   double bytes;
 } kmx_profile_entry;
+/* Large batches are evaluated as two halves on two HIP streams (two engines inside the handle) when the handle was
+ * created with max_batch_size >= the split threshold (default 224 rows, environment KMX_SPLIT_MIN at creation; 0 = off):
+ * one half's memory-bound phases overlap the other's MFMA loops. min_rows = 0 turns splitting off for later calls (used
+ * to time a kernel with the chip to itself), any other value sets the smallest batch that is split. */
+int kmx_handle_set_split_min(kmx_handle* handle, int min_rows);
 int kmx_handle_set_profiling(kmx_handle* handle, int enabled); /* resets the accumulated profile */
 int kmx_handle_get_profile(kmx_handle* handle, kmx_profile_entry* entries, int max_entries, int* n_entries);
 /* Average duration (ms, hipEvents) of one launch of the bf16 convolution kernel on synthetic data: kernel size ks,

@@ -1,4 +1,6 @@
 // conv_mfma.hip — product instantiations and dispatch of the MFMA convolution (kernel: conv_kernel.h).
+#include <cstdlib>
+
 #include "conv_kernel.h"
 
 namespace kmx {
@@ -32,24 +34,33 @@ hipError_t launchConv(int dtype, int ks, int cfg, const ConvArgs& a, hipStream_t
   return hipErrorInvalidValue;
 }
 
-// Work-group shape for a convolution with coutPad (a multiple of 32) output channels on `batch` boards.
-// 4-wave work-groups of 96 channels leave LDS and registers for a second work-group on the same CU; 8-wave
-// work-groups read the board image once for up to 192 channels. See profiles/ for the measurements behind the order.
+// Work-group shape for a convolution with coutPad (a multiple of 32) output channels on `batch` boards (the caller
+// passes boards x concurrent streams). Rules read off tools/small_batch_sweep.py on MI355X
+// (profiles/r01_final/small_batch_sweep.log): a work-group's time is set by its 6..12 x taps steps almost regardless of
+// how many channels it covers, so while the chip is not full the NARROWEST shape (most work-groups) wins: one board
+// of a 3x3 192->192 takes 21.6 us as 6 work-groups of 32 channels, 42.6 us as 2 of 96, 61.7 us as 1 of 192. Once the
+// narrow shape would need more than one round of work-groups, the next wider one takes over; the 8-wave shapes
+// (one image fetch for 128/192 channels) win when they alone fill most of the 256 CUs.
 int chooseConvCfg(int ks, int coutPad, int batch) {
   const int tiles = coutPad / 32;
-  // 8-wave work-groups (up to 192 channels of a board) once they fill the 256 CUs; below that the 4-wave shape gives
-  // twice the work-groups (measured, profiles/r01_v5/sweep_v5.log: batch 128 3x3 54 us vs 71 us, batch 256 1x1 108 vs 78).
-  static const int order8[] = {23, 22, 13, 12, 11};
-  static const int order4[] = {13, 12, 23, 22, 11};
-  int wgs8 = 0;
-  for(int i = 0; i < 2 && wgs8 == 0; i++)
-    if(tiles % (2 * (order8[i] % 10)) == 0 && !(ks == 5 && order8[i] == 23)) wgs8 = batch * (tiles / (2 * (order8[i] % 10)));
-  const int* order = wgs8 >= 200 ? order8 : order4;
-  for(int i = 0; i < 5; i++) {
-    const int wnw = order[i] / 10, wn = order[i] % 10;
-    if(ks == 5 && order[i] == 23) continue;
-    if(tiles % (wn * wnw) == 0) return order[i];
+  static const int minWgs8 = [] {  // experiments only: KMX_MIN_WGS8 moves the switch to the 8-wave x 192 shape
+    const char* e = getenv("KMX_MIN_WGS8");
+    return e ? atoi(e) : 150;
+  }();
+  auto fits = [&](int cfg) { return tiles % ((cfg / 10) * (cfg % 10)) == 0 && !(ks == 1 && cfg == 13); };
+  auto wgs = [&](int cfg) { return batch * (tiles / ((cfg / 10) * (cfg % 10))); };
+  const int widest8 = fits(23) ? 23 : fits(22) ? 22 : 0;
+  if(widest8 && wgs(widest8) >= minWgs8) return widest8;
+  // 3x3/5x5 narrow shapes keep two work-groups per CU (LDS), 1x1 shapes one
+  const int round = ks == 1 ? 200 : 420;
+  if(fits(11) && wgs(11) <= round) return 11;
+  if(fits(12) && wgs(12) <= round) return 12;
+  if(ks == 1) {
+    if(fits(22) && wgs(22) <= round) return 22;
+    if(widest8) return widest8;
   }
+  if(fits(13)) return 13;
+  if(fits(12)) return 12;
   return 11;
 }
 

@@ -153,8 +153,12 @@ Engine::Engine(const ModelDesc& model, int nnXLen, int nnYLen, int maxBatch, int
   hipCheck(hipHostMalloc((void**)&hValue_, (size_t)maxBatch_ * 3 * sizeof(float)), "hipHostMalloc");
   hipCheck(hipHostMalloc((void**)&hScore_, (size_t)maxBatch_ * 6 * sizeof(float)), "hipHostMalloc");
   hipCheck(hipHostMalloc((void**)&hOwnership_, NS * sizeof(float)), "hipHostMalloc");
-  hipCheck(hipHostMalloc((void**)&hSymmetry_, (size_t)maxBatch_ * sizeof(int)), "hipHostMalloc");
-  hipCheck(hipHostMalloc((void**)&hOptimism_, (size_t)maxBatch_ * sizeof(float)), "hipHostMalloc");
+  hipCheck(hipHostMalloc((void**)&hSymmetry_, (size_t)2 * maxBatch_ * sizeof(int)), "hipHostMalloc");
+  hipCheck(hipHostMalloc((void**)&hOptimism_, (size_t)2 * maxBatch_ * sizeof(float)), "hipHostMalloc");
+  for(int i = 0; i < 2; i++) {
+    hipCheck(hipEventCreateWithFlags(&stagingDone_[i], hipEventDisableTiming), "hipEventCreate");
+    hipCheck(hipEventRecord(stagingDone_[i], stream_), "hipEventRecord");
+  }
   buildSchedule(model);
   hipCheck(hipStreamSynchronize(stream_), "sync after build");
 }
@@ -166,6 +170,8 @@ Engine::~Engine() {
     (void)hipEventDestroy(p.b);
   }
   for(hipEvent_t e : eventPool_) (void)hipEventDestroy(e);
+  for(int i = 0; i < 2; i++)
+    if(stagingDone_[i]) (void)hipEventDestroy(stagingDone_[i]);
   (void)hipHostFree(hSpatial_);
   (void)hipHostFree(hGlobal_);
   (void)hipHostFree(hPolicy_);
@@ -228,7 +234,7 @@ void Engine::addConv(const FusedConv* fc, const void* in, int inStride, const fl
   addOp(ks == 1 ? "conv1x1" : ks == 3 ? "conv3x3" : "conv5x5", 2.0 * fc->macPerCell * S_, bytes, [=](int n, hipStream_t st) {
     ConvArgs b = a;
     b.N = n;
-    hipCheck(launchConv(dtype, ks, chooseConvCfg(ks, coutPad, n), b, st), "convolution launch");
+    hipCheck(launchConv(dtype, ks, chooseConvCfg(ks, coutPad, n * cfgScale_), b, st), "convolution launch");
   });
 }
 
@@ -528,30 +534,39 @@ std::vector<Engine::ProfileEntry> Engine::getProfile() {
 
 void Engine::sync() { hipCheck(hipStreamSynchronize(stream_), "stream synchronize"); }
 
+// symmetry / optimism of the rows -> device. Pinned staging is double-buffered: the slot used two calls ago is free as
+// soon as ITS copies have run, so back-to-back asynchronous calls queue up without draining the stream in between.
+void Engine::stageRowParams(int n, const int* symmetry, const float* policyOptimism) {
+  const int slot = stagingSlot_;
+  stagingSlot_ ^= 1;
+  hipCheck(hipEventSynchronize(stagingDone_[slot]), "staging slot");
+  int* hs = hSymmetry_ + (size_t)slot * maxBatch_;
+  float* ho = hOptimism_ + (size_t)slot * maxBatch_;
+  for(int i = 0; i < n; i++) {
+    hs[i] = symmetry ? symmetry[i] : 0;
+    ho[i] = policyOptimism ? policyOptimism[i] : 0.0f;
+  }
+  hipCheck(hipMemcpyAsync(dSymmetry_.get(), hs, n * sizeof(int), hipMemcpyHostToDevice, stream_), "H2D symmetry");
+  hipCheck(hipMemcpyAsync(dOptimism_.get(), ho, n * sizeof(float), hipMemcpyHostToDevice, stream_), "H2D optimism");
+  hipCheck(hipEventRecord(stagingDone_[slot], stream_), "hipEventRecord");
+}
+
 void Engine::evalDevice(int n, const float* dSpatial, const float* dGlobal, const int* symmetry, const float* policyOptimism,
                         float* dPolicy, float* dValue, float* dScore, float* dOwnership, bool doSync) {
   if(n < 1 || n > maxBatch_) throw Error(KMX_ERR_INVALID_ARG, "batch size out of range for this handle");
   hipCheck(hipSetDevice(device_), "hipSetDevice");
-  // the pinned staging of the previous call must have been consumed before it is overwritten
-  hipCheck(hipStreamSynchronize(stream_), "stream synchronize");
-  for(int i = 0; i < n; i++) {
-    hSymmetry_[i] = symmetry ? symmetry[i] : 0;
-    hOptimism_[i] = policyOptimism ? policyOptimism[i] : 0.0f;
-  }
-  hipCheck(hipMemcpyAsync(dSymmetry_.get(), hSymmetry_, n * sizeof(int), hipMemcpyHostToDevice, stream_), "H2D symmetry");
-  hipCheck(hipMemcpyAsync(dOptimism_.get(), hOptimism_, n * sizeof(float), hipMemcpyHostToDevice, stream_), "H2D optimism");
+  stageRowParams(n, symmetry, policyOptimism);
   runSchedule(n, dSpatial, dGlobal, dPolicy, dValue, dScore, dOwnership);
   rows_ += (uint64_t)n;
   batches_ += 1;
   if(doSync) sync();
 }
 
-void Engine::evalHost(int n, const float* const* rowSpatial, const float* const* rowGlobal, const int* symmetry,
-                      const float* policyOptimism, float* const* outPolicy, float* outValue, float* outScore,
-                      float* const* outOwnership) {
+void Engine::evalHostBegin(int n, const float* const* rowSpatial, const float* const* rowGlobal, const int* symmetry,
+                           const float* policyOptimism, float* const* outOwnership) {
   if(n < 1 || n > maxBatch_) throw Error(KMX_ERR_INVALID_ARG, "batch size out of range for this handle");
   hipCheck(hipSetDevice(device_), "hipSetDevice");
-  hipCheck(hipStreamSynchronize(stream_), "stream synchronize");
+  hipCheck(hipStreamSynchronize(stream_), "stream synchronize");  // the single-buffered row staging below
   const size_t rowElts = (size_t)S_ * cin_;
   for(int i = 0; i < n; i++) {
     memcpy(hSpatial_ + i * rowElts, rowSpatial[i], rowElts * sizeof(float));
@@ -562,13 +577,8 @@ void Engine::evalHost(int n, const float* const* rowSpatial, const float* const*
   bool anyOwner = false;
   if(outOwnership)
     for(int i = 0; i < n; i++) anyOwner = anyOwner || outOwnership[i] != nullptr;
-  // evalDevice synchronises the stream first, which is harmless here (the copies above are already queued on it)
-  for(int i = 0; i < n; i++) {
-    hSymmetry_[i] = symmetry ? symmetry[i] : 0;
-    hOptimism_[i] = policyOptimism ? policyOptimism[i] : 0.0f;
-  }
-  hipCheck(hipMemcpyAsync(dSymmetry_.get(), hSymmetry_, n * sizeof(int), hipMemcpyHostToDevice, stream_), "H2D symmetry");
-  hipCheck(hipMemcpyAsync(dOptimism_.get(), hOptimism_, n * sizeof(float), hipMemcpyHostToDevice, stream_), "H2D optimism");
+  hostAnyOwner_ = anyOwner;
+  stageRowParams(n, symmetry, policyOptimism);
   runSchedule(n, dSpatialIn_.as<float>(), dGlobalIn_.as<float>(), dPolicy_.as<float>(), dValue_.as<float>(),
               dScore_.as<float>(), anyOwner ? dOwnership_.as<float>() : nullptr);
   hipCheck(hipMemcpyAsync(hPolicy_, dPolicy_.get(), (size_t)n * (S_ + 1) * sizeof(float), hipMemcpyDeviceToHost, stream_), "D2H policy");
@@ -576,15 +586,25 @@ void Engine::evalHost(int n, const float* const* rowSpatial, const float* const*
   hipCheck(hipMemcpyAsync(hScore_, dScore_.get(), (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost, stream_), "D2H score");
   if(anyOwner)
     hipCheck(hipMemcpyAsync(hOwnership_, dOwnership_.get(), (size_t)n * S_ * sizeof(float), hipMemcpyDeviceToHost, stream_), "D2H ownership");
+}
+
+void Engine::evalHostFinish(int n, float* const* outPolicy, float* outValue, float* outScore, float* const* outOwnership) {
   sync();
   for(int i = 0; i < n; i++) {
     memcpy(outPolicy[i], hPolicy_ + (size_t)i * (S_ + 1), (S_ + 1) * sizeof(float));
-    if(anyOwner && outOwnership[i]) memcpy(outOwnership[i], hOwnership_ + (size_t)i * S_, S_ * sizeof(float));
+    if(hostAnyOwner_ && outOwnership[i]) memcpy(outOwnership[i], hOwnership_ + (size_t)i * S_, S_ * sizeof(float));
   }
   memcpy(outValue, hValue_, (size_t)n * 3 * sizeof(float));
   memcpy(outScore, hScore_, (size_t)n * 6 * sizeof(float));
   rows_ += (uint64_t)n;
   batches_ += 1;
+}
+
+void Engine::evalHost(int n, const float* const* rowSpatial, const float* const* rowGlobal, const int* symmetry,
+                      const float* policyOptimism, float* const* outPolicy, float* outValue, float* outScore,
+                      float* const* outOwnership) {
+  evalHostBegin(n, rowSpatial, rowGlobal, symmetry, policyOptimism, outOwnership);
+  evalHostFinish(n, outPolicy, outValue, outScore, outOwnership);
 }
 
 // ------------------------------------------------------------------------------------------------

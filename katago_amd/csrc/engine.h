@@ -77,13 +77,19 @@ class Engine {
   int maxBatch() const { return maxBatch_; }
   int nnXLen() const { return X_; }
   int nnYLen() const { return Y_; }
+  int numInputChannels() const { return cin_; }
+  int numInputGlobalChannels() const { return gin_; }
   hipStream_t stream() const { return stream_; }
   int device() const { return device_; }
 
-  // Host-buffer entry (kmx_eval). Synchronous.
+  // Host-buffer entry (kmx_eval). Synchronous. = evalHostBegin + evalHostFinish; the two halves exist so that a handle
+  // that splits a batch over two engines can have both halves in flight.
   void evalHost(int n, const float* const* rowSpatial, const float* const* rowGlobal, const int* symmetry,
                 const float* policyOptimism, float* const* outPolicy, float* outValue, float* outScore,
                 float* const* outOwnership);
+  void evalHostBegin(int n, const float* const* rowSpatial, const float* const* rowGlobal, const int* symmetry,
+                     const float* policyOptimism, float* const* outOwnership);
+  void evalHostFinish(int n, float* const* outPolicy, float* outValue, float* outScore, float* const* outOwnership);
   // Device-buffer entry (kmx_eval_device).
   void evalDevice(int n, const float* dSpatial, const float* dGlobal, const int* symmetry, const float* policyOptimism,
                   float* dPolicy, float* dValue, float* dScore, float* dOwnership, bool sync);
@@ -93,6 +99,9 @@ class Engine {
   struct ProfileEntry { std::string name; uint64_t launches = 0; double ms = 0, flops = 0, bytes = 0; };
   std::vector<ProfileEntry> getProfile();  // synchronises
 
+  // The convolution work-group shape is chosen for `rows * scale` boards: a handle that runs two engines side by side
+  // on two streams sets 2, so that each half still uses the 8-wave shape (the other half fills the rest of the chip).
+  void setConcurrency(int scale) { cfgScale_ = scale < 1 ? 1 : scale; }
   uint64_t rowsProcessed() const { return rows_; }
   uint64_t batchesProcessed() const { return batches_; }
   int numLaunchesPerEval() const { return (int)ops_.size(); }
@@ -120,6 +129,7 @@ class Engine {
                int actStride, int actBegin, int actEnd, int actKind);
   const FusedConv* newConv(const std::vector<ConvSegment>& segs, std::vector<int>* offs = nullptr);
   float* uploadFloats(const std::vector<float>& v);
+  void stageRowParams(int n, const int* symmetry, const float* policyOptimism);
   void runSchedule(int n, const float* dSpatial, const float* dGlobal, float* dPolicy, float* dValue, float* dScore,
                    float* dOwnership);
 
@@ -142,8 +152,12 @@ class Engine {
   float* hValue_ = nullptr;
   float* hScore_ = nullptr;
   float* hOwnership_ = nullptr;
-  int* hSymmetry_ = nullptr;
+  int* hSymmetry_ = nullptr;    // two slots of maxBatch: a call never waits for the previous call's copies
   float* hOptimism_ = nullptr;
+  hipEvent_t stagingDone_[2] = {nullptr, nullptr};
+  int stagingSlot_ = 0;
+  bool hostAnyOwner_ = false;
+  int cfgScale_ = 1;
   int cin_ = 0, gin_ = 0;
 
   // pointers the ops read at run time (set by runSchedule)

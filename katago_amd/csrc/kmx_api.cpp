@@ -2,6 +2,7 @@
 // exceptions into a status code + thread-local message; nothing here computes.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -24,9 +25,19 @@ struct kmx_context {
   int nnXLen, nnYLen, precisionMode;
   std::vector<int> gpuIdxs;
 };
+// A handle owns one engine, or — for max_batch >= 2*SPLIT_MIN_HALF — two engines on two streams that each evaluate half
+// of a large batch. The two kernel streams drift apart, so one half's memory-bound phases (1x1 convolutions, residual
+// fetches, epilogue stores) overlap the other half's MFMA loops instead of every work-group of the chip hitting HBM at
+// the same moment: measured +4.5 % evals/s at batch 256 (profiles/r01_final/two_stream.log). Weights are duplicated
+// (60 MB for b18c384nbt); activation memory is the same in total.
 struct kmx_handle {
-  std::unique_ptr<Engine> engine;
+  std::unique_ptr<Engine> engine;   // rows [0, h)  (all rows when not split)
+  std::unique_ptr<Engine> engine2;  // rows [h, n)  or null
   int precision;
+  int maxBatch;
+  int splitMin;  // batches of at least this many rows are split
+  uint64_t batches = 0;
+  bool splits(int n) const { return engine2 && n >= splitMin; }
 };
 
 namespace {
@@ -167,7 +178,13 @@ int kmx_handle_create(kmx_context* ctx, const kmx_model* model, int max_batch_si
     std::unique_ptr<kmx_handle> h(new kmx_handle());
     const int dtype = dtypeForPrecision(ctx->precisionMode);
     h->precision = dtype == DT_F16 ? KMX_PREC_FP16 : KMX_PREC_BF16;
+    h->maxBatch = max_batch_size;
+    int splitMin = 224;  // two halves of >= 112 boards: the 8-wave work-groups of both halves together fill >= 87 % of the CUs
+    if(const char* e = getenv("KMX_SPLIT_MIN")) splitMin = atoi(e);  // 0 disables splitting
+    h->splitMin = splitMin;
     h->engine.reset(new Engine(*model->desc, ctx->nnXLen, ctx->nnYLen, max_batch_size, dtype, dev));
+    if(splitMin > 1 && max_batch_size >= splitMin)
+      h->engine2.reset(new Engine(*model->desc, ctx->nnXLen, ctx->nnYLen, max_batch_size / 2, dtype, dev));
     *out = h.release();
   });
 }
@@ -185,8 +202,23 @@ int kmx_eval(kmx_handle* handle, int n_rows, const float* const* row_spatial, co
     if(symmetry)
       for(int i = 0; i < n_rows; i++)
         if(symmetry[i] < 0 || symmetry[i] > 7) throw Error(KMX_ERR_INVALID_ARG, "kmx_eval: symmetry must be in 0..7");
-    handle->engine->evalHost(n_rows, row_spatial, row_global, symmetry, policy_optimism, out_policy, out_value, out_score,
-                             out_ownership);
+    if(n_rows < 1 || n_rows > handle->maxBatch) throw Error(KMX_ERR_INVALID_ARG, "batch size out of range for this handle");
+    handle->batches++;
+    if(!handle->splits(n_rows)) {
+      handle->engine->setConcurrency(1);
+      handle->engine->evalHost(n_rows, row_spatial, row_global, symmetry, policy_optimism, out_policy, out_value, out_score,
+                               out_ownership);
+      return;
+    }
+    const int h = n_rows - n_rows / 2, r = n_rows / 2;  // engine2 holds max_batch/2 rows
+    handle->engine->setConcurrency(2);
+    handle->engine2->setConcurrency(2);
+    handle->engine->evalHostBegin(h, row_spatial, row_global, symmetry, policy_optimism, out_ownership);
+    handle->engine2->evalHostBegin(r, row_spatial + h, row_global + h, symmetry ? symmetry + h : nullptr,
+                                   policy_optimism ? policy_optimism + h : nullptr, out_ownership ? out_ownership + h : nullptr);
+    handle->engine->evalHostFinish(h, out_policy, out_value, out_score, out_ownership);
+    handle->engine2->evalHostFinish(r, out_policy + h, out_value + (size_t)h * 3, out_score + (size_t)h * 6,
+                                    out_ownership ? out_ownership + h : nullptr);
   });
 }
 
@@ -198,8 +230,27 @@ int kmx_eval_device(kmx_handle* handle, int n_rows, const float* d_spatial, cons
     if(symmetry)
       for(int i = 0; i < n_rows; i++)
         if(symmetry[i] < 0 || symmetry[i] > 7) throw Error(KMX_ERR_INVALID_ARG, "kmx_eval_device: symmetry must be in 0..7");
-    handle->engine->evalDevice(n_rows, d_spatial, d_global, symmetry, policy_optimism, d_policy, d_value, d_score, d_ownership,
-                               sync != 0);
+    if(n_rows < 1 || n_rows > handle->maxBatch) throw Error(KMX_ERR_INVALID_ARG, "batch size out of range for this handle");
+    handle->batches++;
+    if(!handle->splits(n_rows)) {
+      handle->engine->setConcurrency(1);
+      handle->engine->evalDevice(n_rows, d_spatial, d_global, symmetry, policy_optimism, d_policy, d_value, d_score, d_ownership,
+                                 sync != 0);
+      return;
+    }
+    const int h = n_rows - n_rows / 2, r = n_rows / 2;
+    const size_t S = (size_t)handle->engine->nnXLen() * handle->engine->nnYLen();
+    const size_t spRow = S * handle->engine->numInputChannels(), glRow = handle->engine->numInputGlobalChannels();
+    handle->engine->setConcurrency(2);
+    handle->engine2->setConcurrency(2);
+    handle->engine->evalDevice(h, d_spatial, d_global, symmetry, policy_optimism, d_policy, d_value, d_score, d_ownership, false);
+    handle->engine2->evalDevice(r, d_spatial + h * spRow, d_global + h * glRow, symmetry ? symmetry + h : nullptr,
+                                policy_optimism ? policy_optimism + h : nullptr, d_policy + h * (S + 1), d_value + (size_t)h * 3,
+                                d_score + (size_t)h * 6, d_ownership ? d_ownership + h * S : nullptr, false);
+    if(sync != 0) {
+      handle->engine->sync();
+      handle->engine2->sync();
+    }
   });
 }
 void* kmx_handle_stream(kmx_handle* handle) { return handle ? (void*)handle->engine->stream() : nullptr; }
@@ -207,25 +258,46 @@ int kmx_handle_sync(kmx_handle* handle) {
   return guarded([&] {
     if(!handle) throw Error(KMX_ERR_INVALID_ARG, "kmx_handle_sync: null handle");
     handle->engine->sync();
+    if(handle->engine2) handle->engine2->sync();
   });
 }
 int kmx_handle_stats(const kmx_handle* handle, uint64_t* rows, uint64_t* batches) {
   if(!handle) return setError(KMX_ERR_INVALID_ARG, "kmx_handle_stats: null handle");
-  if(rows) *rows = handle->engine->rowsProcessed();
-  if(batches) *batches = handle->engine->batchesProcessed();
+  if(rows) *rows = handle->engine->rowsProcessed() + (handle->engine2 ? handle->engine2->rowsProcessed() : 0);
+  if(batches) *batches = handle->batches;
   return KMX_OK;
+}
+
+int kmx_handle_set_split_min(kmx_handle* handle, int min_rows) {
+  return guarded([&] {
+    if(!handle || min_rows < 0) throw Error(KMX_ERR_INVALID_ARG, "kmx_handle_set_split_min: bad argument");
+    handle->engine->sync();
+    if(handle->engine2) handle->engine2->sync();
+    handle->splitMin = min_rows == 0 ? 0x7fffffff : (min_rows < 2 ? 2 : min_rows);
+  });
 }
 
 int kmx_handle_set_profiling(kmx_handle* handle, int enabled) {
   return guarded([&] {
     if(!handle) throw Error(KMX_ERR_INVALID_ARG, "kmx_handle_set_profiling: null handle");
     handle->engine->setProfiling(enabled != 0);
+    if(handle->engine2) handle->engine2->setProfiling(enabled != 0);
   });
 }
 int kmx_handle_get_profile(kmx_handle* handle, kmx_profile_entry* entries, int max_entries, int* n_entries) {
   return guarded([&] {
     if(!handle || !n_entries || (max_entries > 0 && !entries)) throw Error(KMX_ERR_INVALID_ARG, "kmx_handle_get_profile: null argument");
     std::vector<Engine::ProfileEntry> prof = handle->engine->getProfile();
+    if(handle->engine2)
+      for(const Engine::ProfileEntry& e2 : handle->engine2->getProfile()) {  // same classes: add the second stream's launches
+        bool found = false;
+        for(Engine::ProfileEntry& e : prof)
+          if(e.name == e2.name) {
+            e.launches += e2.launches; e.ms += e2.ms; e.flops += e2.flops; e.bytes += e2.bytes;
+            found = true;
+          }
+        if(!found) prof.push_back(e2);
+      }
     *n_entries = (int)prof.size();
     for(int i = 0; i < (int)prof.size() && i < max_entries; i++) {
       memset(&entries[i], 0, sizeof(entries[i]));

@@ -228,34 +228,59 @@ __global__ __launch_bounds__(GV_THREADS) void gpoolApplyVecKernel(const GPoolArg
   }
   __syncthreads();
   const int RV = R / 8;
-  const int total = S * RV;
   constexpr int UN = 4;  // loads of UN iterations in flight before the first is consumed
-  for(int i0 = tid; i0 < total; i0 += GV_THREADS * UN) {
-    V8 x[UN];
+  if(GV_THREADS % RV == 0) {
+    // every thread keeps ONE group of 8 channels for all its cells: bias, BN scale and BN bias live in registers
+    const int rv = tid % RV, pStep = GV_THREADS / RV;
+    float bv[8], sc[8], bi[8];
 #pragma unroll
-    for(int u = 0; u < UN; u++) {
-      const int i = i0 + u * GV_THREADS;
-      if(i < total) {
-        const int p = i / RV, rv = i - p * RV;
-        x[u] = *(const V8*)((const T*)a.r + (cell0 + p) * a.rStride + a.rOffset + rv * 8);
-      }
+    for(int k = 0; k < 8; k++) {
+      bv[k] = biasv[rv * 8 + k];
+      sc[k] = a.scale[rv * 8 + k];
+      bi[k] = a.bias[rv * 8 + k];
     }
+    T* const col = (T*)a.r + cell0 * a.rStride + a.rOffset + rv * 8;
+    for(int p0 = tid / RV; p0 < S; p0 += pStep * UN) {
+      V8 x[UN];
+      float on[UN];
 #pragma unroll
-    for(int u = 0; u < UN; u++) {
-      const int i = i0 + u * GV_THREADS;
-      if(i < total) {
-        const int p = i / RV, rv = i - p * RV;
-        const bool on = maskB[p] == 1.0f;
-        V8 y;
-#pragma unroll
-        for(int k = 0; k < 8; k++) {
-          const int r = rv * 8 + k;
-          const float v = TR::toFloat(x[u][k]) + biasv[r];
-          y[k] = TR::fromFloat(on ? actApply(v * a.scale[r] + a.bias[r], a.actKind) : 0.0f);
+      for(int u = 0; u < UN; u++) {
+        const int p = p0 + u * pStep;
+        if(p < S) {
+          x[u] = *(const V8*)(col + (size_t)p * a.rStride);
+          on[u] = maskB[p];
         }
-        *(V8*)((T*)a.r + (cell0 + p) * a.rStride + a.rOffset + rv * 8) = y;
+      }
+#pragma unroll
+      for(int u = 0; u < UN; u++) {
+        const int p = p0 + u * pStep;
+        if(p < S) {
+          V8 y;
+#pragma unroll
+          for(int k = 0; k < 8; k++) {
+            const float v = TR::toFloat(x[u][k]) + bv[k];
+            y[k] = TR::fromFloat(on[u] == 1.0f ? actApply(v * sc[k] + bi[k], a.actKind) : 0.0f);
+          }
+          *(V8*)(col + (size_t)p * a.rStride) = y;
+        }
       }
     }
+    return;
+  }
+  const int total = S * RV;
+  for(int i = tid; i < total; i += GV_THREADS) {
+    const int p = i / RV, rv = i - p * RV;
+    T* ptr = (T*)a.r + (cell0 + p) * a.rStride + a.rOffset + rv * 8;
+    V8 x = *(const V8*)ptr;
+    const bool on = maskB[p] == 1.0f;
+    V8 y;
+#pragma unroll
+    for(int k = 0; k < 8; k++) {
+      const int r = rv * 8 + k;
+      const float v = TR::toFloat(x[k]) + biasv[r];
+      y[k] = TR::fromFloat(on ? actApply(v * a.scale[r] + a.bias[r], a.actKind) : 0.0f);
+    }
+    *(V8*)ptr = y;
   }
 }
 

@@ -215,6 +215,17 @@ def getOutput(handle, rowSpatial, rowGlobal, symmetries=None, policyOptimisms=No
     return {"policy": policy, "value": value, "score": score, "ownership": ownership}
 
 
+def getOutputDevice(handle, dSpatial, dGlobal, symmetries, policyOptimisms, dPolicy, dValue, dScore, dOwnership=None, sync=True):
+    """kmx_eval_device: the same pass on device-resident buffers (extension; what a device-side batcher would call).
+    d* are device addresses (ints) of float32 arrays laid out like getOutput's host arrays; symmetries / optimisms are
+    host arrays. With sync=False the call returns after enqueueing; handle.sync() completes it."""
+    n = len(symmetries)
+    sym = np.ascontiguousarray(symmetries, dtype=np.int32)
+    opt = np.ascontiguousarray(policyOptimisms if policyOptimisms is not None else np.zeros(n), dtype=np.float32)
+    capi.check(handle._lib.kmx_eval_device(handle._p, n, dSpatial, dGlobal, sym.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _fp(opt),
+                                           dPolicy, dValue, dScore, dOwnership, 1 if sync else 0), handle._lib)
+
+
 # ---- layer test hooks (nninterface.h:134-180) ------------------------------------------------------
 
 def _conv_desc(w_oihw):

@@ -137,6 +137,22 @@ def test_full_batch_properties(ctx19, model_dir):
     small = nn.getOutput(h, sp[:8], gl[:8], sym[:8])
     for k in big:
         assert np.array_equal(big[k][:8], small[k])
+    # 256 and 255 rows take the two-engine path of the handle (two streams, halves of 128 / 128+127), 8 rows the
+    # single-engine path with a different work-group shape: all bit-identical row by row
+    odd = nn.getOutput(h, sp[:255], gl[:255], sym[:255])
+    for k in big:
+        assert np.array_equal(big[k][:255], odd[k])
+    # device-resident entry (kmx_eval_device), asynchronous then synchronised
+    import torch
+    d_sp, d_gl = torch.from_numpy(sp).cuda(), torch.from_numpy(gl).cuda()
+    d_pol, d_val = torch.zeros((256, 362), device="cuda"), torch.zeros((256, 3), device="cuda")
+    d_sc, d_own = torch.zeros((256, 6), device="cuda"), torch.zeros((256, 361), device="cuda")
+    torch.cuda.synchronize()
+    nn.getOutputDevice(h, d_sp.data_ptr(), d_gl.data_ptr(), sym, None, d_pol.data_ptr(), d_val.data_ptr(), d_sc.data_ptr(),
+                       d_own.data_ptr(), sync=False)
+    h.sync()
+    assert np.array_equal(d_pol.cpu().numpy(), big["policy"]) and np.array_equal(d_val.cpu().numpy(), big["value"])
+    assert np.array_equal(d_sc.cpu().numpy(), big["score"]) and np.array_equal(d_own.cpu().numpy(), big["ownership"])
     # row r (symmetry s) vs the explicitly symmetrised board at symmetry 0
     for s in (1, 2, 4, 7):
         r = 8 * s

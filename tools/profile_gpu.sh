@@ -6,6 +6,8 @@
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
+# kernels are profiled with the chip to themselves (one stream), which is what bench.py's roofline pass measures
+export KMX_SPLIT_MIN=0
 OUT=gpurun_out/${1:-prof}
 rm -rf $OUT; mkdir -p $OUT
 BENCH="python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile"
@@ -21,5 +23,6 @@ for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
   tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $pass -d $OUT/pmc_$tag -o conv -- python tools/conv_one.py 3 23 0 192 192 1 3 > $OUT/pmc_$tag.log 2>&1
 done
+KMX_SPLIT_MIN=224 rocprofv3 --kernel-trace --stats -d $OUT/bench_trace_two_streams -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile > $OUT/bench_trace_two_streams.log 2>&1
 python tools/rocpd_summary.py $OUT $OUT/summary > $OUT/summary.log 2>&1
 python tools/make_traffic.py $OUT/summary > $OUT/make_traffic.log 2>&1

@@ -16,7 +16,7 @@ from katago_amd import capi, modelgen, nninterface as nn  # noqa: E402
 from bench import synthetic_rows  # noqa: E402
 
 
-def run(handles, B, steps=20, warmup=3):
+def run(handles, B, steps=60, warmup=5):
     lib = capi.load_library()
     S = 361
     bufs = []
@@ -54,7 +54,7 @@ def main():
     modelgen.write_model(path, "b18c384nbt", seed=1)
     model = nn.loadModelFile(path)
     ctx = nn.createComputeContext([0], 19, 19, precision="bf16")
-    for nh, B in ((1, 256), (2, 128), (4, 64), (2, 256), (1, 128), (1, 512)):
+    for nh, B in ((1, 256), (2, 128), (4, 64), (8, 32), (4, 128), (2, 128), (4, 64)):
         hs = [nn.createComputeHandle(ctx, model, B, True, 0) for _ in range(nh)]
         v = run(hs, B)
         print("%d handle(s) x batch %3d : %9.1f evals/s" % (nh, B, v), flush=True)
