@@ -65,3 +65,63 @@ def test_real_net_tiny_board_golden_on_hip():
         assert (u is None) == (v is None) and (u is None or abs(u - v) <= 15), (u, v)  # same legality pattern
     for u, v in zip(owna, ownb):
         assert abs(u - v) <= 25, (u, v)
+
+
+BENCH_CFG = """logDir = gtp_logs
+logAllGTPCommunication = false
+logSearchInfo = false
+logToStderr = false
+rules = tromp-taylor
+allowResignation = false
+maxVisits = 200
+numSearchThreads = 8
+nnCacheSizePowerOfTwo = 18
+nnMutexPoolSizePowerOfTwo = 14
+nnRandomize = true
+ponderingEnabled = false
+lagBuffer = 1.0
+searchFactorAfterOnePass = 0.5
+searchFactorAfterTwoPass = 0.25
+searchFactorWhenWinning = 0.4
+searchFactorWhenWinningThreshold = 0.95
+"""
+
+
+def test_reference_benchmark_command_on_hip(tmp_path):
+    """The reference's own definition of the headline metric: `katago benchmark` (command/benchmark.cpp; nnEvals/s =
+    NNEvaluator::numRowsProcessed / search seconds, playutils.cpp:843,991-1000) — BASELINE configs[0] (g170-b6c96, 9x9,
+    200 visits) with the HIP backend in place of Eigen. Search, featurisation, batching and cache are the reference's."""
+    if not os.path.exists(G170):
+        pytest.skip("g170 net not packaged")
+    cfg = tmp_path / "bench.cfg"
+    cfg.write_text(BENCH_CFG)
+    rc, out = run("benchmark", "-model", G170, "-config", str(cfg), "-v", "200", "-t", "8,32", "-boardsize", "9", "-n", "4")
+    assert rc == 0, out[-3000:]
+    assert "katamx (HIP/gfx950) backend" in out
+    rates = [float(x) for x in re.findall(r"nnEvals/s = ([\d.]+)", out)]
+    assert len(rates) >= 2 and all(r > 0 for r in rates), out[-2000:]
+    keep = os.path.join(REPO, "gpurun_out")
+    if os.path.isdir(keep):
+        with open(os.path.join(keep, "reference_benchmark_b6c96_9x9.txt"), "w") as f:
+            f.write("\n".join(l for l in out.replace("\r", "\n").splitlines() if "nnEvals/s" in l) + "\n")
+
+
+def test_reference_benchmark_b18_19x19_on_hip(tmp_path):
+    """BASELINE configs[1] through the reference's own `benchmark`: b18c384nbt (random weights), 19x19, as many search
+    threads as the reference needs to fill batches (its batch size = #threads, benchmark.cpp:206-217). The number is
+    host-bound (one blocked OS thread per in-flight leaf) and recorded, not asserted."""
+    from katago_amd import modelgen
+
+    model = str(tmp_path / "b18.bin.gz")
+    modelgen.write_model(model, "b18c384nbt", seed=7)
+    cfg = tmp_path / "bench.cfg"
+    cfg.write_text(BENCH_CFG)
+    rc, out = run("benchmark", "-model", model, "-config", str(cfg), "-v", "1600", "-t", "64,256", "-boardsize", "19", "-n", "3",
+                  timeout=900)
+    assert rc == 0, out[-3000:]
+    rates = [float(x) for x in re.findall(r"nnEvals/s = ([\d.]+)", out)]
+    assert len(rates) >= 2 and all(r > 0 for r in rates), out[-2000:]
+    keep = os.path.join(REPO, "gpurun_out")
+    if os.path.isdir(keep):
+        with open(os.path.join(keep, "reference_benchmark_b18_19x19.txt"), "w") as f:
+            f.write("\n".join(l for l in out.replace("\r", "\n").splitlines() if "nnEvals/s" in l) + "\n")
