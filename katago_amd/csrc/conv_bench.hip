@@ -16,6 +16,8 @@ hipError_t launchVariant(int ks, int cfg, int variant, const ConvArgs& a, hipStr
   typedef TraitsBF16 TR;
 #define V(KS_, WNW_, WN_, D_, ABL_) \
   if(ks == KS_ && cfg == 10 * WNW_ + WN_ && variant == D_ * 1000 + ABL_) return launchOne<TR, KS_, WN_, WNW_, D_, ABL_>(a, st);
+  V(3, 1, 1, 3, 0) V(3, 1, 1, 4, 0) V(3, 1, 1, 5, 0) V(3, 1, 2, 3, 0) V(3, 1, 2, 4, 0) V(3, 1, 3, 3, 0) V(3, 1, 3, 4, 0)
+  V(1, 1, 1, 3, 0) V(1, 1, 1, 4, 0) V(1, 1, 2, 3, 0) V(1, 1, 2, 4, 0) V(3, 2, 3, 4, 0) V(3, 2, 3, 5, 0)
   V(3, 1, 3, 2, 0) V(3, 2, 3, 2, 0) V(3, 2, 3, 3, 0) V(3, 2, 3, 4, 0)
   V(3, 1, 3, 2, 1) V(3, 1, 3, 2, 2) V(3, 1, 3, 2, 4) V(3, 1, 3, 2, 5) V(3, 1, 3, 2, 8) V(3, 1, 3, 2, 512) V(3, 1, 3, 2, 1024)
   V(3, 2, 3, 3, 16) V(3, 2, 3, 3, 17) V(3, 2, 3, 3, 33) V(3, 2, 3, 3, 65) V(3, 2, 3, 3, 25) V(3, 2, 3, 3, 41) V(3, 2, 3, 3, 73)

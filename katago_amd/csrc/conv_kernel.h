@@ -63,7 +63,16 @@ struct Geom {
   static constexpr int NPW = (WPIECES + NTHREADS - 1) / NTHREADS;
   static constexpr int W_BYTES = (WPIECES * 16 + 1023) / 1024 * 1024;
   static_assert(D >= 2, "the slab of step s+1 is published at the top of step s: at least two steps of requests in flight");
-  static constexpr bool SPREAD = NT >= NPA + D;  // image pieces fit one per step within a chunk
+  // 3x3/5x5: the next chunk's image arrives PPS pieces per step during the first LS steps of the current chunk
+  // (the fewest pieces per step for which it is complete D steps before the chunk ends); 1x1: whole images per step.
+  static constexpr bool SPREAD = NT > 1;
+  static constexpr int pickPPS() {
+    for(int p = 1; p <= NPA; p++)
+      if((NPA + p - 1) / p + D <= NT) return p;
+    return NPA;
+  }
+  static constexpr int PPS = SPREAD ? pickPPS() : NPA;
+  static constexpr int LS = (NPA + PPS - 1) / PPS;
   static constexpr int NSA = SPREAD ? 2 : D + 1;
   static constexpr int NSW = D + 1;
   static constexpr int SLACK_BYTES = NWAVES * 1024;
@@ -75,9 +84,9 @@ struct Geom {
   static constexpr int LDS_BYTES = MASK_OFFSET + MASK_BYTES;
   // DMA instructions younger than the data of the current step when it is waited for
   // top of step s: everything up to slab s+1 has landed (requested in step s+1-D, followed there by its image piece)
-  static constexpr int VMCNT = SPREAD ? 1 + (D - 2) * (NPW + 1) : (D - 2) * (NPW + NPA);
+  static constexpr int VMCNT = SPREAD ? PPS + (D - 2) * (NPW + PPS) : (D - 2) * (NPW + NPA);
   // before the loop: slab 0 and image 0
-  static constexpr int VMCNT_PRO = SPREAD ? 1 + (D - 1) * (NPW + 1) : (D - 1) * (NPW + NPA);
+  static constexpr int VMCNT_PRO = SPREAD ? PPS + (D - 1) * (NPW + PPS) : (D - 1) * (NPW + NPA);
 };
 
 template <int N>
@@ -282,7 +291,8 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
     for(int s = 0; s < D; s++) {
       issueW(s);
-      issueA(0, -1);  // dummy: keeps the per-step DMA count constant
+#pragma unroll
+      for(int i = 0; i < G::PPS; i++) issueA(0, -1);  // dummies: keep the per-step DMA count constant
     }
   }
   else {
@@ -339,7 +349,8 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   auto issueStep = [&](int chunk, int t, int step) {
     issueW(step + D);
     if(SPREAD) {
-      issueA(chunk + 1, t < NPA ? t : -1);
+#pragma unroll
+      for(int i = 0; i < G::PPS; i++) issueA(chunk + 1, t * G::PPS + i < NPA ? t * G::PPS + i : -1);
     }
     else {
 #pragma unroll
@@ -491,7 +502,7 @@ hipError_t launchOne(const ConvArgs& a, hipStream_t stream) {
   typedef Geom<KS, WN, WNW, D> G;
   constexpr int ldsBytes = G::LDS_BYTES;
   static_assert(ldsBytes <= 160 * 1024, "LDS budget exceeded");
-  static_assert(!G::SPREAD || G::NPA + D <= G::NT, "image pieces must land within their chunk");
+  static_assert(!G::SPREAD || G::LS + D <= G::NT, "image pieces must land within their chunk");
   static_assert(G::STAGE_BYTES <= G::MASK_OFFSET, "epilogue staging overlaps the mask tile");
   auto kern = convMfmaKernel<TR, KS, WN, WNW, D, ABL>;
   static bool attrSet = false;  // per instantiation; idempotent

@@ -125,3 +125,32 @@ def test_reference_benchmark_b18_19x19_on_hip(tmp_path):
     if os.path.isdir(keep):
         with open(os.path.join(keep, "reference_benchmark_b18_19x19.txt"), "w") as f:
             f.write("\n".join(l for l in out.replace("\r", "\n").splitlines() if "nnEvals/s" in l) + "\n")
+
+
+def test_oracle_agrees_with_reference_opencl_backend(tmp_path):
+    """Pins the ORACLE against the reference's own GPU implementation of the path, on the MI355X: katago_opencl is the
+    reference's OpenCL backend built from its sources (oracle/Makefile). katago_oracle, in the role of the Eigen build,
+    writes `testgpuerror`'s reference file (CPU); katago_opencl then checks its fp32/fp16, batched/unbatched outputs against
+    it with the reference's own cross-backend thresholds (tests/testnnevalcanary.cpp:573-829) — real trained net
+    (g170-b6c96), the reference's own 9x9 position set. Exit code 0 = every statistic within its limit."""
+    if not os.path.exists(G170):
+        pytest.skip("g170 net not packaged")
+    try:
+        ocl = ref_binary("katago_opencl")
+        orc = ref_binary("katago_oracle")
+    except Exception:
+        pytest.skip("reference OpenCL build not present")
+    cfg = tmp_path / "bench.cfg"
+    cfg.write_text(BENCH_CFG + "homeDataDir = %s\n" % (tmp_path / "home"))
+    ref = str(tmp_path / "ref.txt")
+    args = ["testgpuerror", "-model", G170, "-config", str(cfg), "-boardsize", "9", "-quick", "-reference-file", ref]
+    r = subprocess.run([orc] + args, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0 and os.path.getsize(ref) > 100000, (r.stdout + r.stderr)[-2000:]
+    r = subprocess.run([ocl] + args, capture_output=True, text=True, timeout=1200, cwd=str(tmp_path))
+    out = r.stdout + r.stderr
+    if "No OpenCL" in out or "clGetPlatformIDs" in out:
+        pytest.skip("no OpenCL platform on this box")
+    assert r.returncode == 0, out[-3000:]
+    assert "Loaded reference values for" in out
+    m = re.search(r"fp32 error vs reference closest margin:\s+([\d.eE+-]+)x of limit", out)
+    assert m and float(m.group(1)) < 0.05, out[-2000:]  # measured 0.0009x: fp32 rounding only
