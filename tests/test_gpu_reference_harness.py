@@ -154,3 +154,30 @@ def test_oracle_agrees_with_reference_opencl_backend(tmp_path):
     assert "Loaded reference values for" in out
     m = re.search(r"fp32 error vs reference closest margin:\s+([\d.eE+-]+)x of limit", out)
     assert m and float(m.group(1)) < 0.05, out[-2000:]  # measured 0.0009x: fp32 rounding only
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_reference_gpuerror_acceptance_on_hip(tmp_path, prec):
+    """The reference's cross-backend acceptance test `testgpuerror` (command/gputest.cpp; thresholds
+    tests/testnnevalcanary.cpp:787-788 fp32, :806-807 reduced precision) on the katamx backend: real net (g170-b6c96), the
+    reference's own 9x9 positions, reference values written by the oracle in the role of the Eigen build. The test also
+    builds an "fp32" evaluator; katamx has none, so katamxPrecision pins both evaluators to the mode under test.
+      fp16: passes outright — even the strict fp32-vs-fp32 limits (exit code 0);
+      bf16: within the reduced-precision limits ("current cfg error vs reference"); only the strict fp32 rows exceed."""
+    if not os.path.exists(G170):
+        pytest.skip("g170 net not packaged")
+    cfg = tmp_path / "bench.cfg"
+    cfg.write_text(BENCH_CFG)
+    ref = str(tmp_path / "ref.txt")
+    args = ["testgpuerror", "-model", G170, "-config", str(cfg), "-boardsize", "9", "-quick", "-reference-file", ref]
+    r = subprocess.run([ref_binary("katago_oracle")] + args, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0 and os.path.getsize(ref) > 100000, (r.stdout + r.stderr)[-2000:]
+    r = subprocess.run([ref_binary("katago_hip")] + args + ["-override-config", "katamxPrecision=" + prec], capture_output=True,
+                       text=True, timeout=600, cwd=str(tmp_path))
+    out = r.stdout + r.stderr
+    assert "Loaded reference values for" in out, out[-3000:]
+    margins = {k: float(v) for k, v in re.findall(r": ((?:batched )?(?:fp32|current cfg)) error vs reference closest margin:\s+([\d.eE+-]+)x of limit", out)}
+    assert len(margins) == 4, out[-3000:]
+    assert margins["current cfg"] < 1.0 and margins["batched current cfg"] < 1.0, margins
+    if prec == "fp16":
+        assert r.returncode == 0 and margins["fp32"] < 1.0, (margins, out[-1500:])
