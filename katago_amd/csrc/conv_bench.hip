@@ -1,7 +1,9 @@
 // conv_bench.hip — instrumentation only: times single launches of the MFMA convolution, including
 // ablated variants (no epilogue / no MFMA / no DMA ...) and other pipeline depths, so that the dominant cost
 // of the kernel can be located on hardware before it is optimised. Not used by the evaluation path.
+#include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "conv_kernel.h"
@@ -35,7 +37,9 @@ hipError_t launchVariant(int ks, int cfg, int variant, const ConvArgs& a, hipStr
 
 // epilogueMode: 0 = BN+act output only; 1 = residual in, raw out + BN+act out
 double benchConv(int ks, int cfg, int variant, int cin, int cout, int batch, int X, int Y, int epilogueMode, int iters) {
-  const int dtype = DT_BF16;
+  // KMX_BENCH_DTYPE=fp16 times the fp16 instantiation (product dispatch only: variant 0)
+  const char* dtEnv = getenv("KMX_BENCH_DTYPE");
+  const int dtype = (dtEnv && std::string(dtEnv) == "fp16" && variant == 0) ? DT_F16 : DT_BF16;
   const int S = X * Y;
   const size_t cells = (size_t)batch * S;
   const int inStride = roundUp(cin, 32), outStride = roundUp(cout, 32);
@@ -58,7 +62,7 @@ double benchConv(int ks, int cfg, int variant, int cin, int cout, int batch, int
   bn.bias.assign(cout, 0.1f);
   FusedConv fc = buildFusedConv(dtype, {{&c, &bn}}, nullptr);
   std::vector<uint16_t> hin(cells * inStride);
-  for(uint16_t& v : hin) v = floatToBf16Bits(rnd());
+  for(uint16_t& v : hin) v = dtype == DT_F16 ? floatToHalfBits(rnd()) : floatToBf16Bits(rnd());
   DevBuf in(hin.size() * 2, false), resid(cells * outStride * 2), raw(cells * outStride * 2), act(cells * outStride * 2), zero(ZERO_PAGE_BYTES);
   in.upload(hin.data(), hin.size() * 2);
   std::vector<float> ones(cells, 1.0f);

@@ -17,22 +17,31 @@
 //     the same image at a row offset — no im2col, no per-tap global traffic.
 //   - both LDS images are filled by global_load_lds (LDS-DMA, 16 B/lane), i.e. they are LINEAR copies of
 //     what the DMA lanes fetch: the weights are pre-tiled AND pre-swizzled in HBM by the engine, the
-//     board image is gathered by per-lane source offsets computed once per work-group (halo cells come
-//     from a zero page). No VGPR staging, no ds_write.
-//   - bank conflicts are avoided by an XOR swizzle of the four 16-byte slots of a row with bits 2-3 of the
-//     row index (16 consecutive rows x one logical slot cover all 64 banks once) rather than by padding:
-//     20 % fewer DMA bytes and LDS bytes than 80-byte rows, which is what lets TWO 4-wave work-groups share
-//     a CU (one's residual fetch / epilogue / pipeline fill hides under the other's MFMA loop).
-//   - software pipeline of depth D: the weight slab of step s+D is requested at the top of step s (ring of
-//     D+1 slabs). For 3x3/5x5 the next chunk's board image is requested one DMA instruction per step
-//     into the second image buffer; for 1x1 (one step per chunk) whole images ride the same ring.
-//     Every wave issues the SAME number of DMA instructions per step (padding with dummies into a slack
-//     area), so that one compile-time s_waitcnt vmcnt(N) retires exactly the data of the current step
+//     board image is gathered through per-lane source pointers computed once per work-group and then only
+//     advanced 64 bytes per chunk (halo lanes walk a zero page). No VGPR staging, no ds_write, no address
+//     arithmetic on the vector ALU in the main loop (VALU instructions share the issue slot with the MFMAs:
+//     64 of them per 18 MFMAs cost 24 % of the matrix rate, tools/mfma_peak.py).
+//   - bank conflicts: (a) an XOR swizzle of the four 16-byte slots of a row with bits 2-3 of the row index (16
+//     consecutive rows x one logical slot cover all 64 banks once) rather than padding — 20 % fewer DMA and LDS bytes
+//     than 80-byte rows; (b) GEMM column -> board cell is permuted so that each fixed 16-lane group of a
+//     ds_read_b128 reads 16 CONSECUTIVE image rows (no halo wrap inside a group): see cellOf/posOf below.
+//     PMC, 3x3 192->192: SQ_LDS_BANK_CONFLICT 2.67M -> 0.55M cycles per launch.
+//   - software pipeline of depth D: the weight slab of step s+D is requested in step s (ring of D+1 slabs) and
+//     published by the barrier at the top of step s+D-1, one step before it is consumed, so that the first k-half
+//     fragments of step s+1 can be read during step s. For 3x3/5x5 the next chunk's board image is requested PPS
+//     DMA instructions per step into the second image buffer; for 1x1 (one step per chunk) whole images ride
+//     the same ring. Every wave issues the SAME number of DMA instructions per step (padding with dummies into a
+//     slack area), so that one compile-time s_waitcnt vmcnt(N) retires exactly "everything up to slab s+1"
 //     while D-1 steps of requests stay in flight across the single s_barrier per step.
+//   - LDS reads are software-pipelined too: each batch of fragment reads is issued right after the first MFMA of the
+//     other fragment set (the compiler's own s_waitcnt before an MFMA drains ALL outstanding LDS reads).
 //   - accumulators start from the residual stream, so the epilogue has no global loads (vmcnt counts
 //     stores too: an epilogue alternating loads and stores pays a memory round trip per row).
 //   - epilogue: each wave transposes its tiles through LDS (fp32) and walks them row-wise with 16-byte
 //     stores of whole NHWC runs; BN scale/bias, activation, mask, 16-bit rounding happen there.
+//   Measured cost split of a 3x3 192->192 layer at batch 256 (70 us; profiles/r01_v5/ablate_v5.log): launch+prologue 6,
+//   MFMA loop 34 (1.8 PFLOP/s), LDS reads +1, DMA feed +13, epilogue +16, residual fetch +8 when present. Variants that
+//   were built and measured slower are recorded under profiles/ (weights straight from global memory: r01_v6_experiment).
 #ifndef KMX_CONV_KERNEL_H_
 #define KMX_CONV_KERNEL_H_
 
