@@ -65,7 +65,7 @@ typedef struct kmx_model_info {
   int32_t model_version;
   int32_t num_input_channels;        /* 22 for inputs v7 */
   int32_t num_input_global_channels; /* 19 for inputs v7 */
-  int32_t num_input_meta_channels;   /* 0 (sgf-metadata nets are rejected at load) */
+  int32_t num_input_meta_channels;   /* 0, or 192 for nets with an sgf-metadata encoder (metaEncoderVersion 1) */
   int32_t num_policy_channels;       /* 1, 2 or 4 */
   int32_t num_value_channels;        /* 3 */
   int32_t num_score_value_channels;  /* 4 (v8) or 6 (v>=9) */
@@ -73,7 +73,7 @@ typedef struct kmx_model_info {
   int32_t trunk_num_channels;
   int32_t mid_num_channels;
   int32_t num_blocks;
-  int32_t reserved0;
+  int32_t meta_encoder_version;      /* 0 = none (was reserved0) */
   /* ModelPostProcessParams (desc.cpp:2477-2513); defaults for v<13 as in desc.h */
   float td_score_multiplier;
   float score_mean_multiplier;
@@ -148,6 +148,20 @@ int kmx_eval(kmx_handle* handle, int n_rows,
 int kmx_eval_device(kmx_handle* handle, int n_rows, const float* d_spatial, const float* d_global,
                     const int* symmetry, const float* policy_optimism,
                     float* d_policy, float* d_value, float* d_score, float* d_ownership, int sync);
+/* Nets with an sgf-metadata encoder (model header metaEncoderVersion > 0, "humanSL" nets; desc.cpp:1571-1625,
+ * Trunk::apply eigenbackend.cpp:1929-1932) take one more input per row: NNResultBuf::rowMetaBuf, float[192]
+ * (num_input_meta_channels). These two entry points are kmx_eval / kmx_eval_device with that input:
+ *   row_meta[i] -> float[num_input_meta_channels]   /   d_meta: float[n_rows][num_input_meta_channels] on the device.
+ * A net with an encoder requires it (KMX_ERR_INVALID_ARG through kmx_eval / with NULL); a net without one requires NULL,
+ * as the reference asserts (eigenbackend.cpp:1929-1936). */
+int kmx_eval_meta(kmx_handle* handle, int n_rows,
+                  const float* const* row_spatial, const float* const* row_global, const float* const* row_meta,
+                  const int* symmetry, const float* policy_optimism,
+                  float* const* out_policy, float* out_value, float* out_score,
+                  float* const* out_ownership);
+int kmx_eval_device_meta(kmx_handle* handle, int n_rows, const float* d_spatial, const float* d_global, const float* d_meta,
+                         const int* symmetry, const float* policy_optimism,
+                         float* d_policy, float* d_value, float* d_score, float* d_ownership, int sync);
 void* kmx_handle_stream(kmx_handle* handle); /* hipStream_t the handle launches on */
 int kmx_handle_sync(kmx_handle* handle);
 

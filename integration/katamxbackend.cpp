@@ -86,6 +86,7 @@ struct ComputeHandle {
   int modelVersion;
   int numInputChannels;
   int numInputGlobalChannels;
+  int numInputMetaChannels;
 #ifndef KMX_USE_ORACLE
   kmx_handle* handle = NULL;
 #endif
@@ -99,6 +100,7 @@ struct InputBuffers {
   // Per-call pointer tables and output staging, reused across calls.
   vector<const float*> rowSpatial;
   vector<const float*> rowGlobal;
+  vector<const float*> rowMeta;  // only for nets with an sgf-metadata encoder
   vector<int> symmetry;
   vector<float> policyOptimism;
   vector<float*> outPolicy;
@@ -206,6 +208,7 @@ ComputeHandle* NeuralNet::createComputeHandle(
   handle->modelVersion = loadedModel->modelDesc.modelVersion;
   handle->numInputChannels = loadedModel->modelDesc.numInputChannels;
   handle->numInputGlobalChannels = loadedModel->modelDesc.numInputGlobalChannels;
+  handle->numInputMetaChannels = loadedModel->modelDesc.numInputMetaChannels;
 #ifndef KMX_USE_ORACLE
   check(
     kmx_handle_create(
@@ -260,6 +263,7 @@ InputBuffers* NeuralNet::createInputBuffers(const LoadedModel* loadedModel, int 
   buffers->singleOwnershipElts = (size_t)nnXLen * nnYLen;
   buffers->rowSpatial.resize(maxBatchSize);
   buffers->rowGlobal.resize(maxBatchSize);
+  buffers->rowMeta.resize(maxBatchSize);
   buffers->symmetry.resize(maxBatchSize);
   buffers->policyOptimism.resize(maxBatchSize);
   buffers->outPolicy.resize(maxBatchSize);
@@ -292,7 +296,9 @@ void NeuralNet::getOutput(
 
   for(int row = 0; row < batchSize; row++) {
     const NNResultBuf* in = inputBufs[row];
-    testAssert(!in->hasRowMeta);  // sgf-metadata nets are rejected at load
+    // same pairing as eigenbackend.cpp:2474-2484: metadata rows exactly for nets with an sgf-metadata encoder
+    testAssert(in->hasRowMeta == (handle->numInputMetaChannels > 0));
+    buffers->rowMeta[row] = in->hasRowMeta ? in->rowMetaBuf.data() : NULL;
     NNOutput* out = outputs[row];
     testAssert(out->nnXLen == nnXLen && out->nnYLen == nnYLen);
     if(handle->inputsUseNHWC)
@@ -315,15 +321,16 @@ void NeuralNet::getOutput(
 
 #ifdef KMX_USE_ORACLE
   check(
-    okmx_eval(
+    okmx_eval_meta(
       handle->loadedModel->model, nnXLen, nnYLen, batchSize, buffers->rowSpatial.data(), buffers->rowGlobal.data(),
-      buffers->symmetry.data(), buffers->policyOptimism.data(), buffers->outPolicy.data(), buffers->value.data(),
+      handle->numInputMetaChannels > 0 ? buffers->rowMeta.data() : NULL, buffers->symmetry.data(), buffers->policyOptimism.data(), buffers->outPolicy.data(), buffers->value.data(),
       buffers->score.data(), buffers->outOwnership.data(), 1),
     "evaluating batch");
 #else
   check(
-    kmx_eval(
-      handle->handle, batchSize, buffers->rowSpatial.data(), buffers->rowGlobal.data(), buffers->symmetry.data(),
+    kmx_eval_meta(
+      handle->handle, batchSize, buffers->rowSpatial.data(), buffers->rowGlobal.data(),
+      handle->numInputMetaChannels > 0 ? buffers->rowMeta.data() : NULL, buffers->symmetry.data(),
       buffers->policyOptimism.data(), buffers->outPolicy.data(), buffers->value.data(), buffers->score.data(),
       buffers->outOwnership.data()),
     "evaluating batch");

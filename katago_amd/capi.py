@@ -36,7 +36,7 @@ class ModelInfo(ctypes.Structure):
         ("trunk_num_channels", ctypes.c_int32),
         ("mid_num_channels", ctypes.c_int32),
         ("num_blocks", ctypes.c_int32),
-        ("reserved0", ctypes.c_int32),
+        ("meta_encoder_version", ctypes.c_int32),
         ("td_score_multiplier", ctypes.c_float),
         ("score_mean_multiplier", ctypes.c_float),
         ("score_stdev_multiplier", ctypes.c_float),
@@ -99,6 +99,9 @@ SIGNATURES = {
     "kmx_handle_free": (None, [ctypes.c_void_p]),
     "kmx_handle_precision": (ctypes.c_int, [ctypes.c_void_p]),
     "kmx_eval": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _FPP, _FPP, _IP, _FP, _FPP, _FP, _FP, _FPP]),
+    "kmx_eval_meta": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _FPP, _FPP, _FPP, _IP, _FP, _FPP, _FP, _FP, _FPP]),
+    "kmx_eval_device_meta": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _IP, _FP,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "kmx_eval_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, _IP, _FP,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "kmx_handle_stream": (ctypes.c_void_p, [ctypes.c_void_p]),

@@ -133,6 +133,7 @@ Engine::Engine(const ModelDesc& model, int nnXLen, int nnYLen, int maxBatch, int
   hipCheck(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
   cin_ = model.numInputChannels;
   gin_ = model.numInputGlobalChannels;
+  min_ = model.metaEncoderVersion > 0 ? model.numInputMetaChannels : 0;
   const size_t NS = (size_t)maxBatch_ * S_;
   zeroPage_ = DevBuf(ZERO_PAGE_BYTES);
   inputT_ = DevBuf(NS * KCHUNK * 2);
@@ -143,6 +144,10 @@ Engine::Engine(const ModelDesc& model, int nnXLen, int nnYLen, int maxBatch, int
   dOptimism_ = DevBuf((size_t)maxBatch_ * sizeof(float));
   dSpatialIn_ = DevBuf(NS * cin_ * sizeof(float));
   dGlobalIn_ = DevBuf((size_t)maxBatch_ * gin_ * sizeof(float));
+  if(min_ > 0) {
+    dMetaIn_ = DevBuf((size_t)maxBatch_ * min_ * sizeof(float));
+    hipCheck(hipHostMalloc((void**)&hMeta_, (size_t)maxBatch_ * min_ * sizeof(float)), "hipHostMalloc");
+  }
   dPolicy_ = DevBuf((size_t)maxBatch_ * (S_ + 1) * sizeof(float));
   dValue_ = DevBuf((size_t)maxBatch_ * 3 * sizeof(float));
   dScore_ = DevBuf((size_t)maxBatch_ * 6 * sizeof(float));
@@ -174,6 +179,7 @@ Engine::~Engine() {
     if(stagingDone_[i]) (void)hipEventDestroy(stagingDone_[i]);
   (void)hipHostFree(hSpatial_);
   (void)hipHostFree(hGlobal_);
+  if(hMeta_) (void)hipHostFree(hMeta_);
   (void)hipHostFree(hPolicy_);
   (void)hipHostFree(hValue_);
   (void)hipHostFree(hScore_);
@@ -336,12 +342,25 @@ void Engine::buildSchedule(const ModelDesc& m) {
     ia.C = m.trunkC;
     ia.ncStride = roundUp(m.trunkC, 64);
     ia.symmetry = dSymmetry_.as<int>();
+    if(min_ > 0) {
+      ia.metaIn = min_;
+      ia.metaC1 = m.metaMul1.outC;
+      ia.metaC2 = m.metaMul2.outC;
+      ia.metaAct1 = m.metaAct1;
+      ia.metaAct2 = m.metaAct2;
+      ia.mW1 = uploadFloats(m.metaMul1.w);
+      ia.mB1 = uploadFloats(m.metaBias1.w);
+      ia.mW2 = uploadFloats(m.metaMul2.w);
+      ia.mB2 = uploadFloats(m.metaBias2.w);
+      ia.mW3 = uploadFloats(m.metaMul3.w);
+    }
     const int dtype = dtype_;
     addOp("input_stage", 2.0 * gin_ * m.trunkC, S_ * (4.0 * cin_ + 2.0 * KCHUNK + 4.0), [=](int n, hipStream_t st) {
       InputArgs x = ia;
       x.N = n;
       x.spatial = curSpatial_;
       x.global = curGlobal_;
+      x.meta = curMeta_;
       hipCheck(launchInputExpand(dtype, x, st), "input staging launch");
     });
   }
@@ -455,10 +474,14 @@ void Engine::buildSchedule(const ModelDesc& m) {
   }
 }
 
-void Engine::runSchedule(int n, const float* dSpatial, const float* dGlobal, float* dPolicy, float* dValue, float* dScore,
-                         float* dOwnership) {
+void Engine::runSchedule(int n, const float* dSpatial, const float* dGlobal, const float* dMeta, float* dPolicy, float* dValue,
+                         float* dScore, float* dOwnership) {
+  // the reference asserts the same pairing (eigenbackend.cpp:1929-1936)
+  if(min_ > 0 && dMeta == nullptr) throw Error(KMX_ERR_INVALID_ARG, "this net has an sgf-metadata encoder: rows need the metadata input (kmx_eval_meta)");
+  if(min_ == 0 && dMeta != nullptr) throw Error(KMX_ERR_INVALID_ARG, "this net has no sgf-metadata encoder: the metadata input must be NULL");
   curSpatial_ = dSpatial;
   curGlobal_ = dGlobal;
+  curMeta_ = dMeta;
   curPolicy_ = dPolicy;
   curValue_ = dValue;
   curScore_ = dScore;
@@ -551,19 +574,19 @@ void Engine::stageRowParams(int n, const int* symmetry, const float* policyOptim
   hipCheck(hipEventRecord(stagingDone_[slot], stream_), "hipEventRecord");
 }
 
-void Engine::evalDevice(int n, const float* dSpatial, const float* dGlobal, const int* symmetry, const float* policyOptimism,
-                        float* dPolicy, float* dValue, float* dScore, float* dOwnership, bool doSync) {
+void Engine::evalDevice(int n, const float* dSpatial, const float* dGlobal, const float* dMeta, const int* symmetry,
+                        const float* policyOptimism, float* dPolicy, float* dValue, float* dScore, float* dOwnership, bool doSync) {
   if(n < 1 || n > maxBatch_) throw Error(KMX_ERR_INVALID_ARG, "batch size out of range for this handle");
   hipCheck(hipSetDevice(device_), "hipSetDevice");
   stageRowParams(n, symmetry, policyOptimism);
-  runSchedule(n, dSpatial, dGlobal, dPolicy, dValue, dScore, dOwnership);
+  runSchedule(n, dSpatial, dGlobal, dMeta, dPolicy, dValue, dScore, dOwnership);
   rows_ += (uint64_t)n;
   batches_ += 1;
   if(doSync) sync();
 }
 
-void Engine::evalHostBegin(int n, const float* const* rowSpatial, const float* const* rowGlobal, const int* symmetry,
-                           const float* policyOptimism, float* const* outOwnership) {
+void Engine::evalHostBegin(int n, const float* const* rowSpatial, const float* const* rowGlobal, const float* const* rowMeta,
+                           const int* symmetry, const float* policyOptimism, float* const* outOwnership) {
   if(n < 1 || n > maxBatch_) throw Error(KMX_ERR_INVALID_ARG, "batch size out of range for this handle");
   hipCheck(hipSetDevice(device_), "hipSetDevice");
   hipCheck(hipStreamSynchronize(stream_), "stream synchronize");  // the single-buffered row staging below
@@ -574,13 +597,21 @@ void Engine::evalHostBegin(int n, const float* const* rowSpatial, const float* c
   }
   hipCheck(hipMemcpyAsync(dSpatialIn_.get(), hSpatial_, n * rowElts * sizeof(float), hipMemcpyHostToDevice, stream_), "H2D spatial");
   hipCheck(hipMemcpyAsync(dGlobalIn_.get(), hGlobal_, (size_t)n * gin_ * sizeof(float), hipMemcpyHostToDevice, stream_), "H2D global");
+  if(min_ > 0 && rowMeta != nullptr) {
+    for(int i = 0; i < n; i++) {
+      if(!rowMeta[i]) throw Error(KMX_ERR_INVALID_ARG, "null metadata row pointer");
+      memcpy(hMeta_ + (size_t)i * min_, rowMeta[i], min_ * sizeof(float));
+    }
+    hipCheck(hipMemcpyAsync(dMetaIn_.get(), hMeta_, (size_t)n * min_ * sizeof(float), hipMemcpyHostToDevice, stream_), "H2D meta");
+  }
+  if(min_ == 0 && rowMeta != nullptr) throw Error(KMX_ERR_INVALID_ARG, "this net has no sgf-metadata encoder: the metadata input must be NULL");
   bool anyOwner = false;
   if(outOwnership)
     for(int i = 0; i < n; i++) anyOwner = anyOwner || outOwnership[i] != nullptr;
   hostAnyOwner_ = anyOwner;
   stageRowParams(n, symmetry, policyOptimism);
-  runSchedule(n, dSpatialIn_.as<float>(), dGlobalIn_.as<float>(), dPolicy_.as<float>(), dValue_.as<float>(),
-              dScore_.as<float>(), anyOwner ? dOwnership_.as<float>() : nullptr);
+  runSchedule(n, dSpatialIn_.as<float>(), dGlobalIn_.as<float>(), (min_ > 0 && rowMeta) ? dMetaIn_.as<float>() : nullptr,
+              dPolicy_.as<float>(), dValue_.as<float>(), dScore_.as<float>(), anyOwner ? dOwnership_.as<float>() : nullptr);
   hipCheck(hipMemcpyAsync(hPolicy_, dPolicy_.get(), (size_t)n * (S_ + 1) * sizeof(float), hipMemcpyDeviceToHost, stream_), "D2H policy");
   hipCheck(hipMemcpyAsync(hValue_, dValue_.get(), (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_), "D2H value");
   hipCheck(hipMemcpyAsync(hScore_, dScore_.get(), (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost, stream_), "D2H score");
@@ -600,10 +631,10 @@ void Engine::evalHostFinish(int n, float* const* outPolicy, float* outValue, flo
   batches_ += 1;
 }
 
-void Engine::evalHost(int n, const float* const* rowSpatial, const float* const* rowGlobal, const int* symmetry,
-                      const float* policyOptimism, float* const* outPolicy, float* outValue, float* outScore,
+void Engine::evalHost(int n, const float* const* rowSpatial, const float* const* rowGlobal, const float* const* rowMeta,
+                      const int* symmetry, const float* policyOptimism, float* const* outPolicy, float* outValue, float* outScore,
                       float* const* outOwnership) {
-  evalHostBegin(n, rowSpatial, rowGlobal, symmetry, policyOptimism, outOwnership);
+  evalHostBegin(n, rowSpatial, rowGlobal, rowMeta, symmetry, policyOptimism, outOwnership);
   evalHostFinish(n, outPolicy, outValue, outScore, outOwnership);
 }
 

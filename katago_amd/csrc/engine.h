@@ -84,15 +84,16 @@ class Engine {
 
   // Host-buffer entry (kmx_eval). Synchronous. = evalHostBegin + evalHostFinish; the two halves exist so that a handle
   // that splits a batch over two engines can have both halves in flight.
-  void evalHost(int n, const float* const* rowSpatial, const float* const* rowGlobal, const int* symmetry,
-                const float* policyOptimism, float* const* outPolicy, float* outValue, float* outScore,
+  void evalHost(int n, const float* const* rowSpatial, const float* const* rowGlobal, const float* const* rowMeta,
+                const int* symmetry, const float* policyOptimism, float* const* outPolicy, float* outValue, float* outScore,
                 float* const* outOwnership);
-  void evalHostBegin(int n, const float* const* rowSpatial, const float* const* rowGlobal, const int* symmetry,
-                     const float* policyOptimism, float* const* outOwnership);
+  void evalHostBegin(int n, const float* const* rowSpatial, const float* const* rowGlobal, const float* const* rowMeta,
+                     const int* symmetry, const float* policyOptimism, float* const* outOwnership);
   void evalHostFinish(int n, float* const* outPolicy, float* outValue, float* outScore, float* const* outOwnership);
   // Device-buffer entry (kmx_eval_device).
-  void evalDevice(int n, const float* dSpatial, const float* dGlobal, const int* symmetry, const float* policyOptimism,
-                  float* dPolicy, float* dValue, float* dScore, float* dOwnership, bool sync);
+  void evalDevice(int n, const float* dSpatial, const float* dGlobal, const float* dMeta, const int* symmetry,
+                  const float* policyOptimism, float* dPolicy, float* dValue, float* dScore, float* dOwnership, bool sync);
+  int numInputMetaChannels() const { return min_; }
   void sync();
 
   void setProfiling(bool enabled);
@@ -130,8 +131,8 @@ class Engine {
   const FusedConv* newConv(const std::vector<ConvSegment>& segs, std::vector<int>* offs = nullptr);
   float* uploadFloats(const std::vector<float>& v);
   void stageRowParams(int n, const int* symmetry, const float* policyOptimism);
-  void runSchedule(int n, const float* dSpatial, const float* dGlobal, float* dPolicy, float* dValue, float* dScore,
-                   float* dOwnership);
+  void runSchedule(int n, const float* dSpatial, const float* dGlobal, const float* dMeta, float* dPolicy, float* dValue,
+                   float* dScore, float* dOwnership);
 
   int dtype_, device_, X_, Y_, S_, maxBatch_;
   hipStream_t stream_;
@@ -143,11 +144,12 @@ class Engine {
   DevBuf zeroPage_;
   DevBuf inputT_, mask_, maskSum_, ncBias_;
   DevBuf dSymmetry_, dOptimism_;
-  DevBuf dSpatialIn_, dGlobalIn_;  // staging for the host entry
+  DevBuf dSpatialIn_, dGlobalIn_, dMetaIn_;  // staging for the host entry
   DevBuf dPolicy_, dValue_, dScore_, dOwnership_, polFeat_;
   // pinned host staging
   float* hSpatial_ = nullptr;
   float* hGlobal_ = nullptr;
+  float* hMeta_ = nullptr;
   float* hPolicy_ = nullptr;
   float* hValue_ = nullptr;
   float* hScore_ = nullptr;
@@ -158,11 +160,12 @@ class Engine {
   int stagingSlot_ = 0;
   bool hostAnyOwner_ = false;
   int cfgScale_ = 1;
-  int cin_ = 0, gin_ = 0;
+  int cin_ = 0, gin_ = 0, min_ = 0;  // spatial, global, sgf-metadata input channels
 
   // pointers the ops read at run time (set by runSchedule)
   const float* curSpatial_ = nullptr;
   const float* curGlobal_ = nullptr;
+  const float* curMeta_ = nullptr;
   float* curPolicy_ = nullptr;
   float* curValue_ = nullptr;
   float* curScore_ = nullptr;

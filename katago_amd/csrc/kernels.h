@@ -70,6 +70,14 @@ struct InputArgs {
   const float* wGlobal;  // [gin][C]
   float* ncBias;         // [N][ncStride]
   int C, ncStride;
+  // sgf-metadata encoder (null meta = none): ncBias += W3^T act2(W2^T act1(W1^T meta + b1) + b2)   (eigenbackend.cpp:1848-1860)
+  const float* meta;     // [N][metaIn] device, or null
+  int metaIn, metaC1, metaC2, metaAct1, metaAct2;
+  const float* mW1;      // [metaIn][metaC1]
+  const float* mB1;
+  const float* mW2;      // [metaC1][metaC2]
+  const float* mB2;
+  const float* mW3;      // [metaC2][C]
 };
 hipError_t launchInputExpand(int dtype, const InputArgs& a, hipStream_t stream);
 

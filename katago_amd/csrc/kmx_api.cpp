@@ -121,7 +121,8 @@ int kmx_model_info_get(const kmx_model* model, kmx_model_info* out) {
     out->model_version = d.version;
     out->num_input_channels = d.numInputChannels;
     out->num_input_global_channels = d.numInputGlobalChannels;
-    out->num_input_meta_channels = 0;
+    out->num_input_meta_channels = d.metaEncoderVersion > 0 ? d.numInputMetaChannels : 0;
+    out->meta_encoder_version = d.metaEncoderVersion;
     out->num_policy_channels = d.numPolicyChannels;
     out->num_value_channels = d.numValueChannels;
     out->num_score_value_channels = d.numScoreValueChannels;
@@ -194,6 +195,13 @@ int kmx_handle_precision(const kmx_handle* handle) { return handle ? handle->pre
 int kmx_eval(kmx_handle* handle, int n_rows, const float* const* row_spatial, const float* const* row_global,
              const int* symmetry, const float* policy_optimism, float* const* out_policy, float* out_value, float* out_score,
              float* const* out_ownership) {
+  return kmx_eval_meta(handle, n_rows, row_spatial, row_global, nullptr, symmetry, policy_optimism, out_policy, out_value, out_score,
+                       out_ownership);
+}
+
+int kmx_eval_meta(kmx_handle* handle, int n_rows, const float* const* row_spatial, const float* const* row_global,
+                  const float* const* row_meta, const int* symmetry, const float* policy_optimism, float* const* out_policy,
+                  float* out_value, float* out_score, float* const* out_ownership) {
   return guarded([&] {
     if(!handle || !row_spatial || !row_global || !out_policy || !out_value || !out_score)
       throw Error(KMX_ERR_INVALID_ARG, "kmx_eval: null argument");
@@ -206,15 +214,15 @@ int kmx_eval(kmx_handle* handle, int n_rows, const float* const* row_spatial, co
     handle->batches++;
     if(!handle->splits(n_rows)) {
       handle->engine->setConcurrency(1);
-      handle->engine->evalHost(n_rows, row_spatial, row_global, symmetry, policy_optimism, out_policy, out_value, out_score,
-                               out_ownership);
+      handle->engine->evalHost(n_rows, row_spatial, row_global, row_meta, symmetry, policy_optimism, out_policy, out_value,
+                               out_score, out_ownership);
       return;
     }
     const int h = n_rows - n_rows / 2, r = n_rows / 2;  // engine2 holds max_batch/2 rows
     handle->engine->setConcurrency(2);
     handle->engine2->setConcurrency(2);
-    handle->engine->evalHostBegin(h, row_spatial, row_global, symmetry, policy_optimism, out_ownership);
-    handle->engine2->evalHostBegin(r, row_spatial + h, row_global + h, symmetry ? symmetry + h : nullptr,
+    handle->engine->evalHostBegin(h, row_spatial, row_global, row_meta, symmetry, policy_optimism, out_ownership);
+    handle->engine2->evalHostBegin(r, row_spatial + h, row_global + h, row_meta ? row_meta + h : nullptr, symmetry ? symmetry + h : nullptr,
                                    policy_optimism ? policy_optimism + h : nullptr, out_ownership ? out_ownership + h : nullptr);
     handle->engine->evalHostFinish(h, out_policy, out_value, out_score, out_ownership);
     handle->engine2->evalHostFinish(r, out_policy + h, out_value + (size_t)h * 3, out_score + (size_t)h * 6,
@@ -224,6 +232,13 @@ int kmx_eval(kmx_handle* handle, int n_rows, const float* const* row_spatial, co
 
 int kmx_eval_device(kmx_handle* handle, int n_rows, const float* d_spatial, const float* d_global, const int* symmetry,
                     const float* policy_optimism, float* d_policy, float* d_value, float* d_score, float* d_ownership, int sync) {
+  return kmx_eval_device_meta(handle, n_rows, d_spatial, d_global, nullptr, symmetry, policy_optimism, d_policy, d_value, d_score,
+                              d_ownership, sync);
+}
+
+int kmx_eval_device_meta(kmx_handle* handle, int n_rows, const float* d_spatial, const float* d_global, const float* d_meta,
+                         const int* symmetry, const float* policy_optimism, float* d_policy, float* d_value, float* d_score,
+                         float* d_ownership, int sync) {
   return guarded([&] {
     if(!handle || !d_spatial || !d_global || !d_policy || !d_value || !d_score)
       throw Error(KMX_ERR_INVALID_ARG, "kmx_eval_device: null argument");
@@ -234,8 +249,8 @@ int kmx_eval_device(kmx_handle* handle, int n_rows, const float* d_spatial, cons
     handle->batches++;
     if(!handle->splits(n_rows)) {
       handle->engine->setConcurrency(1);
-      handle->engine->evalDevice(n_rows, d_spatial, d_global, symmetry, policy_optimism, d_policy, d_value, d_score, d_ownership,
-                                 sync != 0);
+      handle->engine->evalDevice(n_rows, d_spatial, d_global, d_meta, symmetry, policy_optimism, d_policy, d_value, d_score,
+                                 d_ownership, sync != 0);
       return;
     }
     const int h = n_rows - n_rows / 2, r = n_rows / 2;
@@ -243,8 +258,10 @@ int kmx_eval_device(kmx_handle* handle, int n_rows, const float* d_spatial, cons
     const size_t spRow = S * handle->engine->numInputChannels(), glRow = handle->engine->numInputGlobalChannels();
     handle->engine->setConcurrency(2);
     handle->engine2->setConcurrency(2);
-    handle->engine->evalDevice(h, d_spatial, d_global, symmetry, policy_optimism, d_policy, d_value, d_score, d_ownership, false);
-    handle->engine2->evalDevice(r, d_spatial + h * spRow, d_global + h * glRow, symmetry ? symmetry + h : nullptr,
+    const size_t mtRow = handle->engine->numInputMetaChannels();
+    handle->engine->evalDevice(h, d_spatial, d_global, d_meta, symmetry, policy_optimism, d_policy, d_value, d_score, d_ownership, false);
+    handle->engine2->evalDevice(r, d_spatial + h * spRow, d_global + h * glRow, d_meta ? d_meta + h * mtRow : nullptr,
+                                symmetry ? symmetry + h : nullptr,
                                 policy_optimism ? policy_optimism + h : nullptr, d_policy + h * (S + 1), d_value + (size_t)h * 3,
                                 d_score + (size_t)h * 6, d_ownership ? d_ownership + h * S : nullptr, false);
     if(sync != 0) {

@@ -59,10 +59,39 @@ __global__ __launch_bounds__(BT) void inputExpandKernel(const InputArgs a) {
   if(tid == 0) a.maskSum[n] = ms;
   // ncBias[n][c] = sum_g global[n][g] * W[g][c]
   const float* gl = a.global + (size_t)n * a.gin;
+  if(a.meta == nullptr) {
+    for(int c = tid; c < a.C; c += BT) {
+      float s = 0.0f;
+      for(int g = 0; g < a.gin; g++) s += gl[g] * a.wGlobal[(size_t)g * a.C + c];
+      a.ncBias[(size_t)n * a.ncStride + c] = s;
+    }
+    return;
+  }
+  // sgf-metadata encoder: a 3-layer MLP per board whose output joins the global-feature bias
+  extern __shared__ float metaSm[];  // in[metaIn], h1[metaC1], h2[metaC2]
+  float* in = metaSm;
+  float* h1 = in + a.metaIn;
+  float* h2 = h1 + a.metaC1;
+  for(int k = tid; k < a.metaIn; k += BT) in[k] = a.meta[(size_t)n * a.metaIn + k];
+  __syncthreads();
+  for(int j = tid; j < a.metaC1; j += BT) {
+    float s = a.mB1[j];
+    for(int k = 0; k < a.metaIn; k++) s += in[k] * a.mW1[(size_t)k * a.metaC1 + j];
+    h1[j] = actApply(s, a.metaAct1);
+  }
+  __syncthreads();
+  for(int i = tid; i < a.metaC2; i += BT) {
+    float s = a.mB2[i];
+    for(int j = 0; j < a.metaC1; j++) s += h1[j] * a.mW2[(size_t)j * a.metaC2 + i];
+    h2[i] = actApply(s, a.metaAct2);
+  }
+  __syncthreads();
   for(int c = tid; c < a.C; c += BT) {
     float s = 0.0f;
     for(int g = 0; g < a.gin; g++) s += gl[g] * a.wGlobal[(size_t)g * a.C + c];
-    a.ncBias[(size_t)n * a.ncStride + c] = s;
+    float t = 0.0f;
+    for(int i = 0; i < a.metaC2; i++) t += h2[i] * a.mW3[(size_t)i * a.C + c];
+    a.ncBias[(size_t)n * a.ncStride + c] = s + t;
   }
 }
 
@@ -621,7 +650,8 @@ inline int gridFor(size_t total) {
 
 hipError_t launchInputExpand(int dtype, const InputArgs& a, hipStream_t stream) {
   if(a.cin > KCHUNK) return hipErrorInvalidValue;
-  KMX_DISPATCH(dtype, inputExpandKernel, dim3(a.N), dim3(BT), 0, stream, a);
+  const size_t lds = a.meta ? sizeof(float) * ((size_t)a.metaIn + a.metaC1 + a.metaC2) : 0;
+  KMX_DISPATCH(dtype, inputExpandKernel, dim3(a.N), dim3(BT), lds, stream, a);
 }
 hipError_t launchGPoolApply(int dtype, const GPoolArgs& a, hipStream_t stream) {
   const bool vec = a.G % 8 == 0 && a.R % 8 == 0 && a.gStride % 8 == 0 && a.rStride % 8 == 0 && a.gOffset % 8 == 0 &&

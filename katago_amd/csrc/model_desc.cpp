@@ -367,11 +367,12 @@ std::unique_ptr<ModelDesc> ModelDesc::loadFromFile(const std::string& path, cons
         if(!(m.postProcess[i] > 0)) bad(m.name + ": post-process multipliers must be positive");
       }
     if(m.version >= 15) {
-      int metaEncoderVersion = r.integer("metaEncoderVersion");
+      m.metaEncoderVersion = r.integer("metaEncoderVersion");
       (void)r.integer("preferPassAliveUnderSuicideRules");
       r.expectZeros(6, "model option");
-      if(metaEncoderVersion != 0)
-        throw ModelError(KMX_ERR_UNSUPPORTED, m.name + ": nets with an sgf-metadata encoder (humanSL) are not supported by the katamx backend");
+      if(m.metaEncoderVersion < 0) bad(m.name + ": model metaEncoderVersion unexpected value");
+      if(m.metaEncoderVersion > 1)  // modelversion.cpp:83-89: only version 1 (192 input features) exists
+        throw ModelError(KMX_ERR_UNSUPPORTED, m.name + ": metaEncoderVersion " + std::to_string(m.metaEncoderVersion) + " is not supported");
     }
     // trunk
     std::string trunkName = r.token("trunk name");
@@ -392,6 +393,21 @@ std::unique_ptr<ModelDesc> ModelDesc::loadFromFile(const std::string& path, cons
     m.initialConv = parseConv(r);
     m.initialMatMul = parseMatMul(r);
     if(m.initialConv.outC != m.trunkC || m.initialMatMul.outC != m.trunkC) bad(trunkName + ": initial layers do not produce trunkNumChannels");
+    if(m.metaEncoderVersion > 0) {  // SGFMetadataEncoderDesc, desc.cpp:1571-1625
+      const std::string ename = r.token("sgf metadata encoder name");
+      m.numInputMetaChannels = r.integer("numInputMetaChannels");
+      if(m.numInputMetaChannels != 192) bad(ename + ": number of in channels did not match expected (192)");
+      m.metaMul1 = parseMatMul(r);
+      m.metaBias1 = parseMatBias(r);
+      m.metaAct1 = parseAct(r, m.version);
+      m.metaMul2 = parseMatMul(r);
+      m.metaBias2 = parseMatBias(r);
+      m.metaAct2 = parseAct(r, m.version);
+      m.metaMul3 = parseMatMul(r);
+      if(m.metaMul1.inC != m.numInputMetaChannels || m.metaMul1.outC != m.metaBias1.c || m.metaMul2.inC != m.metaMul1.outC ||
+         m.metaMul2.outC != m.metaBias2.c || m.metaMul3.inC != m.metaMul2.outC || m.metaMul3.outC != m.trunkC)
+        bad(ename + ": sgf metadata encoder channel counts are inconsistent");
+    }
     m.blocks = parseStack(r, m.version, m.numBlocks, m.trunkC, trunkName);
     m.trunkTipBN = parseBn(r);
     m.trunkTipBN.act = parseAct(r, m.version);

@@ -68,6 +68,12 @@ struct ModelDesc {
 
   ConvDesc initialConv;
   MatMulDesc initialMatMul;
+  // sgf-metadata encoder (desc.cpp:1571-1625): meta[192] -> mul1+bias1+act1 -> mul2+bias2+act2 -> mul3 -> [trunkC],
+  // added to the trunk like the global-feature bias (eigenbackend.cpp:1929-1932). metaEncoderVersion 0 = none.
+  int metaEncoderVersion = 0, numInputMetaChannels = 0;
+  MatMulDesc metaMul1, metaMul2, metaMul3;
+  MatBiasDesc metaBias1, metaBias2;
+  int metaAct1 = 0, metaAct2 = 0;
   std::vector<BlockDesc> blocks;
   BnDesc trunkTipBN;
 

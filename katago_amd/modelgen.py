@@ -130,8 +130,11 @@ def _nested(w, name, c, mid, gpool, with_gpool):
     w.conv(name + ".convq", 1, mid, c, gain=0.35)
 
 
-def write_model(path, arch, seed=20260921, version=15, activation="mish", name=None, stem_kernel=3):
-    """Write a random-weight model file. `path` may end in .bin, .bin.gz, .txt or .txt.gz. Returns the architecture dict."""
+def write_model(path, arch, seed=20260921, version=15, activation="mish", name=None, stem_kernel=3, meta_encoder=None):
+    """Write a random-weight model file. `path` may end in .bin, .bin.gz, .txt or .txt.gz. Returns the architecture dict.
+    meta_encoder = internal channel count of an sgf-metadata encoder (export_model_pytorch.py:493-504; version >= 15), or None."""
+    if meta_encoder and version < 15:
+        raise ValueError("the sgf-metadata encoder needs model version >= 15")
     a = ARCHS[arch] if isinstance(arch, str) else arch
     rng = np.random.default_rng(seed)
     opener = gzip.open if path.endswith(".gz") else open
@@ -145,7 +148,8 @@ def write_model(path, arch, seed=20260921, version=15, activation="mish", name=N
             for v in (20.0, 20.0, 20.0, 20.0, 40.0, 0.25, 150.0):
                 w.ln(v)
         if version >= 15:
-            for _ in range(8):
+            w.ln(1 if meta_encoder else 0)  # metaEncoderVersion
+            for _ in range(7):
                 w.ln(0)
         C, mid, gp = a["C"], a["mid"], a["gpool"]
         w.ln("trunk")
@@ -156,6 +160,17 @@ def write_model(path, arch, seed=20260921, version=15, activation="mish", name=N
                 w.ln(0)
         w.conv("model.conv_spatial", stem_kernel, 22, C)
         w.matmul("model.linear_global", 19, C, gain=0.5)
+        if meta_encoder:
+            e = "model.sgf_metadata_encoder"
+            w.ln(e)
+            w.ln(192)
+            w.matmul(e + ".mul1", 192, meta_encoder, gain=1.5)
+            w.matbias(e + ".bias1", meta_encoder)
+            w.activation(e + ".act1")
+            w.matmul(e + ".mul2", meta_encoder, meta_encoder, gain=1.5)
+            w.matbias(e + ".bias2", meta_encoder)
+            w.activation(e + ".act2")
+            w.matmul(e + ".mul3", meta_encoder, C, gain=0.7)
         for i, kind in enumerate(a["blocks"]):
             bname = "model.blocks.%d" % i
             if kind == "r":

@@ -187,8 +187,9 @@ def isUsingFP16(handle):
     return handle.precision != "fp32"
 
 
-def getOutput(handle, rowSpatial, rowGlobal, symmetries=None, policyOptimisms=None, includeOwnerMap=True):
-    """NeuralNet::getOutput. rowSpatial: float32 [n, nnY*nnX, 22] NHWC (unsymmetrised), rowGlobal: [n, 19].
+def getOutput(handle, rowSpatial, rowGlobal, symmetries=None, policyOptimisms=None, includeOwnerMap=True, rowMeta=None):
+    """NeuralNet::getOutput. rowSpatial: float32 [n, nnY*nnX, 22] NHWC (unsymmetrised), rowGlobal: [n, 19], rowMeta: [n, 192]
+    for nets with an sgf-metadata encoder (NNResultBuf::rowMetaBuf), else None.
     Returns dict of logits: policy [n, S+1] (last = pass), value [n,3], score [n,6], ownership [n,S] or None."""
     lib = handle._lib
     rowSpatial = np.ascontiguousarray(rowSpatial, dtype=np.float32)
@@ -210,8 +211,13 @@ def getOutput(handle, rowSpatial, rowGlobal, symmetries=None, policyOptimisms=No
     gl_ptrs = PT(*[_fp(gl2[i]) for i in range(n)])
     pol_ptrs = PT(*[_fp(policy[i]) for i in range(n)])
     own_ptrs = PT(*[_fp(ownership[i]) for i in range(n)]) if includeOwnerMap else None
-    capi.check(lib.kmx_eval(handle._p, n, sp_ptrs, gl_ptrs, sym.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _fp(opt),
-                            pol_ptrs, _fp(value), _fp(score), own_ptrs), lib)
+    mt_ptrs = None
+    if rowMeta is not None:
+        mt2 = np.ascontiguousarray(rowMeta, dtype=np.float32).reshape(n, -1)
+        assert handle.model.info.num_input_meta_channels in (0, mt2.shape[1])  # 0: the library rejects the call
+        mt_ptrs = PT(*[_fp(mt2[i]) for i in range(n)])
+    capi.check(lib.kmx_eval_meta(handle._p, n, sp_ptrs, gl_ptrs, mt_ptrs, sym.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _fp(opt),
+                                 pol_ptrs, _fp(value), _fp(score), own_ptrs), lib)
     return {"policy": policy, "value": value, "score": score, "ownership": ownership}
 
 

@@ -75,6 +75,11 @@ struct okmx_model {
   int numBlocks, C;
   OConv initialConv;
   OMatMul initialMatMul;
+  /* SGFMetadataEncoderDesc (desc.cpp:1571-1625); metaEncoderVersion 0 = none */
+  int metaEncoderVersion;
+  OMatMul metaMul1, metaMul2, metaMul3;
+  OMatBias metaBias1, metaBias2;
+  int metaAct1, metaAct2;
   OBlock* blocks;
   OBn trunkTipBN;
   /* policy head (desc.cpp:2084-2104) */
@@ -311,6 +316,7 @@ void okmx_model_free(okmx_model* m) {
   if(!m) return;
   free_conv(&m->initialConv);
   free(m->initialMatMul.w);
+  free(m->metaMul1.w); free(m->metaMul2.w); free(m->metaMul3.w); free(m->metaBias1.w); free(m->metaBias2.w);
   for(int i = 0; i < m->numBlocks && m->blocks; i++) free_block(&m->blocks[i]);
   free(m->blocks);
   free_bn(&m->trunkTipBN);
@@ -401,7 +407,8 @@ static int parse_model(Rd* r, okmx_model* m) {
       if(rd_int(r, "unused model option") != 0) rd_fail(r, "unknown/unsupported model option");
   }
   if(r->err) return 0;
-  if(metaEncoderVersion != 0) { rd_fail(r, "sgf-metadata (humanSL) nets are not supported"); return 0; }
+  if(metaEncoderVersion < 0 || metaEncoderVersion > 1) { rd_fail(r, "unsupported metaEncoderVersion"); return 0; } /* modelversion.cpp:83-89 */
+  m->metaEncoderVersion = info->meta_encoder_version = metaEncoderVersion;
 
   /* trunk */
   rd_token(r, tok, sizeof(tok));
@@ -422,6 +429,21 @@ static int parse_model(Rd* r, okmx_model* m) {
   parse_conv(r, &m->initialConv);
   parse_matmul(r, &m->initialMatMul);
   if(r->err) return 0;
+  if(m->metaEncoderVersion > 0) { /* SGFMetadataEncoderDesc, desc.cpp:1571-1625 */
+    rd_token(r, tok, sizeof(tok));
+    info->num_input_meta_channels = rd_int(r, "numInputMetaChannels");
+    parse_matmul(r, &m->metaMul1);
+    parse_matbias(r, &m->metaBias1);
+    m->metaAct1 = parse_act(r, m->version);
+    parse_matmul(r, &m->metaMul2);
+    parse_matbias(r, &m->metaBias2);
+    m->metaAct2 = parse_act(r, m->version);
+    parse_matmul(r, &m->metaMul3);
+    if(r->err) return 0;
+    if(info->num_input_meta_channels != 192 || m->metaMul1.ic != 192 || m->metaMul1.oc != m->metaBias1.c ||
+       m->metaMul2.ic != m->metaMul1.oc || m->metaMul2.oc != m->metaBias2.c || m->metaMul3.ic != m->metaMul2.oc ||
+       m->metaMul3.oc != m->C) { rd_fail(r, "sgf metadata encoder channel counts are inconsistent"); return 0; }
+  }
   m->blocks = (OBlock*)calloc(m->numBlocks, sizeof(OBlock));
   parse_block_stack(r, m->version, m->numBlocks, m->C, m->blocks);
   parse_bn(r, &m->trunkTipBN);
@@ -720,12 +742,26 @@ void okmx_copy_with_symmetry(const float* src, float* dst, int hSize, int wSize,
 
 /* Trunk::apply (eigenbackend.cpp:1909-1947) up to (which==1) or including (which==0) the tip BN */
 static void trunk_apply(const okmx_model* m, int n, int X, int Y, const float* input, const float* inputGlobal,
-                        const float* mask, const float* maskSum, float* trunkRaw, float* trunkOut) {
+                        const float* inputMeta, const float* mask, const float* maskSum, float* trunkRaw, float* trunkOut) {
   const int S = X * Y, C = m->C;
   float* gbias = falloc((size_t)n * C);
   conv_apply(&m->initialConv, n, X, Y, input, trunkRaw, 0);
   matmul_apply(&m->initialMatMul, n, inputGlobal, gbias);
   add_nc_bias(n, S, C, trunkRaw, gbias);
+  if(m->metaEncoderVersion > 0) { /* SGFMetadataEncoder::apply (eigenbackend.cpp:1848-1860), added like the global bias (:1929-1932) */
+    const int C1 = m->metaMul1.oc, C2 = m->metaMul2.oc;
+    float* h1 = falloc((size_t)n * C1);
+    float* h2 = falloc((size_t)n * C2);
+    matmul_apply(&m->metaMul1, n, inputMeta, h1);
+    matbias_apply(&m->metaBias1, n, h1);
+    for(size_t i = 0; i < (size_t)n * C1; i++) h1[i] = act_apply(h1[i], m->metaAct1);
+    matmul_apply(&m->metaMul2, n, h1, h2);
+    matbias_apply(&m->metaBias2, n, h2);
+    for(size_t i = 0; i < (size_t)n * C2; i++) h2[i] = act_apply(h2[i], m->metaAct2);
+    matmul_apply(&m->metaMul3, n, h2, gbias);
+    add_nc_bias(n, S, C, trunkRaw, gbias);
+    free(h1); free(h2);
+  }
   blockstack_apply(m->blocks, m->numBlocks, n, X, Y, trunkRaw, mask, maskSum);
   if(trunkOut) bnact_apply(&m->trunkTipBN, n, S, trunkRaw, trunkOut, mask);
   free(gbias);
@@ -747,12 +783,13 @@ static void compute_mask(int n, int S, int Cin, const float* input, float* mask,
 int okmx_eval_trunk(const okmx_model* m, int X, int Y, int n, const float* spatial, const float* global, int which,
                     float* out) {
   if(!m || !spatial || !global || !out || n <= 0) return fail(KMX_ERR_INVALID_ARG, "okmx_eval_trunk: bad argument");
+  if(m->metaEncoderVersion > 0) return fail(KMX_ERR_UNSUPPORTED, "okmx_eval_trunk: not available for sgf-metadata nets");
   const int S = X * Y, C = m->C;
   float* mask = falloc((size_t)n * S);
   float* maskSum = falloc(n);
   compute_mask(n, S, m->info.num_input_channels, spatial, mask, maskSum);
   float* raw = falloc((size_t)n * S * C);
-  trunk_apply(m, n, X, Y, spatial, global, mask, maskSum, raw, which == 0 ? out : NULL);
+  trunk_apply(m, n, X, Y, spatial, global, NULL, mask, maskSum, raw, which == 0 ? out : NULL);
   if(which != 0) memcpy(out, raw, sizeof(float) * (size_t)n * S * C);
   free(raw); free(mask); free(maskSum);
   return KMX_OK;
@@ -762,8 +799,17 @@ int okmx_eval_trunk(const okmx_model* m, int X, int Y, int n, const float* spati
 int okmx_eval(const okmx_model* m, int X, int Y, int n, const float* const* row_spatial, const float* const* row_global,
               const int* symmetry, const float* policy_optimism, float* const* out_policy, float* out_value,
               float* out_score, float* const* out_ownership, int num_threads) {
+  return okmx_eval_meta(m, X, Y, n, row_spatial, row_global, NULL, symmetry, policy_optimism, out_policy, out_value, out_score,
+                        out_ownership, num_threads);
+}
+
+int okmx_eval_meta(const okmx_model* m, int X, int Y, int n, const float* const* row_spatial, const float* const* row_global,
+                   const float* const* row_meta, const int* symmetry, const float* policy_optimism, float* const* out_policy,
+                   float* out_value, float* out_score, float* const* out_ownership, int num_threads) {
   if(!m || n <= 0 || !row_spatial || !row_global || !out_policy || !out_value || !out_score)
     return fail(KMX_ERR_INVALID_ARG, "okmx_eval: bad argument");
+  if((m->metaEncoderVersion > 0) != (row_meta != NULL)) /* eigenbackend.cpp:1929-1936 asserts the same pairing */
+    return fail(KMX_ERR_INVALID_ARG, "okmx_eval: the metadata input must be given exactly for nets with an sgf-metadata encoder");
   if(X < 2 || Y < 2 || X > 19 || Y > 19) return fail(KMX_ERR_INVALID_ARG, "okmx_eval: nnXLen/nnYLen out of range");
 #ifdef _OPENMP
   int prevThreads = omp_get_max_threads();
@@ -784,8 +830,15 @@ int okmx_eval(const okmx_model* m, int X, int Y, int n, const float* const* row_
   compute_mask(n, S, Cin, input, mask, maskSum);
   float* trunkRaw = falloc((size_t)n * S * C);
   float* trunk = falloc((size_t)n * S * C);
-  trunk_apply(m, n, X, Y, input, inputGlobal, mask, maskSum, trunkRaw, trunk);
+  float* inputMeta = NULL;
+  if(row_meta) {
+    const int M = m->info.num_input_meta_channels;
+    inputMeta = falloc((size_t)n * M);
+    for(int b = 0; b < n; b++) memcpy(inputMeta + (size_t)b * M, row_meta[b], sizeof(float) * M);
+  }
+  trunk_apply(m, n, X, Y, input, inputGlobal, inputMeta, mask, maskSum, trunkRaw, trunk);
   free(trunkRaw);
+  free(inputMeta);
 
   /* PolicyHead::apply (eigenbackend.cpp:1992-2036) */
   const int P1 = m->p1Conv.oc, G1 = m->g1Conv.oc;

@@ -41,6 +41,13 @@ int okmx_eval(const okmx_model* model, int nn_x_len, int nn_y_len, int n_rows,
               float* const* out_policy, float* out_value, float* out_score,
               float* const* out_ownership, int num_threads);
 
+/* okmx_eval for nets with an sgf-metadata encoder: row_meta[i] -> float[num_input_meta_channels] (see kmx_eval_meta) */
+int okmx_eval_meta(const okmx_model* model, int nn_x_len, int nn_y_len, int n_rows,
+                   const float* const* row_spatial, const float* const* row_global, const float* const* row_meta,
+                   const int* symmetry, const float* policy_optimism,
+                   float* const* out_policy, float* out_value, float* out_score,
+                   float* const* out_ownership, int num_threads);
+
 /* Intermediate tensors for parity bisection (the reference's DEBUG_INTERMEDIATE_VALUES idea,
  * eigenbackend.cpp:26-27). which: 0 = trunk after tip BN+act [n][S][C] NHWC,
  * 1 = raw trunk before tip BN. Evaluates with symmetry 0. */

@@ -40,6 +40,8 @@ def lib():
         L.okmx_model_info_get.argtypes = [ctypes.c_void_p, ctypes.POINTER(capi.ModelInfo)]
         L.okmx_eval.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FPP, _FPP, _IP, _FP, _FPP, _FP, _FP, _FPP,
                                 ctypes.c_int]
+        L.okmx_eval_meta.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FPP, _FPP, _FPP, _IP, _FP, _FPP, _FP, _FP,
+                                     _FPP, ctypes.c_int]
         L.okmx_eval_trunk.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP, ctypes.c_int, _FP]
         L.okmx_test_conv.argtypes = [ctypes.POINTER(capi.ConvDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP]
         L.okmx_test_bnact.argtypes = [ctypes.POINTER(capi.BnActDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP, _FP]
@@ -99,7 +101,7 @@ def usable_cores(cap=32):
 
 
 def getOutput(model, nnXLen, nnYLen, rowSpatial, rowGlobal, symmetries=None, policyOptimisms=None, includeOwnerMap=True,
-              numThreads=0):
+              numThreads=0, rowMeta=None):
     if numThreads <= 0:
         numThreads = usable_cores()  # never oversubscribe a cgroup-limited box with one thread per host core
     rowSpatial = np.ascontiguousarray(rowSpatial, dtype=np.float32)
@@ -120,8 +122,12 @@ def getOutput(model, nnXLen, nnYLen, rowSpatial, rowGlobal, symmetries=None, pol
     gl_ptrs = PT(*[_fp(gl2[i]) for i in range(n)])
     pol_ptrs = PT(*[_fp(policy[i]) for i in range(n)])
     own_ptrs = PT(*[_fp(ownership[i]) for i in range(n)]) if includeOwnerMap else None
-    _check(lib().okmx_eval(model._p, nnXLen, nnYLen, n, sp_ptrs, gl_ptrs, sym.ctypes.data_as(_IP), _fp(opt), pol_ptrs, _fp(value),
-                           _fp(score), own_ptrs, numThreads))
+    mt_ptrs = None
+    if rowMeta is not None:
+        mt2 = np.ascontiguousarray(rowMeta, dtype=np.float32).reshape(n, -1)
+        mt_ptrs = PT(*[_fp(mt2[i]) for i in range(n)])
+    _check(lib().okmx_eval_meta(model._p, nnXLen, nnYLen, n, sp_ptrs, gl_ptrs, mt_ptrs, sym.ctypes.data_as(_IP), _fp(opt), pol_ptrs,
+                                _fp(value), _fp(score), own_ptrs, numThreads))
     return {"policy": policy, "value": value, "score": score, "ownership": ownership}
 
 

@@ -177,3 +177,44 @@ def test_handle_errors(ctx19, small_model):
     with pytest.raises(nn.KatamxError):
         nn.getOutput(h, sp, gl, [0, 9])  # symmetry out of range
     h.close()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_metadata_encoder_net(ctx19, model_dir, dtype):
+    """Nets with an sgf-metadata encoder (a19; desc.cpp:1571-1625, eigenbackend.cpp:1848-1860,1929-1932): the HIP path
+    against the reference-torch golden vectors and, on a bigger random net and a batch that takes the two-engine path,
+    against the oracle; the metadata input is mandatory for such nets and forbidden for the others."""
+    v = np.load(os.path.join(GOLD, "torch_meta_vectors.npz"))
+    model = nn.loadModelFile(os.path.join(GOLD, "torch_meta.bin.gz"))
+    assert model.info.meta_encoder_version == 1 and model.info.num_input_meta_channels == 192
+    h = nn.createComputeHandle(ctx19[dtype], model, 8)
+    mask = v["spatial_nhwc"][:, :, 0] > 0
+    n = mask.shape[0]
+    got = nn.getOutput(h, v["spatial_nhwc"], v["glob"], None, np.zeros(n, np.float32), rowMeta=v["meta"])
+    want = dict(policy=v["policy"][:, 0, :], value=v["value"], score=v["score"], ownership=v["ownership"])
+    assert outputs_close(got, want, mask, 0.03, 0.08 if dtype == "bf16" else 0.02)
+    with pytest.raises(nn.KatamxError):
+        nn.getOutput(h, v["spatial_nhwc"], v["glob"])  # metadata missing
+    h.close()
+
+    p = os.path.join(model_dir, "meta_b3c64nbt.bin.gz")
+    if not os.path.exists(p):
+        modelgen.write_model(p, "b3c64nbt", seed=77, version=15, meta_encoder=48)
+    rng = np.random.default_rng(77)
+    n = 230
+    sp, gl = make_rows(rng, n)
+    meta = (rng.random((n, 192)) < 0.15).astype(np.float32)
+    sym = rng.integers(0, 8, n).astype(np.int32)
+    want = oracle_outputs(("meta", n), p, sp, gl, sym) if False else oracle.getOutput(oracle.loadModelFile(p), 19, 19, sp, gl, sym, None, True, 0, meta)
+    h = nn.createComputeHandle(ctx19[dtype], nn.loadModelFile(p), 256)
+    got = nn.getOutput(h, sp, gl, sym, None, rowMeta=meta)
+    assert outputs_close(got, want, sp[:, :, 0] > 0, 0.05 if dtype == "bf16" else 0.02, 0.1 if dtype == "bf16" else 0.03)
+    h.close()
+    # a net WITHOUT an encoder refuses a metadata input (the reference asserts the same pairing)
+    p2 = os.path.join(model_dir, "plain_b2c32nbt.bin.gz")
+    if not os.path.exists(p2):
+        modelgen.write_model(p2, "b2c32nbt", seed=1)
+    h2 = nn.createComputeHandle(ctx19[dtype], nn.loadModelFile(p2), 8)
+    with pytest.raises(nn.KatamxError):
+        nn.getOutput(h2, sp[:2], gl[:2], None, None, rowMeta=meta[:2])
+    h2.close()

@@ -29,3 +29,27 @@ def test_oracle_matches_reference_torch_model():
     o = oracle.getOutput(m, 19, 19, v["spatial_nhwc"], v["glob"], None, np.full(4, 0.25, np.float32))
     want = v["policy"][:, 0, :] + 0.25 * (v["policy"][:, 1, :] - v["policy"][:, 0, :])
     assert np.abs(o["policy"] - want)[full].max() < 2e-5
+
+
+def test_oracle_matches_reference_torch_model_with_metadata_encoder():
+    """A net WITH an sgf-metadata encoder ("humanSL" nets; model header metaEncoderVersion 1): vectors from
+    tools/gen_torch_golden_meta.py (reference MetadataEncoder, model_pytorch.py:2881-2933, reference exporter)."""
+    v = np.load(os.path.join(GOLD, "torch_meta_vectors.npz"))
+    m = oracle.loadModelFile(os.path.join(GOLD, "torch_meta.bin.gz"))
+    assert m.info.meta_encoder_version == 1 and m.info.num_input_meta_channels == 192
+    mask = v["spatial_nhwc"][:, :, 0] > 0
+    n = mask.shape[0]
+    full = np.concatenate([mask, np.ones((n, 1), bool)], axis=1)
+    o = oracle.getOutput(m, 19, 19, v["spatial_nhwc"], v["glob"], None, np.zeros(n, np.float32), rowMeta=v["meta"])
+    assert np.abs(o["policy"] - v["policy"][:, 0, :])[full].max() < 2e-5
+    assert np.abs(o["value"] - v["value"]).max() < 1e-5
+    assert np.abs(o["score"] - v["score"]).max() < 1e-5
+    assert np.abs(o["ownership"] - v["ownership"])[mask].max() < 2e-5
+    # the encoder matters: other metadata -> other outputs; and it is mandatory for such a net
+    o2 = oracle.getOutput(m, 19, 19, v["spatial_nhwc"], v["glob"], None, np.zeros(n, np.float32), rowMeta=np.zeros_like(v["meta"]))
+    assert np.abs(o2["value"] - o["value"]).max() > 1e-3
+    try:
+        oracle.getOutput(m, 19, 19, v["spatial_nhwc"], v["glob"])
+        raise AssertionError("a metadata net must reject rows without metadata")
+    except oracle.OracleError:
+        pass
