@@ -197,7 +197,7 @@ def main():
         capi.check(lib.kmx_handle_set_profiling(handle._p, 0), lib)
         capi.check(lib.kmx_handle_set_split_min(handle._p, 224), lib)
 
-    host_rate = None
+    host_rate = host_packed_rate = None
     if args.host_buffers and rank == 0:
         # the reference's getOutput hands over host rows: same batch through kmx_eval (H2D + pass + D2H, synchronous)
         pol = np.empty((B, S + 1), dtype=np.float32)
@@ -216,6 +216,16 @@ def main():
         for _ in range(args.steps):
             call()
         host_rate = args.steps * B / (time.perf_counter() - th)
+        # the same rows bit-packed (kmx_eval_packed): 1012 bytes per row over PCIe instead of 31768
+        pk = nn.packRows(sp, 19, 19)
+        U8P = ctypes.POINTER(ctypes.c_uint8)
+        pk_ptrs = (U8P * B)(*[pk[i].ctypes.data_as(U8P) for i in range(B)])
+        callp = lambda: capi.check(lib.kmx_eval_packed(handle._p, B, pk_ptrs, ptrs[1], None, sym_p, opt_p, ptrs[2], f(val), f(sco), ptrs[3]), lib)
+        callp()
+        th = time.perf_counter()
+        for _ in range(args.steps):
+            callp()
+        host_packed_rate = args.steps * B / (time.perf_counter() - th)
 
     roofline = None
     if prof_entries:
@@ -246,6 +256,7 @@ def main():
         }
         if host_rate is not None:
             out["host_buffer_evals_per_s"] = round(host_rate, 1)
+            out["host_buffer_packed_evals_per_s"] = round(host_packed_rate, 1)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model_path, 8)
         print(json.dumps(out), flush=True)

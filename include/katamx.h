@@ -162,6 +162,20 @@ int kmx_eval_meta(kmx_handle* handle, int n_rows,
 int kmx_eval_device_meta(kmx_handle* handle, int n_rows, const float* d_spatial, const float* d_global, const float* d_meta,
                          const int* symmetry, const float* policy_optimism,
                          float* d_policy, float* d_value, float* d_score, float* d_ownership, int sync);
+/* Bit-packed spatial input. All 22 spatial features of inputs v7 are 0/1 (nninputs.cpp:2321-2592); the
+ * reference itself stores them bit-packed in its training rows (binaryInputNCHWPacked, dataio/trainingwrite.h:180-183;
+ * packBits, dataio/trainingwrite.cpp:314-337) and that exact layout is accepted here:
+ *   row_packed[i] -> uint8[num_input_channels * ceil(nnX*nnY / 8)]: plane by plane (NCHW), cells in y*nnX+x order, 8 per
+ *   byte, MOST significant bit first, every plane zero-padded to a whole byte — 1012 bytes per 19x19 row instead of the
+ *   31768 of the fp32 NHWC row. The device expands the bits (and applies the symmetry) in the input stage.
+ * Otherwise identical to kmx_eval_meta (row_meta NULL unless the net has an sgf-metadata encoder).
+ * kmx_pack_row converts one fp32 NHWC row (values 0 / 1; anything != 0 packs as 1) into that layout. */
+int kmx_eval_packed(kmx_handle* handle, int n_rows,
+                    const uint8_t* const* row_packed, const float* const* row_global, const float* const* row_meta,
+                    const int* symmetry, const float* policy_optimism,
+                    float* const* out_policy, float* out_value, float* out_score,
+                    float* const* out_ownership);
+int kmx_pack_row(const float* row_spatial_nhwc, int nn_x_len, int nn_y_len, int num_channels, uint8_t* out_packed);
 void* kmx_handle_stream(kmx_handle* handle); /* hipStream_t the handle launches on */
 int kmx_handle_sync(kmx_handle* handle);
 

@@ -99,6 +99,9 @@ SIGNATURES = {
     "kmx_handle_free": (None, [ctypes.c_void_p]),
     "kmx_handle_precision": (ctypes.c_int, [ctypes.c_void_p]),
     "kmx_eval": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _FPP, _FPP, _IP, _FP, _FPP, _FP, _FP, _FPP]),
+    "kmx_eval_packed": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)), _FPP, _FPP, _IP, _FP,
+                                       _FPP, _FP, _FP, _FPP]),
+    "kmx_pack_row": (ctypes.c_int, [_FP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint8)]),
     "kmx_eval_meta": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _FPP, _FPP, _FPP, _IP, _FP, _FPP, _FP, _FP, _FPP]),
     "kmx_eval_device_meta": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _IP, _FP,
                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),

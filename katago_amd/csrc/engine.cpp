@@ -144,6 +144,8 @@ Engine::Engine(const ModelDesc& model, int nnXLen, int nnYLen, int maxBatch, int
   dOptimism_ = DevBuf((size_t)maxBatch_ * sizeof(float));
   dSpatialIn_ = DevBuf(NS * cin_ * sizeof(float));
   dGlobalIn_ = DevBuf((size_t)maxBatch_ * gin_ * sizeof(float));
+  dPackedIn_ = DevBuf((size_t)maxBatch_ * packedRowBytes());
+  hipCheck(hipHostMalloc((void**)&hPacked_, (size_t)maxBatch_ * packedRowBytes()), "hipHostMalloc");
   if(min_ > 0) {
     dMetaIn_ = DevBuf((size_t)maxBatch_ * min_ * sizeof(float));
     hipCheck(hipHostMalloc((void**)&hMeta_, (size_t)maxBatch_ * min_ * sizeof(float)), "hipHostMalloc");
@@ -180,6 +182,7 @@ Engine::~Engine() {
   (void)hipHostFree(hSpatial_);
   (void)hipHostFree(hGlobal_);
   if(hMeta_) (void)hipHostFree(hMeta_);
+  if(hPacked_) (void)hipHostFree(hPacked_);
   (void)hipHostFree(hPolicy_);
   (void)hipHostFree(hValue_);
   (void)hipHostFree(hScore_);
@@ -359,6 +362,7 @@ void Engine::buildSchedule(const ModelDesc& m) {
       InputArgs x = ia;
       x.N = n;
       x.spatial = curSpatial_;
+      x.packed = curPacked_;
       x.global = curGlobal_;
       x.meta = curMeta_;
       hipCheck(launchInputExpand(dtype, x, st), "input staging launch");
@@ -474,12 +478,13 @@ void Engine::buildSchedule(const ModelDesc& m) {
   }
 }
 
-void Engine::runSchedule(int n, const float* dSpatial, const float* dGlobal, const float* dMeta, float* dPolicy, float* dValue,
-                         float* dScore, float* dOwnership) {
+void Engine::runSchedule(int n, const float* dSpatial, const unsigned char* dPacked, const float* dGlobal, const float* dMeta,
+                         float* dPolicy, float* dValue, float* dScore, float* dOwnership) {
   // the reference asserts the same pairing (eigenbackend.cpp:1929-1936)
   if(min_ > 0 && dMeta == nullptr) throw Error(KMX_ERR_INVALID_ARG, "this net has an sgf-metadata encoder: rows need the metadata input (kmx_eval_meta)");
   if(min_ == 0 && dMeta != nullptr) throw Error(KMX_ERR_INVALID_ARG, "this net has no sgf-metadata encoder: the metadata input must be NULL");
   curSpatial_ = dSpatial;
+  curPacked_ = dPacked;
   curGlobal_ = dGlobal;
   curMeta_ = dMeta;
   curPolicy_ = dPolicy;
@@ -579,23 +584,27 @@ void Engine::evalDevice(int n, const float* dSpatial, const float* dGlobal, cons
   if(n < 1 || n > maxBatch_) throw Error(KMX_ERR_INVALID_ARG, "batch size out of range for this handle");
   hipCheck(hipSetDevice(device_), "hipSetDevice");
   stageRowParams(n, symmetry, policyOptimism);
-  runSchedule(n, dSpatial, dGlobal, dMeta, dPolicy, dValue, dScore, dOwnership);
+  runSchedule(n, dSpatial, nullptr, dGlobal, dMeta, dPolicy, dValue, dScore, dOwnership);
   rows_ += (uint64_t)n;
   batches_ += 1;
   if(doSync) sync();
 }
 
-void Engine::evalHostBegin(int n, const float* const* rowSpatial, const float* const* rowGlobal, const float* const* rowMeta,
-                           const int* symmetry, const float* policyOptimism, float* const* outOwnership) {
+void Engine::evalHostBegin(int n, const float* const* rowSpatial, const unsigned char* const* rowPacked,
+                           const float* const* rowGlobal, const float* const* rowMeta, const int* symmetry,
+                           const float* policyOptimism, float* const* outOwnership) {
   if(n < 1 || n > maxBatch_) throw Error(KMX_ERR_INVALID_ARG, "batch size out of range for this handle");
   hipCheck(hipSetDevice(device_), "hipSetDevice");
   hipCheck(hipStreamSynchronize(stream_), "stream synchronize");  // the single-buffered row staging below
   const size_t rowElts = (size_t)S_ * cin_;
+  const size_t rowBytes = (size_t)packedRowBytes();
   for(int i = 0; i < n; i++) {
-    memcpy(hSpatial_ + i * rowElts, rowSpatial[i], rowElts * sizeof(float));
+    if(rowPacked) memcpy(hPacked_ + i * rowBytes, rowPacked[i], rowBytes);
+    else memcpy(hSpatial_ + i * rowElts, rowSpatial[i], rowElts * sizeof(float));
     memcpy(hGlobal_ + (size_t)i * gin_, rowGlobal[i], gin_ * sizeof(float));
   }
-  hipCheck(hipMemcpyAsync(dSpatialIn_.get(), hSpatial_, n * rowElts * sizeof(float), hipMemcpyHostToDevice, stream_), "H2D spatial");
+  if(rowPacked) hipCheck(hipMemcpyAsync(dPackedIn_.get(), hPacked_, n * rowBytes, hipMemcpyHostToDevice, stream_), "H2D packed planes");
+  else hipCheck(hipMemcpyAsync(dSpatialIn_.get(), hSpatial_, n * rowElts * sizeof(float), hipMemcpyHostToDevice, stream_), "H2D spatial");
   hipCheck(hipMemcpyAsync(dGlobalIn_.get(), hGlobal_, (size_t)n * gin_ * sizeof(float), hipMemcpyHostToDevice, stream_), "H2D global");
   if(min_ > 0 && rowMeta != nullptr) {
     for(int i = 0; i < n; i++) {
@@ -610,7 +619,8 @@ void Engine::evalHostBegin(int n, const float* const* rowSpatial, const float* c
     for(int i = 0; i < n; i++) anyOwner = anyOwner || outOwnership[i] != nullptr;
   hostAnyOwner_ = anyOwner;
   stageRowParams(n, symmetry, policyOptimism);
-  runSchedule(n, dSpatialIn_.as<float>(), dGlobalIn_.as<float>(), (min_ > 0 && rowMeta) ? dMetaIn_.as<float>() : nullptr,
+  runSchedule(n, rowPacked ? nullptr : dSpatialIn_.as<float>(), rowPacked ? dPackedIn_.as<unsigned char>() : nullptr,
+              dGlobalIn_.as<float>(), (min_ > 0 && rowMeta) ? dMetaIn_.as<float>() : nullptr,
               dPolicy_.as<float>(), dValue_.as<float>(), dScore_.as<float>(), anyOwner ? dOwnership_.as<float>() : nullptr);
   hipCheck(hipMemcpyAsync(hPolicy_, dPolicy_.get(), (size_t)n * (S_ + 1) * sizeof(float), hipMemcpyDeviceToHost, stream_), "D2H policy");
   hipCheck(hipMemcpyAsync(hValue_, dValue_.get(), (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_), "D2H value");
@@ -634,7 +644,7 @@ void Engine::evalHostFinish(int n, float* const* outPolicy, float* outValue, flo
 void Engine::evalHost(int n, const float* const* rowSpatial, const float* const* rowGlobal, const float* const* rowMeta,
                       const int* symmetry, const float* policyOptimism, float* const* outPolicy, float* outValue, float* outScore,
                       float* const* outOwnership) {
-  evalHostBegin(n, rowSpatial, rowGlobal, rowMeta, symmetry, policyOptimism, outOwnership);
+  evalHostBegin(n, rowSpatial, nullptr, rowGlobal, rowMeta, symmetry, policyOptimism, outOwnership);
   evalHostFinish(n, outPolicy, outValue, outScore, outOwnership);
 }
 

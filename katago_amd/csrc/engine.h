@@ -87,8 +87,10 @@ class Engine {
   void evalHost(int n, const float* const* rowSpatial, const float* const* rowGlobal, const float* const* rowMeta,
                 const int* symmetry, const float* policyOptimism, float* const* outPolicy, float* outValue, float* outScore,
                 float* const* outOwnership);
-  void evalHostBegin(int n, const float* const* rowSpatial, const float* const* rowGlobal, const float* const* rowMeta,
-                     const int* symmetry, const float* policyOptimism, float* const* outOwnership);
+  // rowPacked (bit planes, kernels.h InputArgs::packed) replaces rowSpatial when it is given
+  void evalHostBegin(int n, const float* const* rowSpatial, const unsigned char* const* rowPacked, const float* const* rowGlobal,
+                     const float* const* rowMeta, const int* symmetry, const float* policyOptimism, float* const* outOwnership);
+  int packedRowBytes() const { return cin_ * ((S_ + 7) / 8); }
   void evalHostFinish(int n, float* const* outPolicy, float* outValue, float* outScore, float* const* outOwnership);
   // Device-buffer entry (kmx_eval_device).
   void evalDevice(int n, const float* dSpatial, const float* dGlobal, const float* dMeta, const int* symmetry,
@@ -131,8 +133,8 @@ class Engine {
   const FusedConv* newConv(const std::vector<ConvSegment>& segs, std::vector<int>* offs = nullptr);
   float* uploadFloats(const std::vector<float>& v);
   void stageRowParams(int n, const int* symmetry, const float* policyOptimism);
-  void runSchedule(int n, const float* dSpatial, const float* dGlobal, const float* dMeta, float* dPolicy, float* dValue,
-                   float* dScore, float* dOwnership);
+  void runSchedule(int n, const float* dSpatial, const unsigned char* dPacked, const float* dGlobal, const float* dMeta,
+                   float* dPolicy, float* dValue, float* dScore, float* dOwnership);
 
   int dtype_, device_, X_, Y_, S_, maxBatch_;
   hipStream_t stream_;
@@ -144,12 +146,13 @@ class Engine {
   DevBuf zeroPage_;
   DevBuf inputT_, mask_, maskSum_, ncBias_;
   DevBuf dSymmetry_, dOptimism_;
-  DevBuf dSpatialIn_, dGlobalIn_, dMetaIn_;  // staging for the host entry
+  DevBuf dSpatialIn_, dGlobalIn_, dMetaIn_, dPackedIn_;  // staging for the host entry
   DevBuf dPolicy_, dValue_, dScore_, dOwnership_, polFeat_;
   // pinned host staging
   float* hSpatial_ = nullptr;
   float* hGlobal_ = nullptr;
   float* hMeta_ = nullptr;
+  unsigned char* hPacked_ = nullptr;
   float* hPolicy_ = nullptr;
   float* hValue_ = nullptr;
   float* hScore_ = nullptr;
@@ -166,6 +169,7 @@ class Engine {
   const float* curSpatial_ = nullptr;
   const float* curGlobal_ = nullptr;
   const float* curMeta_ = nullptr;
+  const unsigned char* curPacked_ = nullptr;
   float* curPolicy_ = nullptr;
   float* curValue_ = nullptr;
   float* curScore_ = nullptr;

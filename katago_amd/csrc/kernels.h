@@ -59,7 +59,8 @@ int chooseConvCfg(int ks, int coutPad, int batch);
 // ncBias[n][C] = W_global^T * global[n]   (copyInputsWithSymmetry nninputs.cpp:529-597, Model::apply
 // eigenbackend.cpp:2181-2182, initialMatMul eigenbackend.cpp:1928-1930)
 struct InputArgs {
-  const float* spatial;  // [N][S][cin]
+  const float* spatial;  // [N][S][cin], or null when `packed` is given
+  const unsigned char* packed;  // [N][cin][ceil(S/8)] bit planes, MSB first (binaryInputNCHWPacked layout), or null
   const float* global;   // [N][gin]
   const int* symmetry;   // [N] device
   int cin, gin;

@@ -199,34 +199,71 @@ int kmx_eval(kmx_handle* handle, int n_rows, const float* const* row_spatial, co
                        out_ownership);
 }
 
-int kmx_eval_meta(kmx_handle* handle, int n_rows, const float* const* row_spatial, const float* const* row_global,
-                  const float* const* row_meta, const int* symmetry, const float* policy_optimism, float* const* out_policy,
-                  float* out_value, float* out_score, float* const* out_ownership) {
+// kmx_eval / kmx_eval_meta / kmx_eval_packed: exactly one of row_spatial (fp32 NHWC rows) and row_packed (bit planes)
+static int evalHostEntry(kmx_handle* handle, int n_rows, const float* const* row_spatial, const unsigned char* const* row_packed,
+                         const float* const* row_global, const float* const* row_meta, const int* symmetry,
+                         const float* policy_optimism, float* const* out_policy, float* out_value, float* out_score,
+                         float* const* out_ownership) {
   return guarded([&] {
-    if(!handle || !row_spatial || !row_global || !out_policy || !out_value || !out_score)
+    if(!handle || (!row_spatial && !row_packed) || !row_global || !out_policy || !out_value || !out_score)
       throw Error(KMX_ERR_INVALID_ARG, "kmx_eval: null argument");
+    if(n_rows < 1 || n_rows > handle->maxBatch) throw Error(KMX_ERR_INVALID_ARG, "batch size out of range for this handle");
     for(int i = 0; i < n_rows; i++)
-      if(!row_spatial[i] || !row_global[i] || !out_policy[i]) throw Error(KMX_ERR_INVALID_ARG, "kmx_eval: null row pointer");
+      if((row_packed ? (const void*)row_packed[i] : (const void*)row_spatial[i]) == nullptr || !row_global[i] || !out_policy[i])
+        throw Error(KMX_ERR_INVALID_ARG, "kmx_eval: null row pointer");
     if(symmetry)
       for(int i = 0; i < n_rows; i++)
         if(symmetry[i] < 0 || symmetry[i] > 7) throw Error(KMX_ERR_INVALID_ARG, "kmx_eval: symmetry must be in 0..7");
-    if(n_rows < 1 || n_rows > handle->maxBatch) throw Error(KMX_ERR_INVALID_ARG, "batch size out of range for this handle");
     handle->batches++;
     if(!handle->splits(n_rows)) {
       handle->engine->setConcurrency(1);
-      handle->engine->evalHost(n_rows, row_spatial, row_global, row_meta, symmetry, policy_optimism, out_policy, out_value,
-                               out_score, out_ownership);
+      handle->engine->evalHostBegin(n_rows, row_spatial, row_packed, row_global, row_meta, symmetry, policy_optimism, out_ownership);
+      handle->engine->evalHostFinish(n_rows, out_policy, out_value, out_score, out_ownership);
       return;
     }
     const int h = n_rows - n_rows / 2, r = n_rows / 2;  // engine2 holds max_batch/2 rows
     handle->engine->setConcurrency(2);
     handle->engine2->setConcurrency(2);
-    handle->engine->evalHostBegin(h, row_spatial, row_global, row_meta, symmetry, policy_optimism, out_ownership);
-    handle->engine2->evalHostBegin(r, row_spatial + h, row_global + h, row_meta ? row_meta + h : nullptr, symmetry ? symmetry + h : nullptr,
+    handle->engine->evalHostBegin(h, row_spatial, row_packed, row_global, row_meta, symmetry, policy_optimism, out_ownership);
+    handle->engine2->evalHostBegin(r, row_spatial ? row_spatial + h : nullptr, row_packed ? row_packed + h : nullptr, row_global + h,
+                                   row_meta ? row_meta + h : nullptr, symmetry ? symmetry + h : nullptr,
                                    policy_optimism ? policy_optimism + h : nullptr, out_ownership ? out_ownership + h : nullptr);
     handle->engine->evalHostFinish(h, out_policy, out_value, out_score, out_ownership);
     handle->engine2->evalHostFinish(r, out_policy + h, out_value + (size_t)h * 3, out_score + (size_t)h * 6,
                                     out_ownership ? out_ownership + h : nullptr);
+  });
+}
+
+int kmx_eval_meta(kmx_handle* handle, int n_rows, const float* const* row_spatial, const float* const* row_global,
+                  const float* const* row_meta, const int* symmetry, const float* policy_optimism, float* const* out_policy,
+                  float* out_value, float* out_score, float* const* out_ownership) {
+  if(!row_spatial) return guarded([] { throw Error(KMX_ERR_INVALID_ARG, "kmx_eval: null argument"); });
+  return evalHostEntry(handle, n_rows, row_spatial, nullptr, row_global, row_meta, symmetry, policy_optimism, out_policy, out_value,
+                       out_score, out_ownership);
+}
+
+int kmx_eval_packed(kmx_handle* handle, int n_rows, const uint8_t* const* row_packed, const float* const* row_global,
+                    const float* const* row_meta, const int* symmetry, const float* policy_optimism, float* const* out_policy,
+                    float* out_value, float* out_score, float* const* out_ownership) {
+  if(!row_packed) return guarded([] { throw Error(KMX_ERR_INVALID_ARG, "kmx_eval_packed: null argument"); });
+  return evalHostEntry(handle, n_rows, nullptr, row_packed, row_global, row_meta, symmetry, policy_optimism, out_policy, out_value,
+                       out_score, out_ownership);
+}
+
+// packBits of the reference (dataio/trainingwrite.cpp:314-337) applied plane by plane to an NHWC row
+int kmx_pack_row(const float* row_spatial_nhwc, int nn_x_len, int nn_y_len, int num_channels, uint8_t* out_packed) {
+  return guarded([&] {
+    if(!row_spatial_nhwc || !out_packed || nn_x_len < 1 || nn_y_len < 1 || num_channels < 1)
+      throw Error(KMX_ERR_INVALID_ARG, "kmx_pack_row: bad argument");
+    const int S = nn_x_len * nn_y_len, PB = (S + 7) / 8;
+    memset(out_packed, 0, (size_t)num_channels * PB);
+    for(int p = 0; p < S; p++) {
+      const float* cell = row_spatial_nhwc + (size_t)p * num_channels;
+      const int byte = p >> 3;
+      const uint8_t bit = (uint8_t)(1u << (7 - (p & 7)));
+      for(int c = 0; c < num_channels; c++)
+        if(cell[c] != 0.0f) out_packed[(size_t)c * PB + byte] |= bit;
+    }
   });
 }
 

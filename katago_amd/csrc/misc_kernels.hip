@@ -42,18 +42,39 @@ __global__ __launch_bounds__(BT) void inputExpandKernel(const InputArgs a) {
   const int n = blockIdx.x, tid = threadIdx.x;
   const int S = a.X * a.Y;
   const int sym = a.symmetry ? a.symmetry[n] : 0;
-  const float* src = a.spatial + (size_t)n * S * a.cin;
   typename TR::T* dst = (typename TR::T*)a.out + (size_t)n * S * KCHUNK;
   float localMask = 0.0f;
-  for(int p = tid; p < S; p += BT) {
-    const int h = p / a.X, w = p - h * a.X;
-    const int q = symDst(h, w, a.Y, a.X, sym, false);
-    const float* sp = src + (size_t)p * a.cin;
-    typename TR::T* dp = dst + (size_t)q * KCHUNK;
-    for(int c = 0; c < KCHUNK; c++) dp[c] = TR::fromFloat(c < a.cin ? sp[c] : 0.0f);
-    const float m = sp[0];  // mask = input channel 0 (eigenbackend.cpp:2181)
-    a.mask[(size_t)n * S + q] = m;
-    localMask += m;
+  if(a.packed != nullptr) {
+    // bit planes: plane c, cell p = bit (7 - p%8) of byte p/8 (packBits, dataio/trainingwrite.cpp:314-337)
+    const int PB = (S + 7) / 8;
+    const unsigned char* src = a.packed + (size_t)n * a.cin * PB;
+    for(int p = tid; p < S; p += BT) {
+      const int h = p / a.X, w = p - h * a.X;
+      const int q = symDst(h, w, a.Y, a.X, sym, false);
+      typename TR::T* dp = dst + (size_t)q * KCHUNK;
+      const int byte = p >> 3, shift = 7 - (p & 7);
+      float m = 0.0f;
+      for(int c = 0; c < KCHUNK; c++) {
+        const float v = c < a.cin ? (float)((src[(size_t)c * PB + byte] >> shift) & 1) : 0.0f;
+        dp[c] = TR::fromFloat(v);
+        if(c == 0) m = v;  // mask = input channel 0 (eigenbackend.cpp:2181)
+      }
+      a.mask[(size_t)n * S + q] = m;
+      localMask += m;
+    }
+  }
+  else {
+    const float* src = a.spatial + (size_t)n * S * a.cin;
+    for(int p = tid; p < S; p += BT) {
+      const int h = p / a.X, w = p - h * a.X;
+      const int q = symDst(h, w, a.Y, a.X, sym, false);
+      const float* sp = src + (size_t)p * a.cin;
+      typename TR::T* dp = dst + (size_t)q * KCHUNK;
+      for(int c = 0; c < KCHUNK; c++) dp[c] = TR::fromFloat(c < a.cin ? sp[c] : 0.0f);
+      const float m = sp[0];  // mask = input channel 0 (eigenbackend.cpp:2181)
+      a.mask[(size_t)n * S + q] = m;
+      localMask += m;
+    }
   }
   const float ms = blockSum(localMask, red);
   if(tid == 0) a.maskSum[n] = ms;

@@ -221,6 +221,46 @@ def getOutput(handle, rowSpatial, rowGlobal, symmetries=None, policyOptimisms=No
     return {"policy": policy, "value": value, "score": score, "ownership": ownership}
 
 
+def packRows(rowSpatial, nnXLen, nnYLen):
+    """fp32 NHWC rows [n, nnY*nnX, C] of 0/1 features -> uint8 [n, C * ceil(S/8)] in the reference's binaryInputNCHWPacked
+    layout (dataio/trainingwrite.h:180-183): plane by plane, 8 cells per byte, most significant bit first."""
+    x = np.ascontiguousarray(rowSpatial, dtype=np.float32)
+    n = x.shape[0]
+    S = nnXLen * nnYLen
+    planes = np.ascontiguousarray((x.reshape(n, S, -1) != 0).transpose(0, 2, 1))  # [n, C, S]
+    return np.ascontiguousarray(np.packbits(planes, axis=2, bitorder="big")).reshape(n, -1)
+
+
+def getOutputPacked(handle, rowPacked, rowGlobal, symmetries=None, policyOptimisms=None, includeOwnerMap=True, rowMeta=None):
+    """kmx_eval_packed: getOutput on bit-packed spatial rows (packRows / kmx_pack_row)."""
+    lib = handle._lib
+    rowPacked = np.ascontiguousarray(rowPacked, dtype=np.uint8)
+    rowGlobal = np.ascontiguousarray(rowGlobal, dtype=np.float32)
+    n = rowPacked.shape[0]
+    S = handle.context.nnXLen * handle.context.nnYLen
+    assert rowPacked.reshape(n, -1).shape[1] == handle.model.info.num_input_channels * ((S + 7) // 8)
+    pk2, gl2 = rowPacked.reshape(n, -1), rowGlobal.reshape(n, -1)
+    sym = np.ascontiguousarray(symmetries if symmetries is not None else np.zeros(n), dtype=np.int32)
+    opt = np.ascontiguousarray(policyOptimisms if policyOptimisms is not None else np.zeros(n), dtype=np.float32)
+    policy = np.empty((n, S + 1), dtype=np.float32)
+    value = np.empty((n, 3), dtype=np.float32)
+    score = np.empty((n, 6), dtype=np.float32)
+    ownership = np.empty((n, S), dtype=np.float32) if includeOwnerMap else None
+    U8P = ctypes.POINTER(ctypes.c_uint8)
+    pk_ptrs = (U8P * n)(*[pk2[i].ctypes.data_as(U8P) for i in range(n)])
+    PT = _FP * n
+    gl_ptrs = PT(*[_fp(gl2[i]) for i in range(n)])
+    pol_ptrs = PT(*[_fp(policy[i]) for i in range(n)])
+    own_ptrs = PT(*[_fp(ownership[i]) for i in range(n)]) if includeOwnerMap else None
+    mt_ptrs = None
+    if rowMeta is not None:
+        mt2 = np.ascontiguousarray(rowMeta, dtype=np.float32).reshape(n, -1)
+        mt_ptrs = PT(*[_fp(mt2[i]) for i in range(n)])
+    capi.check(lib.kmx_eval_packed(handle._p, n, pk_ptrs, gl_ptrs, mt_ptrs, sym.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _fp(opt),
+                                   pol_ptrs, _fp(value), _fp(score), own_ptrs), lib)
+    return {"policy": policy, "value": value, "score": score, "ownership": ownership}
+
+
 def getOutputDevice(handle, dSpatial, dGlobal, symmetries, policyOptimisms, dPolicy, dValue, dScore, dOwnership=None, sync=True):
     """kmx_eval_device: the same pass on device-resident buffers (extension; what a device-side batcher would call).
     d* are device addresses (ints) of float32 arrays laid out like getOutput's host arrays; symmetries / optimisms are

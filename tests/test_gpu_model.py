@@ -218,3 +218,25 @@ def test_metadata_encoder_net(ctx19, model_dir, dtype):
     with pytest.raises(nn.KatamxError):
         nn.getOutput(h2, sp[:2], gl[:2], None, None, rowMeta=meta[:2])
     h2.close()
+
+
+def test_packed_input_rows_bit_exact(ctx19, model_dir):
+    """the bit-packed input entry (kmx_eval_packed; the reference's binaryInputNCHWPacked layout) gives
+    bit-identical outputs to the fp32 rows — small batch, and a 256-row batch through the two-engine path."""
+    p = os.path.join(model_dir, "packed_b3c64nbt.bin.gz")
+    if not os.path.exists(p):
+        modelgen.write_model(p, "b3c64nbt", seed=21)
+    rng = np.random.default_rng(21)
+    sizes = [(19, 19), (13, 13), (9, 9), (19, 10)] * 64
+    sp, gl = make_rows(rng, 256, 19, sizes)
+    sym = rng.integers(0, 8, 256).astype(np.int32)
+    opt = rng.random(256).astype(np.float32)
+    pk = nn.packRows(sp, 19, 19)
+    assert pk.shape == (256, 22 * 46)
+    h = nn.createComputeHandle(ctx19["bf16"], nn.loadModelFile(p), 256)
+    for n in (5, 256):
+        a = nn.getOutput(h, sp[:n], gl[:n], sym[:n], opt[:n])
+        b = nn.getOutputPacked(h, pk[:n], gl[:n], sym[:n], opt[:n])
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (n, k)
+    h.close()
