@@ -20,6 +20,7 @@ hipError_t launchVariant(int ks, int cfg, int variant, const ConvArgs& a, hipStr
   if(ks == KS_ && cfg == 10 * WNW_ + WN_ && variant == D_ * 1000 + ABL_) return launchOne<TR, KS_, WN_, WNW_, D_, ABL_>(a, st);
   V(3, 1, 1, 3, 0) V(3, 1, 1, 4, 0) V(3, 1, 1, 5, 0) V(3, 1, 2, 3, 0) V(3, 1, 2, 4, 0) V(3, 1, 3, 3, 0) V(3, 1, 3, 4, 0)
   V(1, 1, 1, 3, 0) V(1, 1, 1, 4, 0) V(1, 1, 2, 3, 0) V(1, 1, 2, 4, 0) V(3, 2, 3, 4, 0) V(3, 2, 3, 5, 0)
+  V(1, 2, 3, 3, 0) V(1, 2, 3, 3, 1) V(1, 2, 3, 3, 2) V(1, 2, 3, 3, 3) V(1, 2, 3, 3, 4) V(1, 2, 3, 3, 5) V(1, 2, 3, 3, 6) V(1, 2, 3, 3, 7) V(1, 2, 3, 3, 8) V(1, 2, 3, 3, 9) V(1, 2, 3, 3, 12) V(1, 2, 3, 3, 13)
   V(3, 1, 3, 2, 0) V(3, 2, 3, 2, 0) V(3, 2, 3, 3, 0) V(3, 2, 3, 4, 0)
   V(3, 1, 3, 2, 1) V(3, 1, 3, 2, 2) V(3, 1, 3, 2, 4) V(3, 1, 3, 2, 5) V(3, 1, 3, 2, 8) V(3, 1, 3, 2, 512) V(3, 1, 3, 2, 1024)
   V(3, 2, 3, 3, 16) V(3, 2, 3, 3, 17) V(3, 2, 3, 3, 33) V(3, 2, 3, 3, 65) V(3, 2, 3, 3, 25) V(3, 2, 3, 3, 41) V(3, 2, 3, 3, 73)

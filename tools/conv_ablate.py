@@ -10,12 +10,13 @@ from katago_amd import capi  # noqa: E402
 
 lib = capi.load_library()
 capi.check(lib.kmx_global_init(), lib)
-for depth, mode in ((3000, 0),):
-    for abl in (0, 1, 4, 5, 8, 9, 13):
+for ks, cfg, depth, cin, cout, mode in ((3, 23, 3000, 192, 192, 0), (3, 23, 3000, 192, 192, 1), (1, 23, 3000, 192, 384, 1)):
+    for abl in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 13):
         ms = ctypes.c_double()
-        rc = lib.kmx_bench_conv(3, 23, depth + abl, 192, 192, 256, 19, 19, mode, 20, ctypes.byref(ms))
+        rc = lib.kmx_bench_conv(ks, cfg, depth + abl, cin, cout, 256, 19, 19, mode, 20, ctypes.byref(ms))
         if rc != 0:
             print("abl %d: %s" % (abl, lib.kmx_last_error().decode()))
             continue
-        print("D%d mode%d abl %2d (%s%s%s%s): %7.2f us" % (depth // 1000, mode, abl, "noEpi " if abl & 1 else "", "noMFMA " if abl & 2 else "",
-                                                      "noDMA " if abl & 4 else "", ("noLdsRead " if abl & 8 else "") + ("noVmWait " if abl & 16 else "") + ("noWdma " if abl & 32 else "") + ("noAdma" if abl & 64 else ""), ms.value * 1e3), flush=True)
+        tags = [t for bit, t in ((1, "noEpi"), (2, "noMFMA"), (4, "noDMA"), (8, "noLdsRead")) if abl & bit]
+        print("ks%d cfg%d D%d %d->%d mode%d abl %2d (%s): %7.2f us" % (ks, cfg, depth // 1000, cin, cout, mode, abl, " ".join(tags), ms.value * 1e3),
+              flush=True)
