@@ -1,6 +1,7 @@
 // conv_bench.hip — instrumentation only: times single launches of the MFMA convolution, including
 // ablated variants (no epilogue / no MFMA / no DMA ...) and other pipeline depths, so that the dominant cost
 // of the kernel can be located on hardware before it is optimised. Not used by the evaluation path.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -21,6 +22,7 @@ hipError_t launchVariant(int ks, int cfg, int variant, const ConvArgs& a, hipStr
   V(3, 1, 1, 3, 0) V(3, 1, 1, 4, 0) V(3, 1, 1, 5, 0) V(3, 1, 2, 3, 0) V(3, 1, 2, 4, 0) V(3, 1, 3, 3, 0) V(3, 1, 3, 4, 0)
   V(1, 1, 1, 3, 0) V(1, 1, 1, 4, 0) V(1, 1, 2, 3, 0) V(1, 1, 2, 4, 0) V(3, 2, 3, 4, 0) V(3, 2, 3, 5, 0)
   V(1, 2, 3, 3, 0) V(1, 2, 3, 3, 1) V(1, 2, 3, 3, 2) V(1, 2, 3, 3, 3) V(1, 2, 3, 3, 4) V(1, 2, 3, 3, 5) V(1, 2, 3, 3, 6) V(1, 2, 3, 3, 7) V(1, 2, 3, 3, 8) V(1, 2, 3, 3, 9) V(1, 2, 3, 3, 12) V(1, 2, 3, 3, 13)
+  V(3, 2, 3, 3, 2048) V(3, 2, 3, 3, 2052) V(3, 2, 3, 3, 2056) V(3, 2, 3, 3, 2049) V(1, 2, 3, 3, 2048) V(3, 1, 3, 2, 2048) V(3, 1, 1, 2, 2048)
   V(3, 1, 3, 2, 0) V(3, 2, 3, 2, 0) V(3, 2, 3, 3, 0) V(3, 2, 3, 4, 0)
   V(3, 1, 3, 2, 1) V(3, 1, 3, 2, 2) V(3, 1, 3, 2, 4) V(3, 1, 3, 2, 5) V(3, 1, 3, 2, 8) V(3, 1, 3, 2, 512) V(3, 1, 3, 2, 1024)
   V(3, 2, 3, 3, 16) V(3, 2, 3, 3, 17) V(3, 2, 3, 3, 33) V(3, 2, 3, 3, 65) V(3, 2, 3, 3, 25) V(3, 2, 3, 3, 41) V(3, 2, 3, 3, 73)
@@ -79,6 +81,8 @@ double benchConv(int ks, int cfg, int variant, int cin, int cout, int batch, int
   }
   a.actOut = act.get(); a.actC = outStride; a.actBegin = 0; a.actEnd = std::min(fc.coutPad, outStride);
   a.scale = fc.scale.as<float>(); a.bias = fc.bias.as<float>(); a.actKind = KMX_ACT_MISH; a.mask = mask.as<float>();
+  DevBuf dbg(8 * 8 * sizeof(unsigned long long));
+  a.dbg = dbg.as<unsigned long long>();
   hipStream_t st = nullptr;
   auto launch = [&]() {
     hipError_t e = variant == 0 ? launchConv(dtype, ks, cfg, a, st) : launchVariant(ks, cfg, variant, a, st);
@@ -97,6 +101,16 @@ double benchConv(int ks, int cfg, int variant, int cin, int cout, int batch, int
   hipCheck(hipEventElapsedTime(&ms, e0, e1), "elapsed");
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  const int r2 = variant - 2000, r3 = variant - 3000;  // variant = D*1000 + ABL with D in {2,3} for the timing variants
+  if((r2 >= 2048 && r2 < 2304) || (r3 >= 2048 && r3 < 2304)) {  // ABL_TIMING: cycle sums of the last launch, one line per wave
+    unsigned long long h[64];
+    hipCheck(hipMemcpy(h, dbg.get(), sizeof(h), hipMemcpyDeviceToHost), "copy timing");
+    const int nw = (cfg / 10) * 4;
+    for(int w = 0; w < nw; w++)
+      fprintf(stderr, "[timing] wave %d: wait+barrier %llu | MFMA F0 + read F1 %llu | DMA issue %llu | MFMA F1 + read F0' %llu | loop %llu "
+                      "| prologue %llu | epilogue %llu | kernel %llu cycles\n",
+              w, h[w * 8 + 0], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3], h[w * 8 + 4], h[w * 8 + 5], h[w * 8 + 6], h[w * 8 + 7]);
+  }
   return (double)ms / iters;
 }
 

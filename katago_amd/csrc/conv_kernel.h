@@ -56,7 +56,8 @@ constexpr int MAXLEN = 19;
 
 // ablation switches (conv_bench.hip only; 0 in the product)
 enum { ABL_NO_EPILOGUE = 1, ABL_NO_COMPUTE = 2, ABL_NO_DMA = 4, ABL_NO_LDS_READ = 8, ABL_NO_VMWAIT = 16, ABL_NO_W_DMA = 32, ABL_NO_A_DMA = 64,
-       ABL_EPI_NOACT = 512, ABL_EPI_NOSTORE = 1024 };
+       ABL_EPI_NOACT = 512, ABL_EPI_NOSTORE = 1024,
+       ABL_TIMING = 2048 /* s_memtime stamps between the segments of a step, summed per wave into ConvArgs::dbg */ };
 
 template <int KS, int WN, int WNW, int D>
 struct Geom {
@@ -65,11 +66,18 @@ struct Geom {
   static constexpr int HALO = KS / 2;
   static constexpr int NT = KS * KS;
   static constexpr int HPMAX = (MAXLEN + 2 * HALO) * (MAXLEN + 2 * HALO);
-  static constexpr int NPA = (HPMAX * 4 + NTHREADS - 1) / NTHREADS;   // DMA instructions per wave per board image
+  // 8-wave work-groups split the DMA work by ROLE: waves 0-3 (the older wave of each SIMD, which the matrix core serves
+  // first and which otherwise idles at the barrier; tools/conv_timing.py) fetch the weight slabs, waves 4-7 the board image.
+  // No dummy requests, per-role s_waitcnt constants, and a weight wave never waits behind an HBM-latency image piece.
+  // 4-wave work-groups: every wave does both, padded with dummies to a constant per-step count.
+  static constexpr bool ROLES = WNW == 2;
+  static constexpr int NLW = ROLES ? 4 : NWAVES;  // waves that fetch weights
+  static constexpr int NLA = ROLES ? 4 : NWAVES;  // waves that fetch the image
+  static constexpr int NPA = (HPMAX * 4 + NLA * 64 - 1) / (NLA * 64);   // DMA instructions per image-loading wave per board image
   static constexpr int ACT_BYTES = (HPMAX * ROWB + 1023) / 1024 * 1024;  // instructions wholly past it go to the slack
   static constexpr int NTILE = 32 * WN * WNW;
   static constexpr int WPIECES = NTILE * 4;
-  static constexpr int NPW = (WPIECES + NTHREADS - 1) / NTHREADS;
+  static constexpr int NPW = (WPIECES + NLW * 64 - 1) / (NLW * 64);  // DMA instructions per weight-loading wave per slab
   static constexpr int W_BYTES = (WPIECES * 16 + 1023) / 1024 * 1024;
   static_assert(D >= 2, "the slab of step s+1 is published at the top of step s: at least two steps of requests in flight");
   // 3x3/5x5: the next chunk's image arrives PPS pieces per step during the first LS steps of the current chunk
@@ -77,7 +85,7 @@ struct Geom {
   static constexpr bool SPREAD = NT > 1;
   static constexpr int pickPPS() {
     for(int p = 1; p <= NPA; p++)
-      if((NPA + p - 1) / p + D <= NT) return p;
+      if((NPA + p - 1) / p + (ROLES ? 1 : D) <= NT) return p;  // ROLES: complete before the last step of the chunk
     return NPA;
   }
   static constexpr int PPS = SPREAD ? pickPPS() : NPA;
@@ -96,6 +104,9 @@ struct Geom {
   static constexpr int VMCNT = SPREAD ? PPS + (D - 2) * (NPW + PPS) : (D - 2) * (NPW + NPA);
   // before the loop: slab 0 and image 0
   static constexpr int VMCNT_PRO = SPREAD ? PPS + (D - 1) * (NPW + PPS) : (D - 1) * (NPW + NPA);
+  // ROLES: a weight wave has only slabs in flight, an image wave only image pieces
+  static constexpr int VMCNT_W = (D - 2) * NPW, VMCNT_PRO_W = (D - 1) * NPW;
+  static constexpr int VMCNT_A1 = (D - 2) * NPA, VMCNT_PRO_A1 = (D - 1) * NPA;  // 1x1: whole images ride the ring
 };
 
 template <int N>
@@ -116,6 +127,7 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   constexpr int HALO = G::HALO, NT = G::NT, NPA = G::NPA, NPW = G::NPW, NWAVES = G::NWAVES;
   constexpr bool SPREAD = G::SPREAD;
 
+  const unsigned long long tKernel0 = (ABL & ABL_TIMING) ? __builtin_readcyclecounter() : 0;  // work-group start
   extern __shared__ __attribute__((aligned(256))) char smem[];
   char* const bufA = smem;
   char* const bufW = smem + G::NSA * G::ACT_BYTES;
@@ -161,20 +173,25 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   // LDS piece p = row p/4, PHYSICAL slot p%4; it holds logical slot (p%4) ^ ((row>>2)&3) of that row. The pointers
   // advance by one 32-channel chunk (64 bytes) each time they are used, so the main loop spends no vector ALU
   // work on DMA addresses (vector ALU instructions compete with the MFMAs for the issue slot).
-  const char* srcPtr[NPA];
+  constexpr bool ROLES = G::ROLES;
+  const bool wLoader = !ROLES || wave < 4;        // wave-uniform
+  const bool aLoader = !ROLES || wave >= 4;
+  const int lw = wave;                            // index among the weight-loading waves
+  const int la = ROLES ? (wave & 3) : wave;       // index among the image-loading waves
+  unsigned srcOff[NPA];  // byte offset from this board's tensor, or (bit 31 set) into the zero page; +64 per chunk
 #pragma unroll
   for(int j = 0; j < NPA; j++) {
-    int p = (j * NWAVES + wave) * 64 + lane;
+    int p = (j * G::NLA + la) * 64 + lane;
     int hp = p >> 2;
     int slot = (p & 3) ^ ((hp >> 2) & 3);
-    const char* ptr = zero;
+    unsigned off = 0x80000000u;
     if(hp < HP) {
       int hy = hp / W2;
       int hx = hp - hy * W2;
       int y = hy - HALO, x = hx - HALO;
-      if(y >= 0 && y < Y && x >= 0 && x < X) ptr = inBoard + ((size_t)(y * X + x) * inC + slot * 8) * sizeof(T);
+      if(y >= 0 && y < Y && x >= 0 && x < X) off = (unsigned)(((y * X + x) * inC + slot * 8) * (int)sizeof(T));
     }
-    srcPtr[j] = ptr;
+    srcOff[j] = off;
   }
   const char* const wBase = (const char*)a.w + (size_t)cout0 * ROWB;
   const size_t wSlabStride = (size_t)a.coutPad * ROWB;
@@ -183,7 +200,7 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   unsigned wOff[NPW];  // per-lane byte offset inside a weight slab; the slab address itself is wave-uniform (SGPR base)
 #pragma unroll
   for(int j = 0; j < NPW; j++) {
-    const int p = (j * NWAVES + wave) * 64 + lane;
+    const int p = (j * G::NLW + (lw % G::NLW)) * 64 + lane;
     wOff[j] = (unsigned)(p < G::WPIECES ? p : lane) * 16u;
   }
 
@@ -195,7 +212,7 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
     char* dst = bufW + (step % G::NSW) * G::W_BYTES;
 #pragma unroll
     for(int j = 0; j < NPW; j++) {
-      const int pbase = (j * NWAVES + wave) * 64;
+      const int pbase = (j * G::NLW + (lw % G::NLW)) * 64;
       const bool inRange = live && pbase < G::WPIECES;
       dma16(slab + wOff[j], inRange ? dst + pbase * 16 : mySlack);
     }
@@ -205,10 +222,12 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   auto issueA = [&](int chunk, int j) {
     if(ABL & (ABL_NO_DMA | ABL_NO_A_DMA)) return;
     const int jj = j < 0 ? 0 : j;
-    const int pbase = (jj * NWAVES + wave) * 64;
+    const int pbase = (jj * G::NLA + la) * 64;
     const bool live = j >= 0 && chunk < nChunks && pbase * 16 < G::ACT_BYTES;
-    dma16(srcPtr[jj], live ? bufA + (chunk % G::NSA) * G::ACT_BYTES + pbase * 16 : mySlack);
-    if(j >= 0) srcPtr[jj] += KCHUNK * sizeof(T);
+    const unsigned off = srcOff[jj];
+    const char* src = (off & 0x80000000u) ? zero + (off & 0x7fffffffu) : inBoard + off;
+    dma16(src, live ? bufA + (chunk % G::NSA) * G::ACT_BYTES + pbase * 16 : mySlack);
+    if(j >= 0) srcOff[jj] = off + KCHUNK * sizeof(T);
   };
 
   // ---- per-lane LDS read addressing (32-bit LDS byte addresses; kept to 3-4 vector ALU operations per fragment) ----
@@ -294,7 +313,23 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
                                      (__attribute__((address_space(3))) void*)(smem + G::MASK_OFFSET + (j * NWAVES + wave) * 256), 4, 0, 0);
   }
   // ---- prologue, part 2: fill the pipeline with the same per-step instruction pattern the loop uses ----
-  if(SPREAD) {
+  if(ROLES) {
+    if(wLoader) {
+#pragma unroll
+      for(int s = 0; s < D; s++) issueW(s);
+    }
+    else if(SPREAD) {
+#pragma unroll
+      for(int j = 0; j < NPA; j++) issueA(0, j);
+    }
+    else {
+#pragma unroll
+      for(int s = 0; s < D; s++)
+#pragma unroll
+        for(int j = 0; j < NPA; j++) issueA(s, j);
+    }
+  }
+  else if(SPREAD) {
 #pragma unroll
     for(int j = 0; j < NPA; j++) issueA(0, j);
 #pragma unroll
@@ -356,6 +391,22 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   // so every LDS read has eight MFMAs (256 matrix-core cycles) to land in, and the matrix core only idles for the
   // barrier skew between waves.
   auto issueStep = [&](int chunk, int t, int step) {
+    if(ROLES) {
+      if(wLoader) issueW(step + D);
+      else if(SPREAD) {
+        // real pieces only; nothing after the image is complete (this wave waits with vmcnt(0) once per chunk)
+        if(t * G::PPS < NPA && chunk + 1 < nChunks) {
+#pragma unroll
+          for(int i = 0; i < G::PPS; i++)
+            if(t * G::PPS + i < NPA) issueA(chunk + 1, t * G::PPS + i);
+        }
+      }
+      else {
+#pragma unroll
+        for(int j = 0; j < NPA; j++) issueA(chunk + D, j);
+      }
+      return;
+    }
     issueW(step + D);
     if(SPREAD) {
 #pragma unroll
@@ -366,21 +417,45 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
       for(int j = 0; j < NPA; j++) issueA(chunk + D, j);
     }
   };
-  if(!(ABL & (ABL_NO_DMA | ABL_NO_W_DMA | ABL_NO_A_DMA))) waitVm<G::VMCNT_PRO>();
+  // top-of-step wait of this wave's own requests: everything the barrier is about to publish
+  auto waitStep = [&](int t) {
+    if(ABL & (ABL_NO_DMA | ABL_NO_VMWAIT | ABL_NO_W_DMA | ABL_NO_A_DMA)) return;
+    if(!ROLES) waitVm<G::VMCNT>();
+    else if(wLoader) waitVm<G::VMCNT_W>();
+    else if(!SPREAD) waitVm<G::VMCNT_A1>();
+    else if(t == NT - 1) waitVm<0>();  // the next chunk's image, first read at the end of this step
+  };
+  if(ABL & (ABL_NO_DMA | ABL_NO_W_DMA | ABL_NO_A_DMA)) waitVm<0>();
+  else if(!ROLES) waitVm<G::VMCNT_PRO>();
+  else if(wLoader) waitVm<G::VMCNT_PRO_W>();
+  else if(!SPREAD) waitVm<G::VMCNT_PRO_A1>();
   else waitVm<0>();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   readW(0, 0);
   readA0(0, 0);
+  // ABL_TIMING: cycles per segment of a step, summed over the steps (segments: wait+barrier | first MFMA + read F1 + MFMA F0
+  // issue | DMA issue | first MFMA + read F0' + MFMA F1 issue); seg[4] = whole loop, seg[5..7] = prologue / loop end / kernel end
+  unsigned long long seg[5] = {0, 0, 0, 0, 0};
+  unsigned long long tPrev = 0;
+  auto stamp = [&](int which) {
+    if(!(ABL & ABL_TIMING)) return;
+    const unsigned long long now = __builtin_readcyclecounter();
+    seg[which] += now - tPrev;
+    tPrev = now;
+  };
+  if(ABL & ABL_TIMING) tPrev = __builtin_readcyclecounter();
+  const unsigned long long tLoop0 = tPrev;
   int step = 0;
   for(int chunk = 0; chunk < nChunks; chunk++) {
     const unsigned curA = (unsigned)(chunk % G::NSA) * G::ACT_BYTES;
     const unsigned nextA = (unsigned)((chunk + 1) % G::NSA) * G::ACT_BYTES;
 #pragma unroll
     for(int t = 0; t < NT; t++, step++) {
-      if(!(ABL & (ABL_NO_DMA | ABL_NO_VMWAIT | ABL_NO_W_DMA | ABL_NO_A_DMA))) waitVm<G::VMCNT>();
+      waitStep(t);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      stamp(0);
       // The compiler's own s_waitcnt before an MFMA drains ALL outstanding LDS reads (lgkmcnt(0)), so each batch of
       // reads is issued right AFTER the first MFMA of the other fragment set: the wait it causes then only covers
       // reads that had eight MFMAs to land.
@@ -391,8 +466,10 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
       __builtin_amdgcn_sched_barrier(0);
       mfmaPart(0, 1, WN * MT, acc);
       __builtin_amdgcn_sched_barrier(0);
-      issueStep(chunk, t, step);
+      stamp(1);
+      issueStep(chunk, t, step);  // (placing the image waves' requests at the start of the step instead measured 1-2 % slower)
       __builtin_amdgcn_sched_barrier(0);
+      stamp(2);
       mfmaPart(1, 0, 1, acc);
       __builtin_amdgcn_sched_barrier(0);
       readW(0, step + 1);
@@ -400,9 +477,11 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
       __builtin_amdgcn_sched_barrier(0);
       mfmaPart(1, 1, WN * MT, acc);
       __builtin_amdgcn_sched_barrier(0);
+      stamp(3);
     }
   }
   if(!(ABL & ABL_NO_DMA)) waitVm<0>();  // retire the trailing dummies before the LDS is reused / the wave exits
+  const unsigned long long tLoop1 = (ABL & ABL_TIMING) ? __builtin_readcyclecounter() : 0;
 
   // ---- epilogue ----
   const float* const maskBoard = (const float*)(smem + G::MASK_OFFSET);
@@ -504,6 +583,16 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
     // keep the staged values observable so the compiler cannot drop the accumulators
     if(stage[lane] == 12345.678f) ((float*)a.actOut)[lane] = stage[lane + 1];
   }
+  if((ABL & ABL_TIMING) && a.dbg != nullptr && lane == 0 && blockIdx.x == 0 && (int)blockIdx.y == a.N / 2) {
+    // one record of 8 counters per wave of the middle board's first work-group
+    unsigned long long* rec = a.dbg + wave * 8;
+    const unsigned long long tEnd = __builtin_readcyclecounter();
+    for(int i = 0; i < 4; i++) rec[i] = seg[i];
+    rec[4] = tLoop1 - tLoop0;
+    rec[5] = tLoop0 - tKernel0;
+    rec[6] = tEnd - tLoop1;
+    rec[7] = tEnd - tKernel0;
+  }
 }
 
 template <class TR, int KS, int WN, int WNW, int D, int ABL>
@@ -511,7 +600,7 @@ hipError_t launchOne(const ConvArgs& a, hipStream_t stream) {
   typedef Geom<KS, WN, WNW, D> G;
   constexpr int ldsBytes = G::LDS_BYTES;
   static_assert(ldsBytes <= 160 * 1024, "LDS budget exceeded");
-  static_assert(!G::SPREAD || G::LS + D <= G::NT, "image pieces must land within their chunk");
+  static_assert(!G::SPREAD || G::LS + (G::ROLES ? 1 : D) <= G::NT, "image pieces must land within their chunk");
   static_assert(G::STAGE_BYTES <= G::MASK_OFFSET, "epilogue staging overlaps the mask tile");
   auto kern = convMfmaKernel<TR, KS, WN, WNW, D, ABL>;
   static bool attrSet = false;  // per instantiation; idempotent

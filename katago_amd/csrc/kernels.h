@@ -48,6 +48,7 @@ struct ConvArgs {
   const float* bias;
   int actKind;
   const float* mask;  // [N][S]
+  unsigned long long* dbg;  // instrumentation only (ABL_TIMING variants of conv_bench.hip): per-segment cycle sums
 };
 
 // KS in {1,3,5}; cfg = 10*WNW + WN (WNW waves along channels: 1 = 4-wave, 2 = 8-wave work-group; WN = 32-channel
