@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define KMX_ABI_VERSION 1
+/* 2: + kmx_eval_meta / kmx_eval_device_meta (sgf-metadata nets), kmx_eval_packed / kmx_pack_row (bit-packed inputs),
+ *    kmx_handle_set_split_min; kmx_model_info.reserved0 became meta_encoder_version. Additive over 1. */
+#define KMX_ABI_VERSION 2
 
 typedef enum kmx_status {
   KMX_OK = 0,

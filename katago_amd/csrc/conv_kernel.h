@@ -45,6 +45,8 @@
 #ifndef KMX_CONV_KERNEL_H_
 #define KMX_CONV_KERNEL_H_
 
+#include <atomic>
+
 #include "device_common.h"
 
 namespace kmx {
@@ -603,11 +605,11 @@ hipError_t launchOne(const ConvArgs& a, hipStream_t stream) {
   static_assert(!G::SPREAD || G::LS + (G::ROLES ? 1 : D) <= G::NT, "image pieces must land within their chunk");
   static_assert(G::STAGE_BYTES <= G::MASK_OFFSET, "epilogue staging overlaps the mask tile");
   auto kern = convMfmaKernel<TR, KS, WN, WNW, D, ABL>;
-  static bool attrSet = false;  // per instantiation; idempotent
-  if(!attrSet) {
+  static std::atomic<bool> attrSet{false};  // per instantiation; the call is idempotent, so a race between two handles' first launches is harmless
+  if(!attrSet.load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes);
     if(e != hipSuccess) return e;
-    attrSet = true;
+    attrSet.store(true, std::memory_order_release);
   }
   if(a.coutPad % G::NTILE != 0) return hipErrorInvalidValue;
   dim3 grid(a.coutPad / G::NTILE, a.N, 1);
