@@ -54,7 +54,13 @@ typedef struct {
   float* w;
 } OMatBias;
 
-enum { BLK_ORDINARY = 0, BLK_GPOOL = 2, BLK_NESTED = 3 }; /* desc.h:374-378 numbering */
+enum { BLK_ORDINARY = 0, BLK_GPOOL = 2, BLK_NESTED = 3, BLK_ATTENTION = 4, BLK_FFN = 5 }; /* desc.h:374-379 numbering */
+
+typedef struct { /* TransformerRMSNormDesc (desc.h:259-276): weight only */
+  int c;
+  float eps;
+  float* w;
+} OTRms;
 
 typedef struct OBlock {
   int kind;
@@ -67,6 +73,15 @@ typedef struct OBlock {
   OMatMul gpoolToBiasMul;
   int numBlocks;
   struct OBlock* blocks;
+  /* transformer_attention_block (TransformerAttentionDesc, desc.h:278-321): preLN qProj kProj vProj outProj [rope]
+   * transformer_ffn_block (TransformerFFNDesc, desc.h:323-346):             preLN linear1 [linearGate] linear2 */
+  OTRms preLN;
+  int numHeads, numKVHeads, qHeadDim, vHeadDim, useRope, learnableRope;
+  float ropeTheta;
+  float* ropeFreqs; /* learnable: [numKVHeads][qHeadDim/2][2] */
+  OMatMul qProj, kProj, vProj, outProj;
+  int ffnChannels, useSwiGLU;
+  OMatMul linear1, linearGate, linear2;
 } OBlock;
 
 struct okmx_model {
@@ -82,6 +97,11 @@ struct okmx_model {
   int metaAct1, metaAct2;
   OBlock* blocks;
   OBn trunkTipBN;
+  /* trunkNormKind != 0: RMSNormLayerDesc tip (desc.h:238-257) + activation instead of the batch norm */
+  int trunkNormKind, trunkTipAct, rmsSpatial;
+  float rmsEps;
+  float* rmsGamma;
+  float* rmsBeta;
   /* policy head (desc.cpp:2084-2104) */
   OConv p1Conv, g1Conv, p2Conv;
   OBn g1BN, p1BN;
@@ -237,6 +257,16 @@ static void parse_matbias(Rd* r, OMatBias* m) { /* MatBiasLayerDesc, desc.cpp:51
 
 static void parse_block_stack(Rd* r, int version, int numBlocks, int trunkC, OBlock* blocks);
 
+static void parse_trms(Rd* r, OTRms* t) { /* TransformerRMSNormDesc, desc.cpp:1125-1144 */
+  char name[160];
+  rd_token(r, name, sizeof(name));
+  t->c = rd_int(r, "numChannels");
+  t->eps = rd_float(r, "epsilon");
+  if(r->err) return;
+  if(t->c < 1 || !(t->eps > 0) || t->eps > 1.0f) { rd_fail(r, "%s: bad transformer rmsnorm header", name); return; }
+  t->w = rd_floats(r, t->c, name);
+}
+
 static void parse_block(Rd* r, int version, OBlock* b, int trunkC) { /* desc.cpp:1444-1562 */
   char kind[160];
   rd_token(r, kind, sizeof(kind));
@@ -293,8 +323,56 @@ static void parse_block(Rd* r, int version, OBlock* b, int trunkC) { /* desc.cpp
     if(b->preBN.c != b->regularConv.ic || b->midBN.c != b->regularConv.oc || b->midBN.c != b->finalConv.ic ||
        b->preBN.c != trunkC || b->finalConv.oc != trunkC)
       rd_fail(r, "%s: nested block channel mismatch", b->name);
-  } else if(!strcmp(kind, "transformer_attention_block") || !strcmp(kind, "transformer_ffn_block")) {
-    rd_fail(r, "transformer blocks (model version 17 attention nets) are not supported by this backend");
+  } else if(!strcmp(kind, "transformer_attention_block")) { /* TransformerAttentionDesc, desc.cpp:1173-1258 */
+    b->kind = BLK_ATTENTION;
+    rd_token(r, b->name, sizeof(b->name));
+    b->numHeads = rd_int(r, "numHeads");
+    b->numKVHeads = rd_int(r, "numKVHeads");
+    b->qHeadDim = rd_int(r, "qHeadDim");
+    b->vHeadDim = rd_int(r, "vHeadDim");
+    b->useRope = rd_int(r, "useRope") != 0;
+    b->learnableRope = rd_int(r, "learnableRope") != 0;
+    if(r->err) return;
+    if(b->numHeads < 1 || b->numKVHeads < 1 || b->numHeads % b->numKVHeads != 0 || b->qHeadDim < 1 || b->vHeadDim < 1 ||
+       (b->useRope && b->qHeadDim % 2 != 0)) { rd_fail(r, "%s: bad attention header", b->name); return; }
+    parse_trms(r, &b->preLN);
+    parse_matmul(r, &b->qProj);
+    parse_matmul(r, &b->kProj);
+    parse_matmul(r, &b->vProj);
+    parse_matmul(r, &b->outProj);
+    if(r->err) return;
+    if(b->qProj.oc != b->numHeads * b->qHeadDim || b->kProj.oc != b->numKVHeads * b->qHeadDim ||
+       b->vProj.oc != b->numKVHeads * b->vHeadDim || b->outProj.ic != b->numHeads * b->vHeadDim || b->qProj.ic != trunkC ||
+       b->outProj.oc != trunkC || b->preLN.c != trunkC) { rd_fail(r, "%s: attention channel mismatch", b->name); return; }
+    if(b->useRope) {
+      char t[160];
+      rd_token(r, t, sizeof(t)); /* rope freqs / theta name */
+      if(b->learnableRope) {
+        int kvh = rd_int(r, "ropeNumKVHeads"), np = rd_int(r, "ropeNumPairs"), d2 = rd_int(r, "ropeDim2");
+        if(r->err) return;
+        if(kvh != b->numKVHeads || np != b->qHeadDim / 2 || d2 != 2) { rd_fail(r, "%s: bad learnable rope header", b->name); return; }
+        b->ropeFreqs = rd_floats(r, (size_t)kvh * np * 2, b->name);
+      } else {
+        b->ropeTheta = rd_float(r, "ropeTheta");
+        if(!r->err && !(b->ropeTheta > 0.0f)) rd_fail(r, "%s: rope theta must be positive", b->name);
+      }
+    }
+  } else if(!strcmp(kind, "transformer_ffn_block")) { /* TransformerFFNDesc, desc.cpp:1371-1405 */
+    b->kind = BLK_FFN;
+    rd_token(r, b->name, sizeof(b->name));
+    int nc = rd_int(r, "numChannels");
+    b->ffnChannels = rd_int(r, "ffnChannels");
+    b->useSwiGLU = rd_int(r, "useSwiGLU") != 0;
+    if(r->err) return;
+    parse_trms(r, &b->preLN);
+    parse_matmul(r, &b->linear1);
+    if(b->useSwiGLU) parse_matmul(r, &b->linearGate);
+    parse_matmul(r, &b->linear2);
+    if(r->err) return;
+    if(nc != trunkC || b->preLN.c != trunkC || b->linear1.ic != nc || b->linear1.oc != b->ffnChannels ||
+       (b->useSwiGLU && (b->linearGate.ic != nc || b->linearGate.oc != b->ffnChannels)) || b->linear2.ic != b->ffnChannels ||
+       b->linear2.oc != nc) { rd_fail(r, "%s: ffn channel mismatch", b->name); return; }
+    if(!b->useSwiGLU) rd_fail(r, "%s: non-SwiGLU transformer FFN is not supported (as in the reference's Eigen backend, eigenbackend.cpp:1631-1633)", b->name);
   } else {
     rd_fail(r, "found unknown block kind: %s", kind);
   }
@@ -311,6 +389,9 @@ static void free_block(OBlock* b) {
   free(b->gpoolToBiasMul.w);
   for(int i = 0; i < b->numBlocks; i++) free_block(&b->blocks[i]);
   free(b->blocks);
+  free(b->preLN.w); free(b->ropeFreqs);
+  free(b->qProj.w); free(b->kProj.w); free(b->vProj.w); free(b->outProj.w);
+  free(b->linear1.w); free(b->linearGate.w); free(b->linear2.w);
 }
 void okmx_model_free(okmx_model* m) {
   if(!m) return;
@@ -320,6 +401,7 @@ void okmx_model_free(okmx_model* m) {
   for(int i = 0; i < m->numBlocks && m->blocks; i++) free_block(&m->blocks[i]);
   free(m->blocks);
   free_bn(&m->trunkTipBN);
+  free(m->rmsGamma); free(m->rmsBeta);
   free_conv(&m->p1Conv); free_conv(&m->g1Conv); free_conv(&m->p2Conv);
   free_bn(&m->g1BN); free_bn(&m->p1BN);
   free(m->gpoolToBiasMul.w); free(m->gpoolToPassMul.w); free(m->gpoolToPassMul2.w); free(m->gpoolToPassBias.w);
@@ -333,6 +415,16 @@ void okmx_model_free(okmx_model* m) {
 static double conv_mac(const OConv* c) { return (double)c->ky * c->kx * c->ic * c->oc; }
 static int64_t conv_params(const OConv* c) { return (int64_t)c->ky * c->kx * c->ic * c->oc; }
 static void block_counts(const OBlock* b, double* mac, int64_t* params) {
+  if(b->kind == BLK_ATTENTION || b->kind == BLK_FFN) {
+    /* projections only: the QK^T / PV products cost area*numHeads*(qHeadDim+vHeadDim) MACs per point on top, which
+       depends on the board and is left out of this per-point figure */
+    const OMatMul* mm[7] = {&b->qProj, &b->kProj, &b->vProj, &b->outProj, &b->linear1, &b->linearGate, &b->linear2};
+    for(int i = 0; i < 7; i++)
+      if(mm[i]->w) { *mac += (double)mm[i]->ic * mm[i]->oc; *params += (int64_t)mm[i]->ic * mm[i]->oc; }
+    *params += b->preLN.c;
+    if(b->kind == BLK_ATTENTION && b->learnableRope) *params += (int64_t)b->numKVHeads * (b->qHeadDim / 2) * 2;
+    return;
+  }
   *mac += conv_mac(&b->regularConv) + conv_mac(&b->finalConv);
   *params += conv_params(&b->regularConv) + conv_params(&b->finalConv) + 2 * b->preBN.c + 2 * b->midBN.c;
   if(b->kind == BLK_GPOOL) {
@@ -422,7 +514,8 @@ static int parse_model(Rd* r, okmx_model* m) {
     int trunkNormKind = rd_int(r, "trunkNormKind");
     for(int i = 0; i < 5; i++)
       if(rd_int(r, "unused trunk option") != 0) rd_fail(r, "unknown/unsupported trunk option");
-    if(!r->err && trunkNormKind != 0) rd_fail(r, "RMSNorm trunk tip is not supported");
+    if(!r->err && (trunkNormKind < 0 || trunkNormKind > 3)) rd_fail(r, "unknown trunkNormKind");
+    m->trunkNormKind = trunkNormKind;
   }
   if(r->err) return 0;
   if(m->numBlocks < 1 || m->C < 1) { rd_fail(r, "bad trunk header"); return 0; }
@@ -446,8 +539,21 @@ static int parse_model(Rd* r, okmx_model* m) {
   }
   m->blocks = (OBlock*)calloc(m->numBlocks, sizeof(OBlock));
   parse_block_stack(r, m->version, m->numBlocks, m->C, m->blocks);
-  parse_bn(r, &m->trunkTipBN);
-  m->trunkTipBN.act = parse_act(r, m->version);
+  if(m->trunkNormKind == 0) {
+    parse_bn(r, &m->trunkTipBN);
+    m->trunkTipBN.act = parse_act(r, m->version);
+  } else { /* RMSNormLayerDesc, desc.cpp:1069-1095 */
+    rd_token(r, tok, sizeof(tok));
+    int c = rd_int(r, "numChannels");
+    m->rmsEps = rd_float(r, "epsilon");
+    m->rmsSpatial = rd_int(r, "spatial") != 0;
+    int cgroup = rd_int(r, "cgroupSize");
+    if(r->err) return 0;
+    if(c != m->C || !(m->rmsEps > 0) || m->rmsEps > 1.0f || cgroup != 0) { rd_fail(r, "bad or unsupported trunk tip rmsnorm"); return 0; }
+    m->rmsGamma = rd_floats(r, c, "trunk tip rmsnorm gamma");
+    m->rmsBeta = rd_floats(r, c, "trunk tip rmsnorm beta");
+    m->trunkTipAct = parse_act(r, m->version);
+  }
   if(r->err) return 0;
 
   /* policy head */
@@ -671,6 +777,196 @@ static void pool_value(int n, int S, int C, const float* in, float* out, const f
 
 static float* falloc(size_t n) { return (float*)malloc(sizeof(float) * (n ? n : 1)); }
 
+
+/* TransformerRMSNormLayer::apply (eigenbackend.cpp:885-915): per cell over channels, weight only, masked cells -> 0 */
+static void trms_apply(const OTRms* t, int n, int S, const float* in, float* out, const float* mask) {
+  const int C = t->c;
+#pragma omp parallel for schedule(static)
+  for(int p = 0; p < n * S; p++) {
+    const float* ip = in + (size_t)p * C;
+    float* op = out + (size_t)p * C;
+    if(mask[p] == 0.0f) { for(int c = 0; c < C; c++) op[c] = 0.0f; continue; }
+    float sumSq = 0.0f;
+    for(int c = 0; c < C; c++) sumSq += ip[c] * ip[c];
+    const float rms = 1.0f / sqrtf(sumSq / (float)C + t->eps);
+    for(int c = 0; c < C; c++) op[c] = ip[c] * rms * t->w[c];
+  }
+}
+/* matmul over all cells: out[p][oc] = sum_ic in[p][ic] W[ic][oc]  (MatMulLayer on the (C, seqLen*N) view) */
+static void matmul_cells(const OMatMul* m, size_t cells, const float* in, float* out) {
+#pragma omp parallel for schedule(static)
+  for(long p = 0; p < (long)cells; p++) {
+    const float* ip = in + (size_t)p * m->ic;
+    float* op = out + (size_t)p * m->oc;
+    for(int o = 0; o < m->oc; o++) op[o] = 0.0f;
+    for(int i = 0; i < m->ic; i++) {
+      const float v = ip[i];
+      const float* wr = m->w + (size_t)i * m->oc;
+      for(int o = 0; o < m->oc; o++) op[o] += v * wr[o];
+    }
+  }
+}
+/* TransformerAttentionDesc::computeRopeCosSin (desc.cpp:1300-1363) with paddedNNXYLen = X*Y */
+static void rope_tables(const OBlock* b, int X, int Y, float* cosT, float* sinT) {
+  const int S = X * Y, numPairs = b->qHeadDim / 2;
+  if(b->learnableRope) {
+    for(int h = 0; h < b->numKVHeads; h++)
+      for(int p = 0; p < numPairs; p++) {
+        const float fx = b->ropeFreqs[(h * numPairs + p) * 2 + 0], fy = b->ropeFreqs[(h * numPairs + p) * 2 + 1];
+        for(int y = 0; y < Y; y++)
+          for(int x = 0; x < X; x++) {
+            const float angle = (float)x * fx + (float)y * fy;
+            cosT[(h * numPairs + p) * S + y * X + x] = cosf(angle);
+            sinT[(h * numPairs + p) * S + y * X + x] = sinf(angle);
+          }
+      }
+  } else {
+    const int perDim = numPairs / 2, dimHalf = b->qHeadDim / 2;
+    for(int p = 0; p < numPairs; p++)
+      for(int y = 0; y < Y; y++)
+        for(int x = 0; x < X; x++) {
+          float angle;
+          if(p < perDim) angle = (float)y * (1.0f / powf(b->ropeTheta, (float)(2 * p) / (float)dimHalf));
+          else angle = (float)x * (1.0f / powf(b->ropeTheta, (float)(2 * (p - perDim)) / (float)dimHalf));
+          cosT[p * S + y * X + x] = cosf(angle);
+          sinT[p * S + y * X + x] = sinf(angle);
+        }
+  }
+}
+/* applyRoPE (eigenbackend.cpp:1417-1456): rotate channel pairs (2p, 2p+1) of every head */
+static void rope_apply(const OBlock* b, int n, int S, float* data, int numBufHeads, const float* cosT, const float* sinT) {
+  const int numPairs = b->qHeadDim / 2, D = numBufHeads * b->qHeadDim;
+#pragma omp parallel for schedule(static)
+  for(int cell = 0; cell < n * S; cell++) {
+    const int xy = cell % S;
+    float* row = data + (size_t)cell * D;
+    for(int h = 0; h < numBufHeads; h++)
+      for(int p = 0; p < numPairs; p++) {
+        const int t = b->learnableRope ? ((h * b->numKVHeads / numBufHeads) * numPairs + p) * S + xy : p * S + xy;
+        const float c = cosT[t], sn = sinT[t];
+        float* v = row + h * b->qHeadDim + 2 * p;
+        const float x0 = v[0], x1 = v[1];
+        v[0] = x0 * c - x1 * sn;
+        v[1] = x0 * sn + x1 * c;
+      }
+  }
+}
+/* TransformerAttentionBlock::apply (eigenbackend.cpp:1376-1600) */
+static void attention_apply(const OBlock* b, int n, int X, int Y, float* trunk, const float* mask) {
+  const int S = X * Y, C = b->qProj.ic, H = b->numHeads, KVH = b->numKVHeads, QD = b->qHeadDim, VD = b->vHeadDim;
+  const size_t NS = (size_t)n * S;
+  float* ln = falloc(NS * C);
+  float* q = falloc(NS * H * QD);
+  float* k = falloc(NS * KVH * QD);
+  float* v = falloc(NS * KVH * VD);
+  float* att = falloc(NS * H * VD);
+  trms_apply(&b->preLN, n, S, trunk, ln, mask);
+  matmul_cells(&b->qProj, NS, ln, q);
+  matmul_cells(&b->kProj, NS, ln, k);
+  matmul_cells(&b->vProj, NS, ln, v);
+  if(b->useRope) {
+    const int numPairs = QD / 2;
+    const size_t tsz = (size_t)(b->learnableRope ? KVH : 1) * numPairs * S;
+    float* cosT = falloc(tsz);
+    float* sinT = falloc(tsz);
+    rope_tables(b, X, Y, cosT, sinT);
+    rope_apply(b, n, S, q, H, cosT, sinT);
+    rope_apply(b, n, S, k, KVH, cosT, sinT);
+    free(cosT); free(sinT);
+  }
+  const float scale = 1.0f / sqrtf((float)QD);
+  const int group = H / KVH;
+#pragma omp parallel for schedule(dynamic) collapse(2)
+  for(int bi = 0; bi < n; bi++)
+    for(int h = 0; h < H; h++) {
+      const int kvh = h / group;
+      const float* maskN = mask + (size_t)bi * S;
+      float* scores = (float*)malloc(sizeof(float) * S);
+      for(int qi = 0; qi < S; qi++) {
+        float* out = att + ((size_t)bi * S + qi) * H * VD + h * VD;
+        for(int d = 0; d < VD; d++) out[d] = 0.0f;
+        if(maskN[qi] == 0.0f) continue; /* masked queries contribute nothing (eigenbackend.cpp:1503-1508) */
+        const float* qv = q + ((size_t)bi * S + qi) * H * QD + h * QD;
+        float maxVal = -1e30f;
+        for(int ki = 0; ki < S; ki++) {
+          if(maskN[ki] == 0.0f) continue;
+          const float* kv = k + ((size_t)bi * S + ki) * KVH * QD + kvh * QD;
+          float s = 0.0f;
+          for(int d = 0; d < QD; d++) s += qv[d] * kv[d];
+          s *= scale;
+          scores[ki] = s;
+          if(s > maxVal) maxVal = s;
+        }
+        float sumExp = 0.0f;
+        for(int ki = 0; ki < S; ki++) {
+          if(maskN[ki] == 0.0f) { scores[ki] = 0.0f; continue; }
+          scores[ki] = expf(scores[ki] - maxVal);
+          sumExp += scores[ki];
+        }
+        const float inv = 1.0f / sumExp;
+        for(int ki = 0; ki < S; ki++) {
+          const float w = scores[ki] * inv;
+          if(w == 0.0f) continue;
+          const float* vv = v + ((size_t)bi * S + ki) * KVH * VD + kvh * VD;
+          for(int d = 0; d < VD; d++) out[d] += w * vv[d];
+        }
+      }
+      free(scores);
+    }
+  matmul_cells(&b->outProj, NS, att, ln); /* ln reused as the block output */
+#pragma omp parallel for schedule(static)
+  for(long p = 0; p < (long)NS; p++)
+    for(int c = 0; c < C; c++) trunk[(size_t)p * C + c] += ln[(size_t)p * C + c] * mask[p];
+  free(ln); free(q); free(k); free(v); free(att);
+}
+/* TransformerFFNBlock::apply (eigenbackend.cpp:1645-1718), SwiGLU */
+static void ffn_apply(const OBlock* b, int n, int S, float* trunk, const float* mask) {
+  const int C = b->linear1.ic, F = b->ffnChannels;
+  const size_t NS = (size_t)n * S;
+  float* ln = falloc(NS * C);
+  float* a = falloc(NS * F);
+  float* g = falloc(NS * F);
+  trms_apply(&b->preLN, n, S, trunk, ln, mask);
+  matmul_cells(&b->linear1, NS, ln, a);
+  matmul_cells(&b->linearGate, NS, ln, g);
+  for(size_t i = 0; i < NS * F; i++) a[i] = a[i] / (1.0f + expf(-a[i])) * g[i];
+  matmul_cells(&b->linear2, NS, a, ln);
+#pragma omp parallel for schedule(static)
+  for(long p = 0; p < (long)NS; p++)
+    for(int c = 0; c < C; c++) trunk[(size_t)p * C + c] += ln[(size_t)p * C + c] * mask[p];
+  free(ln); free(a); free(g);
+}
+/* RMSNormLayer::apply for the trunk tip (eigenbackend.cpp:960-1031): gamma, beta, activation; per cell or (spatial) per board */
+static void rms_tip_apply(const okmx_model* m, int n, int S, const float* in, float* out, const float* mask) {
+  const int C = m->C;
+  for(int bi = 0; bi < n; bi++) {
+    float boardRms = 0.0f;
+    if(m->rmsSpatial) {
+      float sumSq = 0.0f;
+      int count = 0;
+      for(int p = 0; p < S; p++) {
+        if(mask[(size_t)bi * S + p] == 0.0f) continue;
+        const float* ip = in + ((size_t)bi * S + p) * C;
+        for(int c = 0; c < C; c++) sumSq += ip[c] * ip[c];
+        count++;
+      }
+      boardRms = 1.0f / sqrtf(sumSq / ((float)count * (float)C) + m->rmsEps);
+    }
+    for(int p = 0; p < S; p++) {
+      const float* ip = in + ((size_t)bi * S + p) * C;
+      float* op = out + ((size_t)bi * S + p) * C;
+      if(mask[(size_t)bi * S + p] == 0.0f) { for(int c = 0; c < C; c++) op[c] = 0.0f; continue; }
+      float rms = boardRms;
+      if(!m->rmsSpatial) {
+        float sumSq = 0.0f;
+        for(int c = 0; c < C; c++) sumSq += ip[c] * ip[c];
+        rms = 1.0f / sqrtf(sumSq / (float)C + m->rmsEps);
+      }
+      for(int c = 0; c < C; c++) op[c] = act_apply(ip[c] * rms * m->rmsGamma[c] + m->rmsBeta[c], m->trunkTipAct);
+    }
+  }
+}
+
 static void blockstack_apply(const OBlock* blocks, int numBlocks, int n, int X, int Y, float* trunk,
                              const float* mask, const float* maskSum);
 
@@ -704,6 +1000,10 @@ static void block_apply(const OBlock* b, int n, int X, int Y, float* trunk, cons
     bnact_apply(&b->midBN, n, S, r, r, mask);
     conv_apply(&b->finalConv, n, X, Y, r, trunk, 1);
     free(t); free(r); free(g); free(gp); free(gb);
+  } else if(b->kind == BLK_ATTENTION) {
+    attention_apply(b, n, X, Y, trunk, mask);
+  } else if(b->kind == BLK_FFN) {
+    ffn_apply(b, n, S, trunk, mask);
   } else { /* nested bottleneck */
     const int M = b->regularConv.oc;
     float* t = falloc(NS * b->preBN.c);
@@ -763,7 +1063,10 @@ static void trunk_apply(const okmx_model* m, int n, int X, int Y, const float* i
     free(h1); free(h2);
   }
   blockstack_apply(m->blocks, m->numBlocks, n, X, Y, trunkRaw, mask, maskSum);
-  if(trunkOut) bnact_apply(&m->trunkTipBN, n, S, trunkRaw, trunkOut, mask);
+  if(trunkOut) {
+    if(m->trunkNormKind == 0) bnact_apply(&m->trunkTipBN, n, S, trunkRaw, trunkOut, mask);
+    else rms_tip_apply(m, n, S, trunkRaw, trunkOut, mask);
+  }
   free(gbias);
 }
 

@@ -53,3 +53,53 @@ def test_oracle_matches_reference_torch_model_with_metadata_encoder():
         raise AssertionError("a metadata net must reject rows without metadata")
     except oracle.OracleError:
         pass
+
+
+def _check_transformer_golden(name):
+    v = np.load(os.path.join(GOLD, name + "_vectors.npz"))
+    m = oracle.loadModelFile(os.path.join(GOLD, name + ".bin.gz"))
+    assert m.info.model_version == 17
+    mask = v["spatial_nhwc"][:, :, 0] > 0
+    assert mask.sum(axis=1).tolist() == [361, 361, 117, 81]
+    full = np.concatenate([mask, np.ones((4, 1), bool)], axis=1)
+    for opt in (0.0, 1.0):
+        o = oracle.getOutput(m, 19, 19, v["spatial_nhwc"], v["glob"], None, np.full(4, opt, np.float32))
+        assert np.abs(o["policy"] - v["policy"][:, int(opt), :])[full].max() < 2e-5
+        assert np.abs(o["value"] - v["value"]).max() < 1e-5
+        assert np.abs(o["score"] - v["score"]).max() < 1e-5
+        assert np.abs(o["ownership"] - v["ownership"])[mask].max() < 2e-5
+    return m, v
+
+
+def test_oracle_matches_reference_torch_transformer_trunk():
+    """Version-17 attention / SwiGLU-FFN trunk with fixed-theta 2D RoPE and a per-cell RMSNorm trunk tip
+    (model_pytorch.py TransformerAttentionBlock / TransformerFFNBlock / RMSNormMask; vectors: tools/gen_torch_golden_tf.py)."""
+    m, _ = _check_transformer_golden("torch_tfa")
+    assert m.info.num_blocks == 4
+
+
+def test_oracle_matches_reference_torch_transformer_gqa_learnable_rope():
+    """Grouped-query attention (4 query heads on 2 KV heads, q/k dim 8, v dim 4), learnable RoPE frequencies, a nested
+    bottleneck block whose inner stack is attention+FFN, next to a convolutional nested bottleneck block; per-board
+    ("spatial") RMSNorm trunk tip, which has to count only on-board cells on the 13x9 and 9x9 rows."""
+    _check_transformer_golden("torch_tfb")
+
+
+def test_transformer_rows_are_independent_and_translation_of_the_buffer_is_not_assumed():
+    """Size-independent properties of the attention path: a row's outputs do not depend on the other rows of the batch,
+    and a 9x9 board gives the same answer in a 9x9 buffer as in the corner of a 19x19 buffer (masked keys contribute
+    nothing; RoPE angles depend on (x, y), not on the buffer stride)."""
+    v = np.load(os.path.join(GOLD, "torch_tfb_vectors.npz"))
+    m = oracle.loadModelFile(os.path.join(GOLD, "torch_tfb.bin.gz"))
+    z = np.zeros(4, np.float32)
+    o = oracle.getOutput(m, 19, 19, v["spatial_nhwc"], v["glob"], None, z)
+    o3 = oracle.getOutput(m, 19, 19, v["spatial_nhwc"][3:4], v["glob"][3:4], None, z[:1])
+    for k in ("policy", "value", "score", "ownership"):
+        assert np.array_equal(o[k][3], o3[k][0])
+    small = v["spatial_nhwc"][3].reshape(19, 19, 22)[:9, :9, :].reshape(1, 81, 22).copy()
+    o9 = oracle.getOutput(m, 9, 9, small, v["glob"][3:4], None, z[:1])
+    idx = (np.arange(9)[:, None] * 19 + np.arange(9)[None, :]).reshape(-1)
+    assert np.abs(o9["policy"][0, :81] - o3["policy"][0, idx]).max() < 2e-5
+    assert abs(o9["policy"][0, 81] - o3["policy"][0, 361]) < 2e-5
+    assert np.abs(o9["value"] - o3["value"]).max() < 1e-5
+    assert np.abs(o9["ownership"][0] - o3["ownership"][0, idx]).max() < 2e-5
