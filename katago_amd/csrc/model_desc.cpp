@@ -368,7 +368,9 @@ std::unique_ptr<ModelDesc> ModelDesc::loadFromFile(const std::string& path, cons
       }
     if(m.version >= 15) {
       m.metaEncoderVersion = r.integer("metaEncoderVersion");
-      (void)r.integer("preferPassAliveUnderSuicideRules");
+      // a flag the host reads from its own ModelDesc (nneval.cpp:306); any other value is a file from the future (desc.cpp:2538-2548)
+      const int preferPassAlive = r.integer("preferPassAliveUnderSuicideRules");
+      if(preferPassAlive != 0 && preferPassAlive != 1) bad(m.name + ": model preferPassAliveUnderSuicideRules unexpected value");
       r.expectZeros(6, "model option");
       if(m.metaEncoderVersion < 0) bad(m.name + ": model metaEncoderVersion unexpected value");
       if(m.metaEncoderVersion > 1)  // modelversion.cpp:83-89: only version 1 (192 input features) exists

@@ -465,7 +465,7 @@ static int parse_model(Rd* r, okmx_model* m) {
   kmx_model_info* info = &m->info;
   char tok[256];
   rd_token(r, tok, sizeof(tok));
-  snprintf(info->name, sizeof(info->name), "%s", tok);
+  snprintf(info->name, sizeof(info->name), "%.*s", (int)sizeof(info->name) - 1, tok);
   m->version = info->model_version = rd_int(r, "modelVersion");
   if(r->err) return 0;
   if(m->version < 8 || m->version > 17) {
@@ -494,7 +494,8 @@ static int parse_model(Rd* r, okmx_model* m) {
   int metaEncoderVersion = 0;
   if(m->version >= 15) {
     metaEncoderVersion = rd_int(r, "metaEncoderVersion");
-    (void)rd_int(r, "preferPassAliveUnderSuicideRules");
+    const int preferPassAlive = rd_int(r, "preferPassAliveUnderSuicideRules"); /* desc.cpp:2538-2548: a flag, 0 or 1 */
+    if(!r->err && preferPassAlive != 0 && preferPassAlive != 1) rd_fail(r, "model preferPassAliveUnderSuicideRules unexpected value");
     for(int i = 0; i < 6; i++)
       if(rd_int(r, "unused model option") != 0) rd_fail(r, "unknown/unsupported model option");
   }

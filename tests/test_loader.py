@@ -98,3 +98,53 @@ def test_reference_nets(model_dir):
         with pytest.raises(nn.KatamxError) as e:
             nn.loadModelFile(tf)
         assert e.value.code in (capi.KMX_ERR_UNSUPPORTED, capi.KMX_ERR_MODEL)
+
+
+def _patch_header_token(src, dst, index, value):
+    raw = gzip.open(src, "rb").read()
+    cut = raw.index(b"@BIN@")
+    tokens = raw[:cut].split()
+    tokens[index] = value
+    with gzip.open(dst, "wb") as f:
+        f.write(b" ".join(tokens) + b" " + raw[cut:])
+    return tokens
+
+
+def test_prefer_pass_alive_header_slot(model_dir):
+    """tests/testmisc.cpp:159-213 on a v17 file written by the reference's exporter (tests/golden/torch_tfa.bin.gz):
+    header = name, version, 22, 19, 7 post-process multipliers, metaEncoderVersion, preferPassAliveUnderSuicideRules,
+    6 zeros, 'trunk'; slot values 0 and 1 parse, anything else is refused (desc.cpp:2538-2548). The convolutional v17
+    twin goes through the product loader, the transformer file through the oracle's."""
+    src = os.path.join(REPO, "tests", "golden", "torch_tfa.bin.gz")
+    for val, ok in ((b"0", True), (b"1", True), (b"2", False), (b"-1", False)):
+        dst = os.path.join(model_dir, "ppa_tf_%s.bin.gz" % val.decode())
+        tokens = _patch_header_token(src, dst, 12, val)
+        assert tokens[1] == b"17" and tokens[11] == b"0" and tokens[19] == b"trunk" and len(tokens) > 19
+        if ok:
+            assert oracle.loadModelFile(dst).info.model_version == 17
+        else:
+            with pytest.raises(oracle.OracleError):
+                oracle.loadModelFile(dst)
+    conv = os.path.join(model_dir, "ppa_conv.bin.gz")
+    modelgen.write_model(conv, "b2c32nbt", version=17, activation="silu")
+    for val, ok in ((b"0", True), (b"1", True), (b"2", False)):
+        dst = os.path.join(model_dir, "ppa_conv_%s.bin.gz" % val.decode())
+        _patch_header_token(conv, dst, 12, val)
+        if ok:
+            assert nn.getModelDesc(nn.loadModelFile(dst))["modelVersion"] == 17
+            assert oracle.loadModelFile(dst).info.model_version == 17
+        else:
+            with pytest.raises(nn.KatamxError) as e:
+                nn.loadModelFile(dst)
+            assert e.value.code == capi.KMX_ERR_MODEL and "preferPassAlive" in str(e.value)
+
+
+def test_transformer_nets_load_in_the_oracle_and_are_refused_by_the_backend():
+    """Model v17 transformer trunks (SURVEY 8 rows a24 / f4): the oracle evaluates them (tests/test_oracle_torch.py);
+    the HIP backend of this round says so at load time instead of mis-evaluating."""
+    for name in ("torch_tfa", "torch_tfb"):
+        p = os.path.join(REPO, "tests", "golden", name + ".bin.gz")
+        assert oracle.loadModelFile(p).info.num_blocks == 4
+        with pytest.raises(nn.KatamxError) as e:
+            nn.loadModelFile(p)
+        assert e.value.code == capi.KMX_ERR_UNSUPPORTED

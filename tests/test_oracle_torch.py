@@ -103,3 +103,26 @@ def test_transformer_rows_are_independent_and_translation_of_the_buffer_is_not_a
     assert abs(o9["policy"][0, 81] - o3["policy"][0, 361]) < 2e-5
     assert np.abs(o9["value"] - o3["value"]).max() < 1e-5
     assert np.abs(o9["ownership"][0] - o3["ownership"][0, idx]).max() < 2e-5
+
+
+def test_reference_transformer_test_nets_play_the_star_points():
+    """The two trained transformer nets the reference ships for its own GPU tests (cpp/rungpuerrortest.sh:32-34: RoPE +
+    RMSNorm tip; GQA + learnable RoPE + BatchNorm tip) run through the oracle: on an empty 19x19 board the four
+    strongest policy moves are the four 4-4 points — a weak but real check that trained weights, not only the random
+    ones of the fixtures above, are interpreted the way they were trained."""
+    import pytest
+
+    d = os.path.join(os.environ.get("KATAGO_REFERENCE", "/root/reference"), "cpp", "tests", "models")
+    names = ("b7c96h3tfrs-test5-cnorm.bin.gz", "b7c96h6kv3qk32v16tflrs-fson-bnh.bin.gz")
+    if not all(os.path.exists(os.path.join(d, f)) for f in names):
+        pytest.skip("reference checkout not present")
+    sp = np.zeros((1, 361, 22), np.float32)
+    sp[:, :, 0] = 1.0
+    gl = np.zeros((1, 19), np.float32)
+    gl[:, 5] = 7.5 / 20.0
+    for f in names:
+        m = oracle.loadModelFile(os.path.join(d, f))
+        assert m.info.model_version == 17 and m.info.trunk_num_channels == 96 and m.info.num_blocks == 14
+        o = oracle.getOutput(m, 19, 19, sp, gl)
+        assert all(np.isfinite(o[k]).all() for k in o)
+        assert sorted(np.argsort(-o["policy"][0])[:4].tolist()) == [3 * 19 + 3, 3 * 19 + 15, 15 * 19 + 3, 15 * 19 + 15]
