@@ -178,7 +178,10 @@ int kmx_eval_packed(kmx_handle* handle, int n_rows,
                     float* const* out_policy, float* out_value, float* out_score,
                     float* const* out_ownership);
 int kmx_pack_row(const float* row_spatial_nhwc, int nn_x_len, int nn_y_len, int num_channels, uint8_t* out_packed);
-void* kmx_handle_stream(kmx_handle* handle); /* hipStream_t the handle launches on */
+/* hipStream_t the handle launches on. A handle that splits a batch (kmx_handle_set_split_min below) launches the second
+ * half on a stream of its own: after an asynchronous kmx_eval_device (sync = 0) of such a batch, work enqueued on this
+ * stream is ordered after the FIRST half only — wait with kmx_handle_sync, which covers both, or turn splitting off. */
+void* kmx_handle_stream(kmx_handle* handle);
 int kmx_handle_sync(kmx_handle* handle);
 
 /* NNEvaluator counters (nneval.cpp:330-347, incremented :712-713): rows = evaluated

@@ -605,11 +605,19 @@ hipError_t launchOne(const ConvArgs& a, hipStream_t stream) {
   static_assert(!G::SPREAD || G::LS + (G::ROLES ? 1 : D) <= G::NT, "image pieces must land within their chunk");
   static_assert(G::STAGE_BYTES <= G::MASK_OFFSET, "epilogue staging overlaps the mask tile");
   auto kern = convMfmaKernel<TR, KS, WN, WNW, D, ABL>;
-  static std::atomic<bool> attrSet{false};  // per instantiation; the call is idempotent, so a race between two handles' first launches is harmless
-  if(!attrSet.load(std::memory_order_acquire)) {
+  // The opt-in to more than 64 KiB of dynamic LDS is a property of the function ON ONE DEVICE, and one process may hold
+  // handles on several GPUs (the reference runs one server thread per GPU in a single process): one flag per
+  // instantiation and device. The call is idempotent, so a race between two handles' first launches is harmless.
+  constexpr int MAX_DEVICES = 64;
+  static std::atomic<bool> attrSet[MAX_DEVICES];
+  int dev = 0;
+  hipError_t de = hipGetDevice(&dev);
+  if(de != hipSuccess) return de;
+  if(dev < 0 || dev >= MAX_DEVICES) return hipErrorInvalidDevice;
+  if(!attrSet[dev].load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes);
     if(e != hipSuccess) return e;
-    attrSet.store(true, std::memory_order_release);
+    attrSet[dev].store(true, std::memory_order_release);
   }
   if(a.coutPad % G::NTILE != 0) return hipErrorInvalidValue;
   dim3 grid(a.coutPad / G::NTILE, a.N, 1);

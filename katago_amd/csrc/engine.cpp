@@ -129,6 +129,18 @@ Engine::Engine(const ModelDesc& model, int nnXLen, int nnYLen, int maxBatch, int
     throw Error(KMX_ERR_INVALID_ARG, "nnXLen/nnYLen must be in 2..19");
   if(maxBatch < 1 || maxBatch > 65535) throw Error(KMX_ERR_INVALID_ARG, "maxBatchSize must be in 1..65535");
   if(dtype != DT_F16 && dtype != DT_BF16) throw Error(KMX_ERR_UNSUPPORTED, "unsupported device precision");
+  // A constructor that throws does not run the destructor: release the stream, events and pinned buffers acquired so far
+  // (an unsupported layer, or a device out of memory half-way through, must not leak them).
+  try {
+    construct(model);
+  }
+  catch(...) {
+    destroy();
+    throw;
+  }
+}
+
+void Engine::construct(const ModelDesc& model) {
   hipCheck(hipSetDevice(device_), "hipSetDevice");
   hipCheck(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
   cin_ = model.numInputChannels;
@@ -170,7 +182,9 @@ Engine::Engine(const ModelDesc& model, int nnXLen, int nnYLen, int maxBatch, int
   hipCheck(hipStreamSynchronize(stream_), "sync after build");
 }
 
-Engine::~Engine() {
+Engine::~Engine() { destroy(); }
+
+void Engine::destroy() noexcept {
   if(stream_) (void)hipStreamSynchronize(stream_);
   for(const Pending& p : pending_) {
     (void)hipEventDestroy(p.a);
@@ -179,17 +193,17 @@ Engine::~Engine() {
   for(hipEvent_t e : eventPool_) (void)hipEventDestroy(e);
   for(int i = 0; i < 2; i++)
     if(stagingDone_[i]) (void)hipEventDestroy(stagingDone_[i]);
-  (void)hipHostFree(hSpatial_);
-  (void)hipHostFree(hGlobal_);
-  if(hMeta_) (void)hipHostFree(hMeta_);
-  if(hPacked_) (void)hipHostFree(hPacked_);
-  (void)hipHostFree(hPolicy_);
-  (void)hipHostFree(hValue_);
-  (void)hipHostFree(hScore_);
-  (void)hipHostFree(hOwnership_);
-  (void)hipHostFree(hSymmetry_);
-  (void)hipHostFree(hOptimism_);
+  pending_.clear();
+  eventPool_.clear();
+  stagingDone_[0] = stagingDone_[1] = nullptr;
+  void* pinned[] = {hSpatial_, hGlobal_, hMeta_, hPacked_, hPolicy_, hValue_, hScore_, hOwnership_, hSymmetry_, hOptimism_};
+  for(void* p : pinned)
+    if(p) (void)hipHostFree(p);
+  hSpatial_ = hGlobal_ = hMeta_ = hPolicy_ = hValue_ = hScore_ = hOwnership_ = hOptimism_ = nullptr;
+  hPacked_ = nullptr;
+  hSymmetry_ = nullptr;
   if(stream_) (void)hipStreamDestroy(stream_);
+  stream_ = nullptr;
 }
 
 float* Engine::uploadFloats(const std::vector<float>& v) {

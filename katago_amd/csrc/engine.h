@@ -121,6 +121,8 @@ class Engine {
     double flopsPerRow;    // algorithmic flops per evaluated position
     double bytesPerRow;    // algorithmic HBM bytes per evaluated position
   };
+  void construct(const ModelDesc& model);  // the body of the constructor
+  void destroy() noexcept;                 // everything the destructor releases; also run when construct() throws
   int opClass(const std::string& name);
   void addOp(const std::string& cls, double flopsPerRow, double bytesPerRow, std::function<void(int, hipStream_t)> fn);
   void collectProfile();

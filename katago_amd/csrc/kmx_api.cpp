@@ -57,6 +57,7 @@ int guarded(F&& f) {
   catch(const Error& e) { return setError(e.code, e.what()); }
   catch(const std::bad_alloc&) { return setError(KMX_ERR_INTERNAL, "out of host memory"); }
   catch(const std::exception& e) { return setError(KMX_ERR_INTERNAL, e.what()); }
+  catch(...) { return setError(KMX_ERR_INTERNAL, "unknown exception"); }  // nothing may unwind through the C ABI
 }
 int dtypeForPrecision(int mode) {
   switch(mode) {
@@ -173,6 +174,7 @@ int kmx_handle_create(kmx_context* ctx, const kmx_model* model, int max_batch_si
   return guarded([&] {
     if(!ctx || !model || !out) throw Error(KMX_ERR_INVALID_ARG, "kmx_handle_create: null argument");
     *out = nullptr;
+    if(max_batch_size < 1) throw Error(KMX_ERR_INVALID_ARG, "kmx_handle_create: max_batch_size must be positive");
     const int ndev = deviceCountOrThrow();
     const int dev = gpu_idx < 0 ? 0 : gpu_idx;
     if(dev >= ndev) throw Error(KMX_ERR_DEVICE, "kmx_handle_create: device index out of range");
@@ -224,13 +226,22 @@ static int evalHostEntry(kmx_handle* handle, int n_rows, const float* const* row
     const int h = n_rows - n_rows / 2, r = n_rows / 2;  // engine2 holds max_batch/2 rows
     handle->engine->setConcurrency(2);
     handle->engine2->setConcurrency(2);
-    handle->engine->evalHostBegin(h, row_spatial, row_packed, row_global, row_meta, symmetry, policy_optimism, out_ownership);
-    handle->engine2->evalHostBegin(r, row_spatial ? row_spatial + h : nullptr, row_packed ? row_packed + h : nullptr, row_global + h,
-                                   row_meta ? row_meta + h : nullptr, symmetry ? symmetry + h : nullptr,
-                                   policy_optimism ? policy_optimism + h : nullptr, out_ownership ? out_ownership + h : nullptr);
-    handle->engine->evalHostFinish(h, out_policy, out_value, out_score, out_ownership);
-    handle->engine2->evalHostFinish(r, out_policy + h, out_value + (size_t)h * 3, out_score + (size_t)h * 6,
-                                    out_ownership ? out_ownership + h : nullptr);
+    try {
+      handle->engine->evalHostBegin(h, row_spatial, row_packed, row_global, row_meta, symmetry, policy_optimism, out_ownership);
+      handle->engine2->evalHostBegin(r, row_spatial ? row_spatial + h : nullptr, row_packed ? row_packed + h : nullptr, row_global + h,
+                                     row_meta ? row_meta + h : nullptr, symmetry ? symmetry + h : nullptr,
+                                     policy_optimism ? policy_optimism + h : nullptr, out_ownership ? out_ownership + h : nullptr);
+      handle->engine->evalHostFinish(h, out_policy, out_value, out_score, out_ownership);
+      handle->engine2->evalHostFinish(r, out_policy + h, out_value + (size_t)h * 3, out_score + (size_t)h * 6,
+                                      out_ownership ? out_ownership + h : nullptr);
+    }
+    catch(...) {
+      // one half failed while the other may still be in flight: the call is synchronous, so nothing of it may be running
+      // when the error is reported
+      try { handle->engine->sync(); } catch(...) {}
+      try { handle->engine2->sync(); } catch(...) {}
+      throw;
+    }
   });
 }
 
