@@ -19,7 +19,7 @@
 #include "neuralnet/desc.h"
 
 #include <cstring>
-#include <mutex>
+#include <memory>
 #include <vector>
 
 #include "katamx.h"
@@ -158,7 +158,7 @@ ComputeContext* NeuralNet::createComputeContext(
   (void)logger;
   (void)homeDataDirOverride;
   (void)loadedModel;
-  ComputeContext* context = new ComputeContext();
+  std::unique_ptr<ComputeContext> context(new ComputeContext());  // released on success; a throwing check() must not leak it
   context->nnXLen = nnXLen;
   context->nnYLen = nnYLen;
   // useFP16 = false asks for fp32; true/auto picks the backend's 16-bit default. The private key
@@ -180,7 +180,7 @@ ComputeContext* NeuralNet::createComputeContext(
 #else
   (void)gpuIdxs;
 #endif
-  return context;
+  return context.release();
 }
 void NeuralNet::freeComputeContext(ComputeContext* computeContext) {
   if(computeContext == NULL)
@@ -201,7 +201,7 @@ ComputeHandle* NeuralNet::createComputeHandle(
   int gpuIdxForThisThread,
   int serverThreadIdx
 ) {
-  ComputeHandle* handle = new ComputeHandle();
+  std::unique_ptr<ComputeHandle> handle(new ComputeHandle());
   handle->context = context;
   handle->loadedModel = loadedModel;
   handle->inputsUseNHWC = inputsUseNHWC;
@@ -229,7 +229,7 @@ ComputeHandle* NeuralNet::createComputeHandle(
   if(logger != NULL)
     logger->write("katamx CPU ORACLE backend thread " + Global::intToString(serverThreadIdx) + " model " + loadedModel->modelDesc.name);
 #endif
-  return handle;
+  return handle.release();
 }
 void NeuralNet::freeComputeHandle(ComputeHandle* handle) {
   if(handle == NULL)
