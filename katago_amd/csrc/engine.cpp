@@ -2,6 +2,7 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 namespace kmx {
@@ -109,6 +110,14 @@ namespace {
 void scanStack(const std::vector<BlockDesc>& blocks, int depth, std::vector<int>& levelStride, int& tmpStride, int& gStride) {
   for(const BlockDesc& b : blocks) {
     if(b.kind == BlockKind::Ordinary) tmpStride = std::max(tmpStride, roundUp(b.regularConv.outC, 32));
+    else if(b.kind == BlockKind::Attention) {  // [0] holds q|k|v, [1] the attention output
+      tmpStride = std::max(tmpStride, roundUp(roundUp(b.qProj.outC, 8) + roundUp(b.kProj.outC, 8) + roundUp(b.vProj.outC, 8), 32));
+      gStride = std::max(gStride, roundUp(b.outProj.inC, 32));
+    }
+    else if(b.kind == BlockKind::FFN) {  // [0] holds linear1|gate, [1] the SwiGLU product
+      tmpStride = std::max(tmpStride, roundUp(2 * roundUp(b.ffnChannels, 8), 32));
+      gStride = std::max(gStride, roundUp(b.ffnChannels, 32));
+    }
     else if(b.kind == BlockKind::GPool) {
       tmpStride = std::max(tmpStride, roundUp(b.regularConv.outC, 32));
       gStride = std::max(gStride, roundUp(b.gpoolConv.outC, 32));
@@ -261,25 +270,155 @@ void Engine::addConv(const FusedConv* fc, const void* in, int inStride, const fl
   });
 }
 
+// The last convolution of a block adds into the residual stream and, when the next consumer is a convolutional block (or a
+// BatchNorm tip), also writes that consumer's BN+activation image of the stream. Transformer blocks and RMSNorm tips
+// normalise over all channels of a cell, which no single work-group of the convolution sees: they get no image (nextBN null).
+void Engine::addResidualConv(const ConvDesc& conv, const void* in, int inStride, const Stream& s, const BnDesc* nextBN) {
+  const FusedConv* c = newConv({{&conv, nextBN}});
+  if(nextBN != nullptr)
+    addConv(c, in, inStride, nullptr, 0, s.raw, s.stride, s.raw, s.stride, 0, c->coutPad, s.act, s.stride, 0, c->coutPad, nextBN->act);
+  else
+    addConv(c, in, inStride, nullptr, 0, s.raw, s.stride, s.raw, s.stride, 0, c->coutPad, nullptr, 0, 0, 0, KMX_ACT_IDENTITY);
+}
+
+namespace {
+ConvDesc convOfMatMul(const MatMulDesc& m) {  // a matmul over channels at every cell = a 1x1 convolution; [ic][oc] = [1][1][ic][oc]
+  ConvDesc c;
+  c.name = m.name;
+  c.ky = c.kx = 1;
+  c.inC = m.inC;
+  c.outC = m.outC;
+  c.w = m.w;
+  return c;
+}
+}  // namespace
+
+void Engine::addRmsNorm(const void* in, int inStride, void* out, int outStride, int C, float eps, const std::vector<float>& w,
+                        const std::vector<float>* beta, int actKind, bool perBoard) {
+  RmsNormArgs ra;
+  memset(&ra, 0, sizeof(ra));
+  ra.in = in; ra.inStride = inStride; ra.out = out; ra.outStride = outStride; ra.C = C; ra.eps = eps;
+  ra.w = uploadFloats(w);
+  ra.beta = beta != nullptr ? uploadFloats(*beta) : nullptr;
+  ra.actKind = actKind;
+  ra.mask = mask_.as<float>();
+  ra.S = S_;
+  const int dtype = dtype_;
+  if(perBoard) {
+    if(boardRms_.get() == nullptr) boardRms_ = DevBuf((size_t)maxBatch_ * sizeof(float));
+    float* rms = boardRms_.as<float>();
+    const float* mask = mask_.as<float>();
+    const float* maskSum = maskSum_.as<float>();
+    const int S = S_;
+    ra.boardRms = rms;
+    addOp("rmsnorm", 2.0 * S_ * C, 2.0 * S_ * C, [=](int n, hipStream_t st) {
+      hipCheck(launchBoardRms(dtype, in, inStride, C, mask, maskSum, n, S, eps, rms, st), "board rms launch");
+    });
+  }
+  addOp("rmsnorm", 3.0 * S_ * C, 2.0 * S_ * (C + outStride), [=](int n, hipStream_t st) {
+    RmsNormArgs x = ra;
+    x.N = n;
+    hipCheck(launchRmsNorm(dtype, x, st), "rmsnorm launch");
+  });
+}
+
+// TransformerAttentionDesc::computeRopeCosSin (desc.cpp:1300-1363) for this engine's buffer: [heads][numPairs][S]
+static void ropeTables(const BlockDesc& b, int X, int Y, std::vector<float>& cosT, std::vector<float>& sinT) {
+  const int S = X * Y, numPairs = b.qHeadDim / 2, heads = b.learnableRope ? b.numKVHeads : 1;
+  cosT.assign((size_t)heads * numPairs * S, 1.0f);
+  sinT.assign((size_t)heads * numPairs * S, 0.0f);
+  for(int h = 0; h < heads; h++)
+    for(int p = 0; p < numPairs; p++)
+      for(int y = 0; y < Y; y++)
+        for(int x = 0; x < X; x++) {
+          float angle;
+          if(b.learnableRope)
+            angle = (float)x * b.ropeFreqs[((size_t)h * numPairs + p) * 2 + 0] + (float)y * b.ropeFreqs[((size_t)h * numPairs + p) * 2 + 1];
+          else {
+            const int perDim = numPairs / 2, dimHalf = b.qHeadDim / 2;
+            if(p < perDim) angle = (float)y * (1.0f / powf(b.ropeTheta, (float)(2 * p) / (float)dimHalf));
+            else angle = (float)x * (1.0f / powf(b.ropeTheta, (float)(2 * (p - perDim)) / (float)dimHalf));
+          }
+          cosT[((size_t)h * numPairs + p) * S + y * X + x] = cosf(angle);
+          sinT[((size_t)h * numPairs + p) * S + y * X + x] = sinf(angle);
+        }
+}
+
 void Engine::buildStack(const std::vector<BlockDesc>& blocks, const Stream& s, const BnDesc* bnAfter, int depth) {
   for(size_t i = 0; i < blocks.size(); i++) {
     const BlockDesc& b = blocks[i];
-    const BnDesc* nextBN = i + 1 < blocks.size() ? &blocks[i + 1].preBN : bnAfter;
-      if(b.kind == BlockKind::Ordinary) {
+    const BnDesc* nextBN = i + 1 < blocks.size() ? (blocks[i + 1].isTransformer() ? nullptr : &blocks[i + 1].preBN) : bnAfter;
+    if(b.kind == BlockKind::Attention) {
+      // ln = rmsnorm(s.raw); q|k|v = ln W; att = softmax(rope(q) rope(k)^T / sqrt(d) + keymask) v; s.raw += att Wo  (eigenbackend.cpp:1376-1600)
+      if(b.preLN.c % 8 != 0) throw Error(KMX_ERR_UNSUPPORTED, b.name + ": channel counts must be multiples of 8");
+      if(!attentionDimsSupported(b.qHeadDim, b.vHeadDim)) throw Error(KMX_ERR_UNSUPPORTED, b.name + ": attention head dims above 64 are not supported");
+      addRmsNorm(s.raw, s.stride, s.act, s.stride, b.preLN.c, b.preLN.eps, b.preLN.w, nullptr, KMX_ACT_IDENTITY, false);
+      const ConvDesc cq = convOfMatMul(b.qProj), ck = convOfMatMul(b.kProj), cv = convOfMatMul(b.vProj), co = convOfMatMul(b.outProj);
+      std::vector<int> offs;
+      const FusedConv* qkv = newConv({{&cq, nullptr}, {&ck, nullptr}, {&cv, nullptr}}, &offs);
+      void* tQkv = acts_[0]->get();
+      void* tAtt = acts_[1]->get();
+      const int qkvStride = roundUp(qkv->cout, 32), attStride = roundUp(co.inC, 32);
+      addConv(qkv, s.act, s.stride, nullptr, 0, nullptr, 0, tQkv, qkvStride, 0, qkv->coutPad, nullptr, 0, 0, 0, KMX_ACT_IDENTITY);
+      AttentionArgs aa;
+      memset(&aa, 0, sizeof(aa));
+      aa.qkv = tQkv; aa.stride = qkvStride; aa.kOff = offs[1]; aa.vOff = offs[2];
+      aa.H = b.numHeads; aa.KVH = b.numKVHeads; aa.QD = b.qHeadDim; aa.VD = b.vHeadDim;
+      if(b.useRope) {
+        std::vector<float> cosT, sinT;
+        ropeTables(b, X_, Y_, cosT, sinT);
+        aa.ropeCos = uploadFloats(cosT);
+        aa.ropeSin = uploadFloats(sinT);
+        aa.ropeHeads = b.learnableRope ? b.numKVHeads : 1;
+      }
+      aa.mask = mask_.as<float>();
+      aa.out = tAtt; aa.outStride = attStride;
+      aa.scale = 1.0f / sqrtf((float)b.qHeadDim);
+      aa.S = S_;
+      const int dtype = dtype_;
+      addOp("attention", 2.0 * S_ * S_ * b.numHeads * (b.qHeadDim + b.vHeadDim), 2.0 * S_ * (qkv->cout + co.inC), [=](int n, hipStream_t st) {
+        AttentionArgs x = aa;
+        x.N = n;
+        hipCheck(launchAttention(dtype, x, st), "attention launch");
+      });
+      addResidualConv(co, tAtt, attStride, s, nextBN);
+    }
+    else if(b.kind == BlockKind::FFN) {
+      // ln = rmsnorm(s.raw); h = silu(ln W1) * (ln Wg); s.raw += h W2   (eigenbackend.cpp:1645-1718)
+      if(b.preLN.c % 8 != 0 || b.ffnChannels % 8 != 0) throw Error(KMX_ERR_UNSUPPORTED, b.name + ": channel counts must be multiples of 8");
+      addRmsNorm(s.raw, s.stride, s.act, s.stride, b.preLN.c, b.preLN.eps, b.preLN.w, nullptr, KMX_ACT_IDENTITY, false);
+      const ConvDesc c1 = convOfMatMul(b.linear1), cg = convOfMatMul(b.linearGate), c2 = convOfMatMul(b.linear2);
+      std::vector<int> offs;
+      const FusedConv* up = newConv({{&c1, nullptr}, {&cg, nullptr}}, &offs);
+      void* tUp = acts_[0]->get();
+      void* tH = acts_[1]->get();
+      const int upStride = roundUp(up->cout, 32), hStride = roundUp(b.ffnChannels, 32);
+      addConv(up, s.act, s.stride, nullptr, 0, nullptr, 0, tUp, upStride, 0, up->coutPad, nullptr, 0, 0, 0, KMX_ACT_IDENTITY);
+      SwiGluArgs ga;
+      memset(&ga, 0, sizeof(ga));
+      ga.in = tUp; ga.inStride = upStride; ga.gOff = offs[1]; ga.F = b.ffnChannels;
+      ga.out = tH; ga.outStride = hStride;
+      const int dtype = dtype_;
+      const size_t S = (size_t)S_;
+      addOp("swiglu", 4.0 * S_ * b.ffnChannels, 2.0 * S_ * 3.0 * b.ffnChannels, [=](int n, hipStream_t st) {
+        SwiGluArgs x = ga;
+        x.cells = (size_t)n * S;
+        hipCheck(launchSwiGlu(dtype, x, st), "swiglu launch");
+      });
+      addResidualConv(c2, tH, hStride, s, nextBN);
+    }
+    else if(b.kind == BlockKind::Ordinary) {
       // mid = act(midBN(conv1(s.act)));  s.raw += conv2(mid);  s.act = act(nextBN(s.raw))   (eigenbackend.cpp:1139-1145)
       const FusedConv* c1 = newConv({{&b.regularConv, &b.midBN}});
-      const FusedConv* c2 = newConv({{&b.finalConv, nextBN}});
       void* tmp = acts_[0]->get();
       const int tmpStride = roundUp(b.regularConv.outC, 32);
       addConv(c1, s.act, s.stride, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, tmp, tmpStride, 0, c1->coutPad, b.midBN.act);
-      addConv(c2, tmp, tmpStride, nullptr, 0, s.raw, s.stride, s.raw, s.stride, 0, c2->coutPad, s.act, s.stride, 0,
-              c2->coutPad, nextBN->act);
+      addResidualConv(b.finalConv, tmp, tmpStride, s, nextBN);
     }
     else if(b.kind == BlockKind::GPool) {
       // r = convR(s.act); g = act(gpoolBN(convG(s.act))); r += W*pool(g); s.raw += conv2(act(midBN(r)))  (eigenbackend.cpp:1204-1220)
       std::vector<int> offs;
       const FusedConv* c1 = newConv({{&b.regularConv, nullptr}, {&b.gpoolConv, &b.gpoolBN}}, &offs);
-      const FusedConv* c2 = newConv({{&b.finalConv, nextBN}});
       const int R = b.regularConv.outC, G = b.gpoolConv.outC;
       const int rStride = roundUp(R, 32), gStride = roundUp(G, 32);
       void* tmpR = acts_[0]->get();
@@ -304,8 +443,7 @@ void Engine::buildStack(const std::vector<BlockDesc>& blocks, const Stream& s, c
         x.N = n;
         hipCheck(launchGPoolApply(dtype, x, st), "gpool launch");
       });
-      addConv(c2, tmpR, rStride, nullptr, 0, s.raw, s.stride, s.raw, s.stride, 0, c2->coutPad, s.act, s.stride, 0,
-              c2->coutPad, nextBN->act);
+      addResidualConv(b.finalConv, tmpR, rStride, s, nextBN);
     }
     else {
       // mid = conv1x1(s.act); inner stack on mid; s.raw += conv1x1(act(postBN(mid)))   (eigenbackend.cpp:1308-1314)
@@ -314,14 +452,15 @@ void Engine::buildStack(const std::vector<BlockDesc>& blocks, const Stream& s, c
       mid.raw = acts_[2 + 2 * (depth + 1)]->get();
       mid.act = acts_[3 + 2 * (depth + 1)]->get();
       mid.stride = roundUp(M, 32);
-      const BnDesc* firstInnerBN = &b.inner[0].preBN;
+      const BnDesc* firstInnerBN = b.inner[0].isTransformer() ? nullptr : &b.inner[0].preBN;
       const FusedConv* pre = newConv({{&b.regularConv, firstInnerBN}});
-      addConv(pre, s.act, s.stride, nullptr, 0, nullptr, 0, mid.raw, mid.stride, 0, pre->coutPad, mid.act, mid.stride, 0,
-              pre->coutPad, firstInnerBN->act);
+      if(firstInnerBN != nullptr)
+        addConv(pre, s.act, s.stride, nullptr, 0, nullptr, 0, mid.raw, mid.stride, 0, pre->coutPad, mid.act, mid.stride, 0,
+                pre->coutPad, firstInnerBN->act);
+      else
+        addConv(pre, s.act, s.stride, nullptr, 0, nullptr, 0, mid.raw, mid.stride, 0, pre->coutPad, nullptr, 0, 0, 0, KMX_ACT_IDENTITY);
       buildStack(b.inner, mid, &b.midBN, depth + 1);
-      const FusedConv* post = newConv({{&b.finalConv, nextBN}});
-      addConv(post, mid.act, mid.stride, nullptr, 0, s.raw, s.stride, s.raw, s.stride, 0, post->coutPad, s.act, s.stride, 0,
-              post->coutPad, nextBN->act);
+      addResidualConv(b.finalConv, mid.act, mid.stride, s, nextBN);
     }
   }
 }
@@ -383,11 +522,21 @@ void Engine::buildSchedule(const ModelDesc& m) {
     });
   }
   // ---- trunk (Trunk::apply, eigenbackend.cpp:1909-1947) ----
-  const BnDesc* firstBN = &m.blocks[0].preBN;
+  const BnDesc* firstBN = m.blocks[0].isTransformer() ? nullptr : &m.blocks[0].preBN;
   const FusedConv* stem = newConv({{&m.initialConv, firstBN}});
-  addConv(stem, inputT_.get(), KCHUNK, ncBias_.as<float>(), roundUp(m.trunkC, 64), nullptr, 0, trunk.raw, trunk.stride, 0,
-          stem->coutPad, trunk.act, trunk.stride, 0, stem->coutPad, firstBN->act);
-  buildStack(m.blocks, trunk, &m.trunkTipBN, 0);
+  if(firstBN != nullptr)
+    addConv(stem, inputT_.get(), KCHUNK, ncBias_.as<float>(), roundUp(m.trunkC, 64), nullptr, 0, trunk.raw, trunk.stride, 0,
+            stem->coutPad, trunk.act, trunk.stride, 0, stem->coutPad, firstBN->act);
+  else
+    addConv(stem, inputT_.get(), KCHUNK, ncBias_.as<float>(), roundUp(m.trunkC, 64), nullptr, 0, trunk.raw, trunk.stride, 0,
+            stem->coutPad, nullptr, 0, 0, 0, KMX_ACT_IDENTITY);
+  if(m.trunkNormKind == 0) buildStack(m.blocks, trunk, &m.trunkTipBN, 0);
+  else {
+    // RMSNorm trunk tip (RMSNormLayer::apply, eigenbackend.cpp:960-1031): gamma, beta, activation, masked; per cell or per board
+    if(m.trunkC % 8 != 0) throw Error(KMX_ERR_UNSUPPORTED, "RMSNorm trunk tip: trunk channels must be a multiple of 8");
+    buildStack(m.blocks, trunk, nullptr, 0);
+    addRmsNorm(trunk.raw, trunk.stride, trunk.act, trunk.stride, m.trunkC, m.rmsEps, m.rmsGamma, &m.rmsBeta, m.trunkTipAct, m.rmsSpatial);
+  }
 
   // ---- heads: one 1x1 conv for p1 (raw), g1 (BN+act), v1 (BN+act) ----
   const bool fuseV = m.g1BN.act == m.v1BN.act;

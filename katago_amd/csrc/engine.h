@@ -133,6 +133,9 @@ class Engine {
                const void* resid, int residStride, void* rawOut, int rawStride, int rawBegin, int rawEnd, void* actOut,
                int actStride, int actBegin, int actEnd, int actKind);
   const FusedConv* newConv(const std::vector<ConvSegment>& segs, std::vector<int>* offs = nullptr);
+  void addResidualConv(const ConvDesc& conv, const void* in, int inStride, const Stream& s, const BnDesc* nextBN);
+  void addRmsNorm(const void* in, int inStride, void* out, int outStride, int C, float eps, const std::vector<float>& w,
+                  const std::vector<float>* beta, int actKind, bool perBoard);
   float* uploadFloats(const std::vector<float>& v);
   void stageRowParams(int n, const int* symmetry, const float* policyOptimism);
   void runSchedule(int n, const float* dSpatial, const unsigned char* dPacked, const float* dGlobal, const float* dMeta,
@@ -150,6 +153,7 @@ class Engine {
   DevBuf dSymmetry_, dOptimism_;
   DevBuf dSpatialIn_, dGlobalIn_, dMetaIn_, dPackedIn_;  // staging for the host entry
   DevBuf dPolicy_, dValue_, dScore_, dOwnership_, polFeat_;
+  DevBuf boardRms_;  // [maxBatch] per-board 1/rms of a spatial RMSNorm trunk tip
   // pinned host staging
   float* hSpatial_ = nullptr;
   float* hGlobal_ = nullptr;

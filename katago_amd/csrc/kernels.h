@@ -146,6 +146,52 @@ struct ValueArgs {
 };
 hipError_t launchValueFinal(int dtype, const ValueArgs& a, hipStream_t stream);
 
+// ---- model-v17 transformer trunks (transformer_kernels.hip; experimental, see the header of that file) ----
+// RMSNorm over channels: out = act(in * r * w + beta) on on-board cells, 0 elsewhere and in channels [C, outStride);
+// r = 1/sqrt(mean_c(in^2) + eps) per cell, or boardRms[n] (launchBoardRms) for the per-board trunk tip.
+struct RmsNormArgs {
+  const void* in;   // T [N][S][inStride]
+  int inStride;
+  void* out;        // T [N][S][outStride]
+  int outStride;
+  int C;
+  float eps;
+  const float* w;     // [C]
+  const float* beta;  // [C] or null
+  int actKind;
+  const float* boardRms;  // [N] or null
+  const float* mask;      // [N][S]
+  int N, S;
+};
+hipError_t launchRmsNorm(int dtype, const RmsNormArgs& a, hipStream_t stream);
+hipError_t launchBoardRms(int dtype, const void* in, int inStride, int C, const float* mask, const float* maskSum, int N, int S,
+                          float eps, float* outRms, hipStream_t stream);
+// Masked softmax attention with grouped-query heads and 2D RoPE, one work-group per (head, board).
+struct AttentionArgs {
+  const void* qkv;  // T [N][S][stride]: q at [0, H*QD), k at [kOff, kOff + KVH*QD), v at [vOff, vOff + KVH*VD)
+  int stride, kOff, vOff;
+  int H, KVH, QD, VD;
+  const float* ropeCos;  // [ropeHeads][QD/2][S], or null without RoPE
+  const float* ropeSin;
+  int ropeHeads;         // 1 = one table for all heads (fixed theta), KVH = per KV head (learnable frequencies)
+  const float* mask;     // [N][S]
+  void* out;             // T [N][S][outStride], head h at channels [h*VD, (h+1)*VD)
+  int outStride;
+  float scale;           // 1/sqrt(QD)
+  int N, S;
+};
+hipError_t launchAttention(int dtype, const AttentionArgs& a, hipStream_t stream);
+bool attentionDimsSupported(int qHeadDim, int vHeadDim);
+// SwiGLU: out[c] = silu(in[c]) * in[gOff + c] for c < F; channels [F, outStride) = 0
+struct SwiGluArgs {
+  const void* in;
+  int inStride, gOff, F;
+  void* out;
+  int outStride;
+  size_t cells;
+};
+hipError_t launchSwiGlu(int dtype, const SwiGluArgs& a, hipStream_t stream);
+
 // Stand-alone masked BN + activation (only the layer test hooks need it un-fused).
 struct BnActArgs {
   const void* in;

@@ -1,6 +1,8 @@
 // model_desc.cpp — parser for KataGo model files. See model_desc.h for the format citations.
 #include "model_desc.h"
 
+#include <cstdlib>
+
 #include <zlib.h>
 
 #include <cctype>
@@ -248,6 +250,17 @@ MatBiasDesc parseMatBias(Reader& r) {
   return m;
 }
 
+TRmsDesc parseTRms(Reader& r) {
+  TRmsDesc t;
+  t.name = r.token("rmsnorm name");
+  t.c = r.integer("numChannels");
+  t.eps = r.real("epsilon");
+  if(t.c < 1) bad(t.name + ": number of channels must be positive");
+  if(!(t.eps > 0.0f) || t.eps > 1.0f) bad(t.name + ": epsilon out of range");
+  t.w = r.floats(t.c, t.name);
+  return t;
+}
+
 std::vector<BlockDesc> parseStack(Reader& r, int version, int numBlocks, int trunkC, const std::string& owner);
 
 BlockDesc parseBlock(Reader& r, int version, int trunkC, const std::string& owner) {
@@ -298,8 +311,59 @@ BlockDesc parseBlock(Reader& r, int version, int trunkC, const std::string& owne
     if(b.preBN.c != b.regularConv.inC || b.midBN.c != b.regularConv.outC || b.midBN.c != b.finalConv.inC)
       bad(b.name + ": nested block channel counts are inconsistent");
   }
-  else if(kind == "transformer_attention_block" || kind == "transformer_ffn_block") {
-    throw ModelError(KMX_ERR_UNSUPPORTED, owner + ": transformer blocks are not supported by the katamx backend (convolutional nets only)");
+  else if(kind == "transformer_attention_block") {
+    b.kind = BlockKind::Attention;
+    b.name = r.token("block name");
+    b.numHeads = r.integer("numHeads");
+    b.numKVHeads = r.integer("numKVHeads");
+    b.qHeadDim = r.integer("qHeadDim");
+    b.vHeadDim = r.integer("vHeadDim");
+    b.useRope = r.integer("useRope") != 0;
+    b.learnableRope = r.integer("learnableRope") != 0;
+    if(b.numHeads < 1 || b.numKVHeads < 1 || b.qHeadDim < 1 || b.vHeadDim < 1) bad(b.name + ": transformer attention dimensions must be positive");
+    if(b.numHeads % b.numKVHeads != 0) bad(b.name + ": numHeads must be divisible by numKVHeads");
+    if(b.useRope && b.qHeadDim % 2 != 0) bad(b.name + ": qHeadDim must be even for RoPE");
+    b.preLN = parseTRms(r);
+    b.qProj = parseMatMul(r);
+    b.kProj = parseMatMul(r);
+    b.vProj = parseMatMul(r);
+    b.outProj = parseMatMul(r);
+    if(b.preLN.c != trunkC || b.qProj.inC != trunkC || b.kProj.inC != trunkC || b.vProj.inC != trunkC ||
+       b.qProj.outC != b.numHeads * b.qHeadDim || b.kProj.outC != b.numKVHeads * b.qHeadDim ||
+       b.vProj.outC != b.numKVHeads * b.vHeadDim || b.outProj.inC != b.numHeads * b.vHeadDim || b.outProj.outC != trunkC)
+      bad(b.name + ": transformer attention channel counts are inconsistent");
+    if(b.useRope) {
+      (void)r.token("rope parameter name");
+      if(b.learnableRope) {
+        const int kvh = r.integer("rope numKVHeads"), np = r.integer("rope numPairs"), two = r.integer("rope freq dims");
+        if(kvh != b.numKVHeads || np != b.qHeadDim / 2 || two != 2) bad(b.name + ": learnable rope frequency table has the wrong shape");
+        b.ropeFreqs = r.floats((size_t)kvh * np * 2, b.name);
+      }
+      else {
+        b.ropeTheta = r.real("rope theta");
+        if(!(b.ropeTheta > 0.0f)) bad(b.name + ": rope theta must be positive");
+      }
+    }
+    return b;
+  }
+  else if(kind == "transformer_ffn_block") {
+    b.kind = BlockKind::FFN;
+    b.name = r.token("block name");
+    const int nc = r.integer("numChannels");
+    b.ffnChannels = r.integer("ffnChannels");
+    const bool useSwiGLU = r.integer("useSwiGLU") != 0;
+    if(nc < 1 || b.ffnChannels < 1) bad(b.name + ": transformer ffn channels must be positive");
+    b.preLN = parseTRms(r);
+    b.linear1 = parseMatMul(r);
+    if(useSwiGLU) b.linearGate = parseMatMul(r);
+    b.linear2 = parseMatMul(r);
+    if(nc != trunkC || b.preLN.c != trunkC || b.linear1.inC != nc || b.linear1.outC != b.ffnChannels ||
+       (useSwiGLU && (b.linearGate.inC != nc || b.linearGate.outC != b.ffnChannels)) || b.linear2.inC != b.ffnChannels ||
+       b.linear2.outC != nc)
+      bad(b.name + ": transformer ffn channel counts are inconsistent");
+    if(!useSwiGLU)  // the reference's own backends refuse it too (eigenbackend.cpp:1631-1633, cudabackend.cpp:1996)
+      throw ModelError(KMX_ERR_UNSUPPORTED, b.name + ": non-SwiGLU transformer FFN is not supported");
+    return b;
   }
   else
     bad(owner + ": found unknown block kind: " + kind);
@@ -313,7 +377,22 @@ std::vector<BlockDesc> parseStack(Reader& r, int version, int numBlocks, int tru
   return v;
 }
 
+bool anyTransformer(const std::vector<BlockDesc>& blocks) {
+  for(const BlockDesc& b : blocks)
+    if(b.isTransformer() || anyTransformer(b.inner)) return true;
+  return false;
+}
+
 void countBlock(const BlockDesc& b, double& mac, int64_t& params) {
+  if(b.isTransformer()) {
+    // projections only; the QK^T / PV products cost area*numHeads*(qHeadDim+vHeadDim) MACs per point more (board dependent)
+    for(const MatMulDesc* m : {&b.qProj, &b.kProj, &b.vProj, &b.outProj, &b.linear1, &b.linearGate, &b.linear2}) {
+      mac += (double)m->inC * m->outC;
+      params += (int64_t)m->inC * m->outC;
+    }
+    params += b.preLN.c + (int64_t)b.ropeFreqs.size();
+    return;
+  }
   auto conv = [&](const ConvDesc& c) {
     mac += (double)c.ky * c.kx * c.inC * c.outC;
     params += (int64_t)c.ky * c.kx * c.inC * c.outC;
@@ -385,10 +464,9 @@ std::unique_ptr<ModelDesc> ModelDesc::loadFromFile(const std::string& path, cons
     (void)r.integer("dilatedNumChannels");
     m.gpoolC = r.integer("gpoolNumChannels");
     if(m.version >= 15) {
-      int trunkNormKind = r.integer("trunkNormKind");
+      m.trunkNormKind = r.integer("trunkNormKind");
       r.expectZeros(5, "trunk option");
-      if(trunkNormKind != 0)
-        throw ModelError(KMX_ERR_UNSUPPORTED, m.name + ": RMSNorm trunk tips are not supported by the katamx backend");
+      if(m.trunkNormKind < 0 || m.trunkNormKind > 3) bad(trunkName + ": unknown trunkNormKind");
     }
     if(m.numBlocks < 1) bad(trunkName + ": trunk num blocks must be positive");
     if(m.trunkC <= 0 || m.midC <= 0 || m.regularC <= 0 || m.gpoolC <= 0) bad(trunkName + ": all numbers of channels must be positive");
@@ -411,9 +489,25 @@ std::unique_ptr<ModelDesc> ModelDesc::loadFromFile(const std::string& path, cons
         bad(ename + ": sgf metadata encoder channel counts are inconsistent");
     }
     m.blocks = parseStack(r, m.version, m.numBlocks, m.trunkC, trunkName);
-    m.trunkTipBN = parseBn(r);
-    m.trunkTipBN.act = parseAct(r, m.version);
-    if(m.trunkTipBN.c != m.trunkC) bad(trunkName + ": trunkTipBN.numChannels != trunkNumChannels");
+    m.hasTransformerBlocks = anyTransformer(m.blocks);
+    if(m.trunkNormKind == 0) {
+      m.trunkTipBN = parseBn(r);
+      m.trunkTipBN.act = parseAct(r, m.version);
+      if(m.trunkTipBN.c != m.trunkC) bad(trunkName + ": trunkTipBN.numChannels != trunkNumChannels");
+    }
+    else {  // RMSNormLayerDesc, desc.cpp:1069-1095
+      const std::string nname = r.token("trunk tip rmsnorm name");
+      const int c = r.integer("numChannels");
+      m.rmsEps = r.real("epsilon");
+      m.rmsSpatial = r.integer("spatial") != 0;
+      const int cgroup = r.integer("cgroupSize");
+      if(c != m.trunkC) bad(nname + ": numChannels != trunkNumChannels");
+      if(!(m.rmsEps > 0.0f) || m.rmsEps > 1.0f) bad(nname + ": epsilon out of range");
+      if(cgroup != 0) throw ModelError(KMX_ERR_UNSUPPORTED, nname + ": grouped spatial RMSNorm is not supported");
+      m.rmsGamma = r.floats(c, nname);
+      m.rmsBeta = r.floats(c, nname);
+      m.trunkTipAct = parseAct(r, m.version);
+    }
 
     // policy head
     std::string pname = r.token("policy head name");
@@ -499,6 +593,13 @@ std::unique_ptr<ModelDesc> ModelDesc::loadFromFile(const std::string& path, cons
   conv(m.p1Conv); conv(m.g1Conv); conv(m.p2Conv); conv(m.v1Conv); conv(m.vOwnershipConv);
   m.macPerPosition = mac;
   m.numParameters = params;
+  if(m.hasTransformerBlocks || m.trunkNormKind != 0) {
+    // The device kernels for these layers (transformer_kernels.hip) have been written against the oracle but have not
+    // run on hardware yet: until they have, such a net is refused unless the caller opts in explicitly.
+    const char* e = getenv("KMX_EXPERIMENTAL_TRANSFORMER");
+    if(e == nullptr || std::string(e) != "1")
+      throw ModelError(KMX_ERR_UNSUPPORTED, m.name + ": transformer blocks / RMSNorm trunk tips are not supported by the katamx backend yet (convolutional nets only)");
+  }
   return mp;
 }
 

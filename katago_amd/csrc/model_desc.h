@@ -44,7 +44,15 @@ struct MatBiasDesc {
   std::vector<float> w;
 };
 
-enum class BlockKind { Ordinary, GPool, Nested };
+// RMSNorm inside transformer blocks (TransformerRMSNormDesc, desc.cpp:1125-1144): y = x / rms(x over channels) * w
+struct TRmsDesc {
+  std::string name;
+  int c = 0;
+  float eps = 0.0f;
+  std::vector<float> w;
+};
+
+enum class BlockKind { Ordinary, GPool, Nested, Attention, FFN };
 
 struct BlockDesc {
   BlockKind kind = BlockKind::Ordinary;
@@ -56,6 +64,17 @@ struct BlockDesc {
   ConvDesc regularConv, finalConv, gpoolConv;
   MatMulDesc gpoolToBiasMul;
   std::vector<BlockDesc> inner;
+  // Attention (TransformerAttentionDesc, desc.cpp:1173-1258): preLN, qProj/kProj/vProj/outProj, 2D RoPE
+  // FFN       (TransformerFFNDesc, desc.cpp:1371-1405):       preLN, linear1, linearGate (SwiGLU), linear2
+  TRmsDesc preLN;
+  int numHeads = 0, numKVHeads = 0, qHeadDim = 0, vHeadDim = 0;
+  bool useRope = false, learnableRope = false;
+  float ropeTheta = 0.0f;
+  std::vector<float> ropeFreqs;  // learnable: [numKVHeads][qHeadDim/2][2] = (omega_x, omega_y)
+  MatMulDesc qProj, kProj, vProj, outProj;
+  int ffnChannels = 0;
+  MatMulDesc linear1, linearGate, linear2;
+  bool isTransformer() const { return kind == BlockKind::Attention || kind == BlockKind::FFN; }
 };
 
 struct ModelDesc {
@@ -76,6 +95,13 @@ struct ModelDesc {
   int metaAct1 = 0, metaAct2 = 0;
   std::vector<BlockDesc> blocks;
   BnDesc trunkTipBN;
+  // trunkNormKind != 0: the tip is an RMSNorm (RMSNormLayerDesc, desc.cpp:1069-1095) with gamma/beta and an activation;
+  // rmsSpatial: one RMS per board over on-board cells x channels instead of one per cell
+  int trunkNormKind = 0, trunkTipAct = 0;
+  bool rmsSpatial = false;
+  float rmsEps = 0.0f;
+  std::vector<float> rmsGamma, rmsBeta;
+  bool hasTransformerBlocks = false;
 
   ConvDesc p1Conv, g1Conv, p2Conv;
   BnDesc g1BN, p1BN;
