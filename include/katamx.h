@@ -31,8 +31,9 @@ extern "C" {
 #endif
 
 /* 2: + kmx_eval_meta / kmx_eval_device_meta (sgf-metadata nets), kmx_eval_packed / kmx_pack_row (bit-packed inputs),
- *    kmx_handle_set_split_min; kmx_model_info.reserved0 became meta_encoder_version. Additive over 1. */
-#define KMX_ABI_VERSION 2
+ *    kmx_handle_set_split_min; kmx_model_info.reserved0 became meta_encoder_version. Additive over 1.
+ * 3: + kmx_test_rmsnorm / kmx_test_attention / kmx_test_swiglu (experimental unit hooks). Additive over 2. */
+#define KMX_ABI_VERSION 3
 
 typedef enum kmx_status {
   KMX_OK = 0,
@@ -262,6 +263,25 @@ int kmx_test_resblock(const kmx_resblock_desc* desc, int batch, int nn_x_len, in
                       int precision_mode, const float* in_nhwc, const float* mask_nhw, float* out_nhwc);
 int kmx_test_gpoolblock(const kmx_gpoolblock_desc* desc, int batch, int nn_x_len, int nn_y_len,
                         int precision_mode, const float* in_nhwc, const float* mask_nhw, float* out_nhwc);
+
+/* EXPERIMENTAL unit hooks for the layers of model-v17 transformer trunks that are not convolutions (the reference has no
+ * test hook for them; its definitions are TransformerRMSNormLayer / RMSNormLayer, eigenbackend.cpp:867-1034, the attention
+ * of TransformerAttentionBlock::apply, :1376-1600, and the SwiGLU of TransformerFFNBlock::apply, :1674-1689). fp32 NHWC
+ * buffers in and out, like the hooks above. These kernels have not run on hardware yet.
+ *   rmsnorm:   out = act(in / rms * weight + beta) on on-board cells, 0 elsewhere; rms per cell over channels, or
+ *              (per_board) per board over on-board cells x channels; beta may be NULL.
+ *   attention: q [n][S][heads*q_dim], k [n][S][kv_heads*q_dim], v [n][S][kv_heads*v_dim] -> out [n][S][heads*v_dim];
+ *              rope_cos/rope_sin [rope_heads == 1 ? 1 : kv_heads][q_dim/2][S] or NULL; keys with mask 0 are ignored,
+ *              queries with mask 0 give 0.
+ *   swiglu:    out = silu(a) * gate, [n][S][ffn_channels]. */
+int kmx_test_rmsnorm(int batch, int nn_x_len, int nn_y_len, int precision_mode, int num_channels, float epsilon,
+                     const float* weight, const float* beta, int activation, int per_board,
+                     const float* in_nhwc, const float* mask_nhw, float* out_nhwc);
+int kmx_test_attention(int batch, int nn_x_len, int nn_y_len, int precision_mode, int num_heads, int num_kv_heads,
+                       int q_head_dim, int v_head_dim, const float* rope_cos, const float* rope_sin, int rope_heads,
+                       const float* q, const float* k, const float* v, const float* mask_nhw, float* out);
+int kmx_test_swiglu(int batch, int nn_x_len, int nn_y_len, int precision_mode, int ffn_channels,
+                    const float* a, const float* gate, float* out);
 
 #ifdef __cplusplus
 }

@@ -119,6 +119,9 @@ SIGNATURES = {
     "kmx_test_bnact": (ctypes.c_int, [ctypes.POINTER(BnActDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP, _FP]),
     "kmx_test_resblock": (ctypes.c_int, [ctypes.POINTER(ResBlockDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP, _FP]),
     "kmx_test_gpoolblock": (ctypes.c_int, [ctypes.POINTER(GPoolBlockDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP, _FP]),
+    "kmx_test_rmsnorm": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.c_float, _FP, _FP, ctypes.c_int, ctypes.c_int, _FP, _FP, _FP]),
+    "kmx_test_attention": (ctypes.c_int, [ctypes.c_int] * 8 + [_FP, _FP, ctypes.c_int, _FP, _FP, _FP, _FP, _FP]),
+    "kmx_test_swiglu": (ctypes.c_int, [ctypes.c_int] * 5 + [_FP, _FP, _FP]),
 }
 
 _lib = None

@@ -977,4 +977,91 @@ void testGPoolBlock(int dtype, const kmx_gpoolblock_desc* d, int batch, int X, i
   h.toHost(raw, stride, C, out);
 }
 
+// ---- unit hooks for the transformer kernels (experimental; tests/test_gpu_transformer.py) ----
+void testRmsNorm(int dtype, int batch, int X, int Y, int C, float eps, const float* w, const float* beta, int actKind, bool perBoard,
+                 const float* in, const float* mask, float* out) {
+  if(!w || !in || !out || C < 1) throw Error(KMX_ERR_INVALID_ARG, "test rmsnorm: bad argument");
+  HookCtx h(dtype, batch, X, Y, mask);
+  int stride;
+  DevBuf x = h.toDevice(in, C, &stride);
+  DevBuf y((size_t)batch * h.S * stride * 2);
+  DevBuf dw = uploadVec(std::vector<float>(w, w + C));
+  DevBuf db = uploadVec(beta ? std::vector<float>(beta, beta + C) : std::vector<float>(1, 0.0f));
+  DevBuf rms((size_t)batch * sizeof(float));
+  RmsNormArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = x.get(); a.inStride = stride; a.out = y.get(); a.outStride = stride; a.C = C; a.eps = eps;
+  a.w = dw.as<float>(); a.beta = beta ? db.as<float>() : nullptr; a.actKind = actKind;
+  a.mask = h.mask.as<float>(); a.N = batch; a.S = h.S;
+  if(perBoard) {
+    std::vector<float> ms(batch, 0.0f);
+    for(int b = 0; b < batch; b++)
+      for(int p = 0; p < h.S; p++) ms[b] += mask ? mask[(size_t)b * h.S + p] : 1.0f;
+    DevBuf dms = uploadVec(ms);
+    hipCheck(launchBoardRms(dtype, x.get(), stride, C, h.mask.as<float>(), dms.as<float>(), batch, h.S, eps, rms.as<float>(), h.st), "board rms launch");
+    hipCheck(hipStreamSynchronize(h.st), "sync");
+    a.boardRms = rms.as<float>();
+  }
+  hipCheck(launchRmsNorm(dtype, a, h.st), "rmsnorm launch");
+  hipCheck(hipStreamSynchronize(h.st), "sync");
+  h.toHost(y, stride, C, out);
+}
+
+void testAttention(int dtype, int batch, int X, int Y, int H, int KVH, int QD, int VD, const float* ropeCos, const float* ropeSin,
+                   int ropeHeads, const float* q, const float* k, const float* v, const float* mask, float* out) {
+  if(!q || !k || !v || !out || H < 1 || KVH < 1 || QD < 1 || VD < 1 || H % KVH != 0 || (ropeCos != nullptr) != (ropeSin != nullptr))
+    throw Error(KMX_ERR_INVALID_ARG, "test attention: bad argument");
+  if(!attentionDimsSupported(QD, VD)) throw Error(KMX_ERR_UNSUPPORTED, "test attention: head dims above 64");
+  HookCtx h(dtype, batch, X, Y, mask);
+  const int kOff = roundUp(H * QD, 8), vOff = kOff + roundUp(KVH * QD, 8), ctot = vOff + roundUp(KVH * VD, 8);
+  const size_t cells = (size_t)batch * h.S;
+  std::vector<float> cat(cells * ctot, 0.0f);
+  for(size_t c = 0; c < cells; c++) {
+    std::copy(q + c * H * QD, q + (c + 1) * H * QD, cat.begin() + c * ctot);
+    std::copy(k + c * KVH * QD, k + (c + 1) * KVH * QD, cat.begin() + c * ctot + kOff);
+    std::copy(v + c * KVH * VD, v + (c + 1) * KVH * VD, cat.begin() + c * ctot + vOff);
+  }
+  int stride;
+  DevBuf qkv = h.toDevice(cat.data(), ctot, &stride);
+  const int outStride = roundUp(H * VD, 32);
+  DevBuf y(cells * outStride * 2);
+  const size_t tbl = ropeCos ? (size_t)(ropeHeads > 1 ? KVH : 1) * (QD / 2) * h.S : 1;
+  DevBuf dc = uploadVec(ropeCos ? std::vector<float>(ropeCos, ropeCos + tbl) : std::vector<float>(1, 1.0f));
+  DevBuf ds = uploadVec(ropeSin ? std::vector<float>(ropeSin, ropeSin + tbl) : std::vector<float>(1, 0.0f));
+  AttentionArgs a;
+  memset(&a, 0, sizeof(a));
+  a.qkv = qkv.get(); a.stride = stride; a.kOff = kOff; a.vOff = vOff;
+  a.H = H; a.KVH = KVH; a.QD = QD; a.VD = VD;
+  a.ropeCos = ropeCos ? dc.as<float>() : nullptr;
+  a.ropeSin = ropeSin ? ds.as<float>() : nullptr;
+  a.ropeHeads = ropeHeads > 1 ? KVH : 1;
+  a.mask = h.mask.as<float>(); a.out = y.get(); a.outStride = outStride;
+  a.scale = 1.0f / sqrtf((float)QD);
+  a.N = batch; a.S = h.S;
+  hipCheck(launchAttention(dtype, a, h.st), "attention launch");
+  hipCheck(hipStreamSynchronize(h.st), "sync");
+  h.toHost(y, outStride, H * VD, out);
+}
+
+void testSwiGlu(int dtype, int batch, int X, int Y, int F, const float* a1, const float* g, float* out) {
+  if(!a1 || !g || !out || F < 1 || F % 8 != 0) throw Error(KMX_ERR_INVALID_ARG, "test swiglu: bad argument (ffn channels must be a multiple of 8)");
+  HookCtx h(dtype, batch, X, Y, nullptr);
+  const size_t cells = (size_t)batch * h.S;
+  std::vector<float> cat(cells * 2 * F);
+  for(size_t c = 0; c < cells; c++) {
+    std::copy(a1 + c * F, a1 + (c + 1) * F, cat.begin() + c * 2 * F);
+    std::copy(g + c * F, g + (c + 1) * F, cat.begin() + c * 2 * F + F);
+  }
+  int stride;
+  DevBuf x = h.toDevice(cat.data(), 2 * F, &stride);
+  const int outStride = roundUp(F, 32);
+  DevBuf y(cells * outStride * 2);
+  SwiGluArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = x.get(); a.inStride = stride; a.gOff = F; a.F = F; a.out = y.get(); a.outStride = outStride; a.cells = cells;
+  hipCheck(launchSwiGlu(dtype, a, h.st), "swiglu launch");
+  hipCheck(hipStreamSynchronize(h.st), "sync");
+  h.toHost(y, outStride, F, out);
+}
+
 }  // namespace kmx

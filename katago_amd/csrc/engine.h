@@ -199,5 +199,12 @@ void testResBlock(int dtype, const kmx_resblock_desc* d, int batch, int X, int Y
 void testGPoolBlock(int dtype, const kmx_gpoolblock_desc* d, int batch, int X, int Y, const float* in, const float* mask,
                     float* out);
 
+// Unit hooks for the transformer kernels (experimental): fp32 NHWC in/out like the hooks above.
+void testRmsNorm(int dtype, int batch, int X, int Y, int C, float eps, const float* w, const float* beta, int actKind, bool perBoard,
+                 const float* in, const float* mask, float* out);
+void testAttention(int dtype, int batch, int X, int Y, int H, int KVH, int QD, int VD, const float* ropeCos, const float* ropeSin,
+                   int ropeHeads, const float* q, const float* k, const float* v, const float* mask, float* out);
+void testSwiGlu(int dtype, int batch, int X, int Y, int F, const float* a, const float* g, float* out);
+
 }  // namespace kmx
 #endif

@@ -429,4 +429,24 @@ int kmx_test_gpoolblock(const kmx_gpoolblock_desc* desc, int batch, int nn_x_len
   });
 }
 
+int kmx_test_rmsnorm(int batch, int nn_x_len, int nn_y_len, int precision_mode, int num_channels, float epsilon, const float* weight,
+                     const float* beta, int activation, int per_board, const float* in_nhwc, const float* mask_nhw, float* out_nhwc) {
+  return guarded([&] {
+    testRmsNorm(hookDtype(precision_mode), batch, nn_x_len, nn_y_len, num_channels, epsilon, weight, beta, activation, per_board != 0,
+                in_nhwc, mask_nhw, out_nhwc);
+  });
+}
+int kmx_test_attention(int batch, int nn_x_len, int nn_y_len, int precision_mode, int num_heads, int num_kv_heads, int q_head_dim,
+                       int v_head_dim, const float* rope_cos, const float* rope_sin, int rope_heads, const float* q, const float* k,
+                       const float* v, const float* mask_nhw, float* out) {
+  return guarded([&] {
+    testAttention(hookDtype(precision_mode), batch, nn_x_len, nn_y_len, num_heads, num_kv_heads, q_head_dim, v_head_dim, rope_cos,
+                  rope_sin, rope_heads, q, k, v, mask_nhw, out);
+  });
+}
+int kmx_test_swiglu(int batch, int nn_x_len, int nn_y_len, int precision_mode, int ffn_channels, const float* a, const float* gate,
+                    float* out) {
+  return guarded([&] { testSwiGlu(hookDtype(precision_mode), batch, nn_x_len, nn_y_len, ffn_channels, a, gate, out); });
+}
+
 }  // extern "C"

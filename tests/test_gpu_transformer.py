@@ -60,3 +60,149 @@ def test_reference_transformer_nets_vs_oracle(ctx19, net):
     for k in ("policy", "value", "score", "ownership"):
         assert np.array_equal(one[k][0], got[k][5])
     h.close()
+
+
+# ---- unit level: one kernel at a time against numpy restatements of the reference formulas -------------------------
+import ctypes  # noqa: E402
+
+from katago_amd import capi  # noqa: E402
+
+_FP = ctypes.POINTER(ctypes.c_float)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_FP)
+
+
+def _q16(a, dtype):
+    """Round to the device's 16-bit type the way the hooks do on upload, so the comparison isolates the kernel."""
+    import torch
+
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    return t.to(torch.bfloat16 if dtype == "bf16" else torch.float16).to(torch.float32).numpy()
+
+
+def _masks(rng, n, X, Y):
+    m = np.zeros((n, Y, X), np.float32)
+    for b in range(n):
+        ys, xs = (Y, X) if b == 0 else (int(rng.integers(2, Y + 1)), int(rng.integers(2, X + 1)))
+        m[b, :ys, :xs] = 1.0
+    return m.reshape(n, X * Y)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("C,per_board,with_beta,act", [(32, False, False, capi.ACT_IDENTITY), (96, False, False, capi.ACT_IDENTITY),
+                                                         (32, True, True, capi.ACT_MISH), (384, False, True, capi.ACT_SILU),
+                                                         (96, True, True, capi.ACT_RELU)])
+def test_rmsnorm_kernel(dtype, C, per_board, with_beta, act):
+    lib = capi.load_library()
+    rng = np.random.default_rng(C + per_board)
+    n, X, Y = 3, 19, 19
+    S = X * Y
+    mask = _masks(rng, n, X, Y)
+    x = _q16(rng.normal(0, 2.0, (n, S, C)), dtype)
+    w = (1.0 + 0.3 * rng.normal(size=C)).astype(np.float32)
+    beta = (0.2 * rng.normal(size=C)).astype(np.float32) if with_beta else None
+    eps = 1e-6
+    if per_board:
+        ss = (x.astype(np.float64) ** 2 * mask[:, :, None]).sum(axis=(1, 2)) / (mask.sum(axis=1) * C)
+        r = 1.0 / np.sqrt(ss + eps)[:, None, None]
+    else:
+        r = 1.0 / np.sqrt((x.astype(np.float64) ** 2).mean(axis=2, keepdims=True) + eps)
+    y = x * r * w + (beta if beta is not None else 0.0)
+    if act == capi.ACT_RELU:
+        y = np.maximum(y, 0)
+    elif act == capi.ACT_SILU:
+        y = y / (1 + np.exp(-y))
+    elif act == capi.ACT_MISH:
+        y = y * np.tanh(np.log1p(np.exp(np.minimum(y, 20.0))))
+    want = (y * mask[:, :, None]).astype(np.float32)
+    got = np.full((n, S, C), np.nan, np.float32)
+    prec = capi.PREC_BF16 if dtype == "bf16" else capi.PREC_FP16
+    capi.check(lib.kmx_test_rmsnorm(n, X, Y, prec, C, eps, _p(w), _p(beta), act, int(per_board), _p(x), _p(mask), _p(got)), lib)
+    tol = 2.0 ** -7 if dtype == "bf16" else 2.0 ** -10  # one rounding of the output
+    assert np.isfinite(got).all() and np.all(np.abs(got - want) <= tol * np.maximum(1.0, np.abs(want)) * 1.5)
+    assert np.all(got[mask == 0] == 0)
+
+
+def _rope_tables(rng, heads, QD, X, Y, learnable):
+    S, P = X * Y, QD // 2
+    xs, ys = np.meshgrid(np.arange(X), np.arange(Y))
+    ang = np.zeros((heads, P, S), np.float64)
+    for h in range(heads):
+        for p in range(P):
+            if learnable:
+                fx, fy = rng.uniform(-0.7, 0.7, 2)
+                ang[h, p] = (xs * fx + ys * fy).reshape(-1)
+            else:  # desc.cpp:1340-1358: first half of the pairs turns with y, second half with x
+                per = P // 2
+                ang[h, p] = ((ys if p < per else xs) / 100.0 ** (2.0 * (p if p < per else p - per) / P)).reshape(-1)
+    return np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+
+
+def _rope(t, cos, sin, heads_of_table):
+    """t [n][S][Hb][D] -> rotated pairs (2p, 2p+1); cos/sin [tableHeads][P][S]; heads_of_table[h] = table index"""
+    out = t.copy()
+    P = cos.shape[1]
+    for h in range(t.shape[2]):
+        c, s = cos[heads_of_table[h]].T, sin[heads_of_table[h]].T  # [S][P]
+        a, b = t[:, :, h, 0:2 * P:2], t[:, :, h, 1:2 * P:2]
+        out[:, :, h, 0:2 * P:2] = a * c - b * s
+        out[:, :, h, 1:2 * P:2] = a * s + b * c
+    return out
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("H,KVH,QD,VD,rope", [(4, 4, 8, 8, "fixed"), (4, 2, 8, 4, "learnable"), (3, 3, 32, 32, "fixed"),
+                                               (6, 3, 32, 16, "learnable"), (2, 1, 64, 64, "none"), (2, 2, 16, 32, "none")])
+def test_attention_kernel(dtype, H, KVH, QD, VD, rope):
+    lib = capi.load_library()
+    rng = np.random.default_rng(H * 100 + QD)
+    n, X, Y = 3, 19, 19
+    S = X * Y
+    mask = _masks(rng, n, X, Y)
+    q = _q16(rng.normal(0, 1.0, (n, S, H, QD)), dtype)
+    k = _q16(rng.normal(0, 1.0, (n, S, KVH, QD)), dtype)
+    v = _q16(rng.normal(0, 1.0, (n, S, KVH, VD)), dtype)
+    cos = sin = None
+    qr, kr = q, k
+    if rope != "none":
+        th = KVH if rope == "learnable" else 1
+        cos, sin = _rope_tables(rng, th, QD, X, Y, rope == "learnable")
+        qr = _rope(q, cos, sin, [(h * KVH // H) if th > 1 else 0 for h in range(H)])
+        kr = _q16(_rope(k, cos, sin, [h if th > 1 else 0 for h in range(KVH)]), dtype)  # the kernel keeps rotated K in 16 bits
+    want = np.zeros((n, S, H, VD), np.float64)
+    for b in range(n):
+        on = mask[b] > 0
+        for h in range(H):
+            g = h // (H // KVH)
+            logits = (qr[b, :, h].astype(np.float64) @ kr[b, on, g].astype(np.float64).T) / np.sqrt(QD)
+            p = np.exp(logits - logits.max(axis=1, keepdims=True))
+            p /= p.sum(axis=1, keepdims=True)
+            want[b, :, h] = (p @ v[b, on, g].astype(np.float64)) * mask[b][:, None]
+    got = np.full((n, S, H * VD), np.nan, np.float32)
+    prec = capi.PREC_BF16 if dtype == "bf16" else capi.PREC_FP16
+    capi.check(lib.kmx_test_attention(n, X, Y, prec, H, KVH, QD, VD, _p(cos), _p(sin), 1 if rope != "learnable" else KVH,
+                                      _p(q.reshape(n, S, -1)), _p(k.reshape(n, S, -1)), _p(v.reshape(n, S, -1)), _p(mask), _p(got)), lib)
+    err = np.abs(got.reshape(n, S, H, VD) - want)
+    tol = 2.0 ** -7 if dtype == "bf16" else 2.0 ** -10
+    print("attention max err %.4g (scale %.3g)" % (err.max(), np.abs(want).max()))
+    assert np.isfinite(got).all() and err.max() <= 3 * tol * max(1.0, np.abs(want).max())
+    assert np.all(got[mask == 0] == 0)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("F", [48, 256])
+def test_swiglu_kernel(dtype, F):
+    lib = capi.load_library()
+    rng = np.random.default_rng(F)
+    n, X, Y = 2, 13, 9
+    S = X * Y
+    a = _q16(rng.normal(0, 2.0, (n, S, F)), dtype)
+    g = _q16(rng.normal(0, 2.0, (n, S, F)), dtype)
+    want = a / (1 + np.exp(-a.astype(np.float64))) * g
+    got = np.full((n, S, F), np.nan, np.float32)
+    prec = capi.PREC_BF16 if dtype == "bf16" else capi.PREC_FP16
+    capi.check(lib.kmx_test_swiglu(n, X, Y, prec, F, _p(a), _p(g), _p(got)), lib)
+    tol = 2.0 ** -7 if dtype == "bf16" else 2.0 ** -10
+    assert np.all(np.abs(got - want) <= 1.5 * tol * np.maximum(1.0, np.abs(want)))
