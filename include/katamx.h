@@ -214,6 +214,11 @@ int kmx_handle_get_profile(kmx_handle* handle, kmx_profile_entry* entries, int m
  * epilogue_mode 0 = BN+act output, 1 = residual + raw + BN+act outputs. Kernel tuning instrumentation. */
 int kmx_bench_conv(int ks, int wn, int variant, int cin, int cout, int batch, int nn_x_len, int nn_y_len,
                    int epilogue_mode, int iters, double* avg_ms);
+/* Host-only introspection of the convolution launcher (no device needed): the work-group shape chosen for a kernel size,
+ * a padded channel count (multiple of 64) and a batch, and whether a kernel of that shape exists and tiles the channels.
+ * tests/test_conv_chooser.py walks every combination the engine can ask for. */
+int kmx_debug_conv_cfg(int ks, int cout_pad, int batch, int* cfg, int* instantiated);
+
 /* MFMA issue-rate microbenchmark (v_mfma_f32_32x32x16_bf16, 18 per step as in the convolution): mode bit 1 adds an
  * s_barrier per step, bit 2 adds the step's 12 ds_read_b128. Reports the rate and the shader clock it ran at: the
  * practical ceiling the convolution is measured against. Kernel tuning instrumentation. */

@@ -114,6 +114,7 @@ SIGNATURES = {
     "kmx_handle_get_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ProfileEntry), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "kmx_handle_set_split_min": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "kmx_bench_conv": (ctypes.c_int, [ctypes.c_int] * 10 + [ctypes.POINTER(ctypes.c_double)]),
+    "kmx_debug_conv_cfg": (ctypes.c_int, [ctypes.c_int] * 3 + [_IP, _IP]),
     "kmx_bench_mfma": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_double)] * 3),
     "kmx_test_conv": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP]),
     "kmx_test_bnact": (ctypes.c_int, [ctypes.POINTER(BnActDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP, _FP]),

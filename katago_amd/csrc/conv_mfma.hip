@@ -10,16 +10,21 @@ using namespace convk;
 
 // cfg = 10*WNW + WN : WNW = waves along the channel dimension (1: 4-wave work-group, 2: 8-wave), WN = 32-channel
 // tiles per wave; a work-group covers 32*WN*WNW output channels of one board.
+// The instantiated (kernel size, WNW, WN, ring depth) combinations: one list for the dispatcher and for
+// convCfgInstantiated(), which the chooser and tests/test_conv_chooser.py check against.
+#define KMX_CFG_LIST(X)                      \
+  X(3, 1, 1, 2) X(3, 1, 2, 2) X(3, 1, 3, 2)  \
+  X(3, 2, 2, 3) X(3, 2, 3, 3)                \
+  X(1, 1, 1, 2) X(1, 1, 2, 2) X(1, 1, 3, 2)  \
+  X(1, 2, 2, 3) X(1, 2, 3, 3)                \
+  X(5, 1, 1, 2) X(5, 1, 2, 2) X(5, 1, 3, 2)  \
+  X(5, 2, 2, 2)
+
 template <class TR>
 hipError_t launchT(int ks, int cfg, const ConvArgs& a, hipStream_t stream) {
 #define KMX_CFG(KS_, WNW_, WN_, D_) \
   if(ks == KS_ && cfg == 10 * WNW_ + WN_) return launchOne<TR, KS_, WN_, WNW_, D_, 0>(a, stream);
-  KMX_CFG(3, 1, 1, 2) KMX_CFG(3, 1, 2, 2) KMX_CFG(3, 1, 3, 2)
-  KMX_CFG(3, 2, 2, 3) KMX_CFG(3, 2, 3, 3)
-  KMX_CFG(1, 1, 1, 2) KMX_CFG(1, 1, 2, 2) KMX_CFG(1, 1, 3, 2)
-  KMX_CFG(1, 2, 2, 3) KMX_CFG(1, 2, 3, 3)
-  KMX_CFG(5, 1, 1, 2) KMX_CFG(5, 1, 2, 2) KMX_CFG(5, 1, 3, 2)
-  KMX_CFG(5, 2, 2, 2)
+  KMX_CFG_LIST(KMX_CFG)
 #undef KMX_CFG
   return hipErrorInvalidValue;
 }
@@ -32,6 +37,14 @@ hipError_t launchConv(int dtype, int ks, int cfg, const ConvArgs& a, hipStream_t
   if(dtype == DT_F16) return launchT<TraitsF16>(ks, cfg, a, stream);
   if(dtype == DT_BF16) return launchT<TraitsBF16>(ks, cfg, a, stream);
   return hipErrorInvalidValue;
+}
+
+bool convCfgInstantiated(int ks, int cfg) {
+#define KMX_CFG(KS_, WNW_, WN_, D_) \
+  if(ks == KS_ && cfg == 10 * WNW_ + WN_) return true;
+  KMX_CFG_LIST(KMX_CFG)
+#undef KMX_CFG
+  return false;
 }
 
 // Work-group shape for a convolution with coutPad (a multiple of 32) output channels on `batch` boards (the caller
@@ -47,7 +60,9 @@ int chooseConvCfg(int ks, int coutPad, int batch) {
     const char* e = getenv("KMX_MIN_WGS8");
     return e ? atoi(e) : 150;
   }();
-  auto fits = [&](int cfg) { return tiles % ((cfg / 10) * (cfg % 10)) == 0 && !(ks == 1 && cfg == 13); };
+  // a shape is a candidate if it tiles the channels AND exists for this kernel size (5x5 has no 8-wave x 192 shape: its
+  // ring would not fit the LDS); 1x1 never uses the 4-wave x 96 shape (measured slower than 4-wave x 64)
+  auto fits = [&](int cfg) { return tiles % ((cfg / 10) * (cfg % 10)) == 0 && convCfgInstantiated(ks, cfg) && !(ks == 1 && cfg == 13); };
   auto wgs = [&](int cfg) { return batch * (tiles / ((cfg / 10) * (cfg % 10))); };
   const int widest8 = fits(23) ? 23 : fits(22) ? 22 : 0;
   if(widest8 && wgs(widest8) >= minWgs8) return widest8;

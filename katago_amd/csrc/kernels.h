@@ -55,6 +55,7 @@ struct ConvArgs {
 // tiles per wave). Returns hipSuccess or an error (unsupported combination -> hipErrorInvalidValue).
 hipError_t launchConv(int dtype, int ks, int cfg, const ConvArgs& a, hipStream_t stream);
 int chooseConvCfg(int ks, int coutPad, int batch);
+bool convCfgInstantiated(int ks, int cfg);  // is there a kernel for this (kernel size, shape)?
 
 // Input staging: fp32 NHWC rows (not symmetrised) -> T[N][S][32] symmetrised + mask + maskSum +
 // ncBias[n][C] = W_global^T * global[n]   (copyInputsWithSymmetry nninputs.cpp:529-597, Model::apply

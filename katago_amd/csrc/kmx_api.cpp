@@ -384,6 +384,16 @@ int kmx_bench_conv(int ks, int wn, int variant, int cin, int cout, int batch, in
   });
 }
 
+int kmx_debug_conv_cfg(int ks, int cout_pad, int batch, int* cfg, int* instantiated) {
+  return guarded([&] {
+    if(!cfg || !instantiated || cout_pad < 64 || cout_pad % 64 != 0 || batch < 1 || (ks != 1 && ks != 3 && ks != 5))
+      throw Error(KMX_ERR_INVALID_ARG, "kmx_debug_conv_cfg: bad argument");
+    *cfg = chooseConvCfg(ks, cout_pad, batch);
+    const int ntile = 32 * (*cfg / 10) * (*cfg % 10);
+    *instantiated = (convCfgInstantiated(ks, *cfg) && cout_pad % ntile == 0) ? 1 : 0;
+  });
+}
+
 int kmx_bench_mfma(int waves_per_wg, int wgs, int mode, int steps, int iters, double* avg_ms, double* tflops, double* core_mhz) {
   return guarded([&] {
     if(!avg_ms || iters < 1 || steps < 1 || wgs < 1 || waves_per_wg < 1 || waves_per_wg > 8)

@@ -1,0 +1,34 @@
+"""Host logic of the convolution launcher, no GPU: for every (kernel size, padded channel count, batch) the engine can
+ask for, chooseConvCfg must name a work-group shape for which a kernel is instantiated and which tiles the channels —
+otherwise the launch fails at run time with hipErrorInvalidValue (found this way: 5x5 stems of 192-channel v8 nets at
+batch >= 150 used to pick an 8-wave x 192 shape that only exists for 1x1 and 3x3)."""
+import ctypes
+
+import pytest
+
+from katago_amd import capi
+
+
+def test_every_choice_is_launchable():
+    lib = capi.load_library()
+    cfg, ok = ctypes.c_int(), ctypes.c_int()
+    seen = {}
+    for ks in (1, 3, 5):
+        for cout_pad in range(64, 1536 + 1, 64):
+            for batch in list(range(1, 66)) + [96, 112, 128, 149, 150, 151, 192, 224, 255, 256, 300, 420, 421, 512, 1024, 2048]:
+                capi.check(lib.kmx_debug_conv_cfg(ks, cout_pad, batch, ctypes.byref(cfg), ctypes.byref(ok)), lib)
+                assert ok.value == 1, (ks, cout_pad, batch, cfg.value)
+                seen.setdefault(ks, set()).add(cfg.value)
+    assert seen[3] >= {11, 12, 13, 22, 23} and seen[1] >= {11, 12, 22, 23} and seen[5] >= {11, 12, 13, 22}
+    assert 23 not in seen[5] and 13 not in seen[1]
+
+
+def test_baseline_shapes_unchanged():
+    """The b18c384nbt layers at batch 256 (128 per stream x 2 streams) keep the shapes the measurements were taken with."""
+    lib = capi.load_library()
+    cfg, ok = ctypes.c_int(), ctypes.c_int()
+    for ks, cout_pad, want in ((3, 192, 23), (1, 384, 23), (1, 192, 23), (3, 384, 23), (1, 256, 22)):
+        capi.check(lib.kmx_debug_conv_cfg(ks, cout_pad, 256, ctypes.byref(cfg), ctypes.byref(ok)), lib)
+        assert (cfg.value, ok.value) == (want, 1), (ks, cout_pad, cfg.value)
+    for bad in ((2, 64, 1), (3, 100, 1), (3, 64, 0)):
+        assert lib.kmx_debug_conv_cfg(bad[0], bad[1], bad[2], ctypes.byref(cfg), ctypes.byref(ok)) == capi.KMX_ERR_INVALID_ARG
