@@ -206,3 +206,61 @@ def test_swiglu_kernel(dtype, F):
     capi.check(lib.kmx_test_swiglu(n, X, Y, prec, F, _p(a), _p(g), _p(got)), lib)
     tol = 2.0 ** -7 if dtype == "bf16" else 2.0 ** -10
     assert np.all(np.abs(got - want) <= 1.5 * tol * np.maximum(1.0, np.abs(want)))
+
+
+# ---- the reference's own cross-backend harness on the trained transformer nets ---------------------------------------
+import re  # noqa: E402
+import subprocess  # noqa: E402
+
+from conftest import ref_binary  # noqa: E402
+from test_gpu_reference_harness import BENCH_CFG  # noqa: E402
+
+TF_NETS = ["b7c96h3tfrs-test5-cnorm.bin.gz", "b7c96h6kv3qk32v16tflrs-fson-bnh.bin.gz"]
+_MARGIN = r": ((?:batched )?(?:fp32|current cfg)) error vs reference closest margin:\s+([\d.eE+-]+)x of limit"
+
+
+def _reference_file(tmp_path, net):
+    cfg = tmp_path / "bench.cfg"
+    cfg.write_text(BENCH_CFG + "homeDataDir = %s\n" % (tmp_path / "home"))
+    ref = str(tmp_path / "ref.txt")
+    args = ["testgpuerror", "-model", os.path.join(REF_MODELS, net), "-config", str(cfg), "-boardsize", "9", "-quick", "-reference-file", ref]
+    r = subprocess.run([ref_binary("katago_oracle")] + args, capture_output=True, text=True, timeout=1800, cwd=str(tmp_path))
+    assert r.returncode == 0 and os.path.getsize(ref) > 100000, (r.stdout + r.stderr)[-2000:]
+    return args
+
+
+@pytest.mark.parametrize("net", TF_NETS)
+def test_oracle_transformer_agrees_with_reference_opencl_backend(tmp_path, net):
+    """The ORACLE's attention / FFN / RMSNorm against the reference's own GPU implementation of them (its OpenCL backend,
+    neuralnet/openclbackend.cpp:2300-2900) on trained nets, through the reference's `testgpuerror -reference-file`: the
+    fp32 rows have to sit at rounding level, as they do for the convolutional net (0.0009x of the limit)."""
+    if not os.path.exists(os.path.join(REF_MODELS, net)):
+        pytest.skip("reference test nets not packaged")
+    try:
+        ocl = ref_binary("katago_opencl")
+    except Exception:
+        pytest.skip("reference OpenCL build not present")
+    args = _reference_file(tmp_path, net)
+    r = subprocess.run([ocl] + args, capture_output=True, text=True, timeout=2400, cwd=str(tmp_path))
+    out = r.stdout + r.stderr
+    if "No OpenCL" in out or "clGetPlatformIDs" in out:
+        pytest.skip("no OpenCL platform on this box")
+    assert "Loaded reference values for" in out, out[-3000:]
+    margins = {k: float(v) for k, v in re.findall(_MARGIN, out)}
+    print(net, margins, "exit code", r.returncode)
+    assert margins.get("fp32", 1.0) < 0.05 and margins.get("batched fp32", 1.0) < 0.05, (margins, out[-1500:])
+
+
+@pytest.mark.parametrize("net", TF_NETS)
+def test_reference_gpuerror_acceptance_transformer_on_hip(tmp_path, net):
+    """`testgpuerror` on the katamx backend for the transformer nets, bf16, against the reduced-precision limits."""
+    if not os.path.exists(os.path.join(REF_MODELS, net)):
+        pytest.skip("reference test nets not packaged")
+    args = _reference_file(tmp_path, net)
+    r = subprocess.run([ref_binary("katago_hip")] + args + ["-override-config", "katamxPrecision=bf16"], capture_output=True, text=True,
+                       timeout=900, cwd=str(tmp_path))
+    out = r.stdout + r.stderr
+    assert "Loaded reference values for" in out, out[-3000:]
+    margins = {k: float(v) for k, v in re.findall(_MARGIN, out)}
+    print(net, margins)
+    assert len(margins) == 4 and margins["current cfg"] < 1.0 and margins["batched current cfg"] < 1.0, (margins, out[-1500:])
