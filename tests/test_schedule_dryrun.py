@@ -1,0 +1,153 @@
+"""The launch schedule, checked without a GPU. tests/fakehip/fakehip.cpp stands in for the HIP runtime (LD_PRELOAD): device
+memory is host memory, kernels are not executed, every launch is logged — kernel, grid, block, LDS bytes, every byte of
+the argument struct with pointers rewritten as buffer-ordinal+offset, and a content hash of every buffer (weights!) when
+it first appears. tests/fakehip/run_schedule.py drives libkatamx.so through kmx_eval for a list of batch sizes.
+
+Two uses:
+  * regression guard for the convolutional nets: the md5 of the log must equal tests/golden/schedule_md5.json, which was
+    generated with the library built from the last commit whose kernels and schedule ran green on the MI355X (126 -m gpu
+    tests). A refactor of the engine that changes any launch argument, any weight re-tiling or the shape chooser shows up
+    here before it reaches a GPU. (Regenerate deliberately with `python tests/test_schedule_dryrun.py --regenerate`.)
+  * the transformer schedule (off by default) is constructed and walked: strides, offsets and LDS
+    sizes of every launch are checked against the model's dimensions."""
+import hashlib
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+FAKE_DIR = os.path.join(REPO, "tests", "fakehip")
+GOLDEN = os.path.join(REPO, "tests", "golden", "schedule_md5.json")
+LIB = os.path.join(REPO, "katago_amd", "libkatamx.so")
+# (architecture, modelgen keywords, max batch, batch sizes): small batches pick the narrow shapes, 224+ is split in two
+CASES = {
+    "b3c64nbt_v15": ("b3c64nbt", {}, 256, [1, 7, 64, 150, 223, 224, 256]),
+    "b6c96_v8": ("b6c96", {"version": 8}, 256, [1, 7, 64, 150, 223, 224, 256]),
+    "b10c128_v14": ("b10c128", {"version": 14}, 256, [1, 7, 64, 150, 223, 224, 256]),
+    "b2c32nbt_v16": ("b2c32nbt", {"version": 16}, 256, [1, 7, 64, 150, 223, 224, 256]),
+    "b18c384nbt_v15": ("b18c384nbt", {}, 256, [1, 7, 64, 150, 223, 224, 256]),
+}
+
+
+def build_fakehip(out_dir):
+    so = os.path.join(out_dir, "libfakehip.so")
+    cmd = ["/opt/rocm/bin/hipcc", "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+           "-DKMX_FAKEHIP_TRANSFORMER", "-o", so, os.path.join(FAKE_DIR, "fakehip.cpp")]
+    subprocess.run(cmd, check=True, capture_output=True)
+    return so
+
+
+def dry_run(fake_so, model_path, max_batch, sizes, log_path, env_extra=None, lib=LIB):
+    env = dict(os.environ, LD_PRELOAD=fake_so, KMX_FAKEHIP_LOG=log_path)
+    env.pop("KMX_EXPERIMENTAL_TRANSFORMER", None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(FAKE_DIR, "run_schedule.py"), lib, model_path, str(max_batch)] + [str(s) for s in sizes],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and "done" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+    return open(log_path).read()
+
+
+def generate(case, tmp_dir, fake_so, lib=LIB):
+    from katago_amd import modelgen
+
+    arch, kw, max_batch, sizes = CASES[case]
+    model = os.path.join(tmp_dir, case + ".bin")
+    modelgen.write_model(model, arch, seed=1, **kw)
+    log = dry_run(fake_so, model, max_batch, sizes, os.path.join(tmp_dir, case + ".log"), lib=lib)
+    return hashlib.md5(log.encode()).hexdigest(), log
+
+
+@pytest.fixture(scope="module")
+def fake_so(tmp_path_factory):
+    return build_fakehip(str(tmp_path_factory.mktemp("fakehip")))
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_convnet_schedule_matches_the_gpu_verified_one(case, fake_so, tmp_path):
+    golden = json.load(open(GOLDEN))
+    digest, log = generate(case, str(tmp_path), fake_so)
+    launches = [l for l in log.splitlines() if l.startswith("launch ")]
+    assert len(launches) > 50
+    assert digest == golden["md5"][case], "launch log of %s differs from the GPU-verified schedule (%d launches)" % (case, len(launches))
+
+
+def _fields(line):
+    m = re.match(r"launch (\S+) grid (\d+),(\d+),(\d+) block (\d+) lds (\d+) args(.*)", line)
+    return m.group(1), tuple(int(m.group(i)) for i in (2, 3, 4)), int(m.group(5)), int(m.group(6)), m.group(7).split()
+
+
+@pytest.mark.parametrize("name,C,H,KVH,QD,VD,F,blocks", [("torch_tfa", 32, 4, 4, 8, 8, 48, ("attn", "ffn", "attn", "ffn")),
+                                                           ("torch_tfb", 32, 4, 2, 8, 4, 48, None)])
+def test_transformer_schedule_is_consistent(name, C, H, KVH, QD, VD, F, blocks, fake_so, tmp_path):
+    model = os.path.join(REPO, "tests", "golden", name + ".bin.gz")
+    n = 3
+    log = dry_run(fake_so, model, 8, [n], str(tmp_path / "tf.log"), {"KMX_EXPERIMENTAL_TRANSFORMER": "1"})
+    launches = [_fields(l) for l in log.splitlines() if l.startswith("launch ")]
+    kinds = [("attention" if "attentionKernel" in k else "rmsnorm" if "rmsNormKernel" in k else "boardrms" if "boardRmsKernel" in k else
+              "swiglu" if "swiGluKernel" in k else "conv" if "convMfmaKernel" in k else "other") for k, *_ in launches]
+    S = 361
+    att = [l for l, k in zip(launches, kinds) if k == "attention"]
+    assert att
+    for kname, grid, block, lds, args in att:
+        if name == "torch_tfb" and "Li8ELi8E" not in kname:
+            continue  # the nested transformer block of tfb runs at c_mid with its own head dims
+        assert grid[1] == n and block == 192
+    if blocks is not None:
+        # per block: rmsnorm, fused projection conv, attention|swiglu, residual conv; then the tip rmsnorm
+        body = kinds[2:2 + 4 * len(blocks)]
+        want = []
+        for b in blocks:
+            want += ["rmsnorm", "conv", "attention" if b == "attn" else "swiglu", "conv"]
+        assert body == want and kinds[2 + 4 * len(blocks)] == "rmsnorm"
+        kname, grid, block, lds, args = att[0]
+        assert grid == (H, n, 1) and lds == S * (8 + 8) * 2 + S * 4
+        qkv_stride = int(args[1], 16) & 0xFFFFFFFF
+        k_off = int(args[1], 16) >> 32
+        v_off = int(args[2], 16) & 0xFFFFFFFF
+        assert (qkv_stride, k_off, v_off) == (96, H * QD, H * QD + KVH * QD)
+        assert int(args[2], 16) >> 32 == H and int(args[3], 16) == (QD << 32 | KVH) and int(args[4], 16) == VD
+        sw = [l for l, k in zip(launches, kinds) if k == "swiglu"][0]
+        assert int(sw[4][1], 16) == (F << 32 | 2 * F) and int(sw[4][2], 16) == F and int(sw[4][5], 16) == n * S
+    else:
+        assert "boardrms" in kinds and kinds.count("attention") == 3  # two inside the nested block, one in the trunk
+    # every convolution tiles its padded channels with the chosen shape
+    for (kname, grid, block, lds, args), k in zip(launches, kinds):
+        if k == "conv":
+            m = re.search(r"ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi0EEE", kname)
+            ks, wn, wnw = int(m.group(1)), int(m.group(2)), int(m.group(3))
+            cout_pad = int(args[4], 16) & 0xFFFFFFFF
+            assert grid == (cout_pad // (32 * wn * wnw), n, 1) and block == 256 * wnw and lds <= 160 * 1024
+
+
+def test_reference_transformer_nets_build_a_schedule(fake_so, tmp_path):
+    d = os.path.join(REPO, "oracle", "_ref", "models")
+    nets = [os.path.join(d, f) for f in ("b7c96h3tfrs-test5-cnorm.bin.gz", "b7c96h6kv3qk32v16tflrs-fson-bnh.bin.gz")]
+    if not all(os.path.exists(p) for p in nets):
+        pytest.skip("reference test nets not packaged")
+    for p, head in zip(nets, ("Li32ELi32E", "Li32ELi16E")):
+        log = dry_run(fake_so, p, 16, [16], str(tmp_path / "ref.log"), {"KMX_EXPERIMENTAL_TRANSFORMER": "1"})
+        att = [l for l in log.splitlines() if l.startswith("launch ") and "attentionKernel" in l]
+        assert len(att) == 7 and all(head in l for l in att)
+    # and without the opt-in the loader refuses them, dry run or not
+    env = dict(os.environ, LD_PRELOAD=fake_so, KMX_FAKEHIP_LOG=str(tmp_path / "no.log"))
+    env.pop("KMX_EXPERIMENTAL_TRANSFORMER", None)
+    r = subprocess.run([sys.executable, os.path.join(FAKE_DIR, "run_schedule.py"), LIB, nets[0], "8", "1"], capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "not supported" in (r.stdout + r.stderr)
+
+
+if __name__ == "__main__":
+    if "--regenerate" in sys.argv:
+        import tempfile
+
+        lib = sys.argv[sys.argv.index("--lib") + 1] if "--lib" in sys.argv else LIB
+        tmp = tempfile.mkdtemp(prefix="kmxsched")
+        so = build_fakehip(tmp)
+        out = {"generated_with": lib, "md5": {c: generate(c, tmp, so, lib=lib)[0] for c in sorted(CASES)}}
+        json.dump(out, open(GOLDEN, "w"), indent=1, sort_keys=True)
+        print(json.dumps(out, indent=1))
