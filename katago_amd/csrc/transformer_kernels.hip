@@ -107,7 +107,7 @@ template <class TR, int QDP, int VDP>
 __global__ __launch_bounds__(192) void attentionKernel(AttentionArgs a) {
   typedef typename TR::T T;
   typedef typename TR::V8 V8;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smemAttn[];
+  HIP_DYNAMIC_SHARED(f32x4, smemAttn)  // dynamic LDS; the 16-byte element type carries the alignment the V8 reads need
   const int S = a.S, h = blockIdx.x, n = blockIdx.y;
   const int kvh = h / (a.H / a.KVH);
   T* const Ks = (T*)smemAttn;                            // [S][QDP]

@@ -1,0 +1,74 @@
+// TEST INFRASTRUCTURE: a host-side stand-in for <hip/hip_runtime.h> under which the plain-C++ device kernels of
+// katago_amd/csrc/transformer_kernels.hip compile for x86 and RUN on the CPU (tests/fakehip/emulate_transformer.cpp):
+// a work-group is a set of OS threads, __syncthreads a std::barrier, __shfl_xor an exchange through a per-wave array,
+// dynamic LDS a static buffer, work-groups run one after the other. Only what those kernels use is provided.
+#pragma once
+#include <barrier>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <thread>
+#include <vector>
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorInvalidDevice = 101 };
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+
+namespace emu {
+struct Idx { unsigned x, y, z; };
+struct Wave {
+  float buf[64];
+  std::unique_ptr<std::barrier<>> bar;
+};
+struct Block {
+  std::unique_ptr<std::barrier<>> bar;
+  std::vector<Wave> waves;
+};
+extern thread_local Idx tIdx, bIdx, bDim, gDim;
+extern thread_local Block* cur;
+extern thread_local bool dropped;
+void* dynLds();
+void launchImpl(dim3 grid, dim3 block, const std::function<void()>& body);
+}  // namespace emu
+
+#define threadIdx (emu::tIdx)
+#define blockIdx (emu::bIdx)
+#define blockDim (emu::bDim)
+#define gridDim (emu::gDim)
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+#define HIP_DYNAMIC_SHARED(type, var) type* const var = (type*)emu::dynLds();
+#define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) emu::launchImpl(grid, block, [&] { kern(__VA_ARGS__); })
+// matrix-core builtins appear in the element traits (device_common.h) but are never called by the emulated kernels
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) (c)
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) (c)
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+
+inline void __syncthreads() { emu::cur->bar->arrive_and_wait(); }
+inline float __shfl_xor(float v, int laneMask) {
+  emu::Wave& w = emu::cur->waves[emu::tIdx.x >> 6];
+  const unsigned lane = emu::tIdx.x & 63;
+  w.buf[lane] = v;
+  w.bar->arrive_and_wait();
+  const float r = w.buf[lane ^ (unsigned)laneMask];
+  w.bar->arrive_and_wait();
+  return r;
+}
