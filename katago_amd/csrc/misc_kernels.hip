@@ -89,7 +89,7 @@ __global__ __launch_bounds__(BT) void inputExpandKernel(const InputArgs a) {
     return;
   }
   // sgf-metadata encoder: a 3-layer MLP per board whose output joins the global-feature bias
-  extern __shared__ float metaSm[];  // in[metaIn], h1[metaC1], h2[metaC2]
+  HIP_DYNAMIC_SHARED(float, metaSm)  // in[metaIn], h1[metaC1], h2[metaC2]
   float* in = metaSm;
   float* h1 = in + a.metaIn;
   float* h2 = h1 + a.metaC1;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(BT) void inputExpandKernel(const InputArgs a) {
 // ------------------------------------------------------------------------------------------------
 template <class TR>
 __global__ __launch_bounds__(BT) void gpoolApplyKernel(const GPoolArgs a) {
-  extern __shared__ float sm[];
+  HIP_DYNAMIC_SHARED(float, sm)
   // layout: partSum[BT], partMax[BT], feat[3G], biasv[R]
   float* partSum = sm;
   float* partMax = sm + BT;
@@ -190,7 +190,7 @@ template <class TR>
 __global__ __launch_bounds__(GV_THREADS) void gpoolApplyVecKernel(const GPoolArgs a) {
   typedef typename TR::T T;
   typedef typename TR::V8 V8;
-  extern __shared__ float sm[];
+  HIP_DYNAMIC_SHARED(float, sm)
   const int n = blockIdx.x, tid = threadIdx.x;
   const int S = a.S, G = a.G, R = a.R;
   const int NG = G / 8;                    // channel groups of 8
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(GV_THREADS) void gpoolApplyVecKernel(const GPoolArg
 // ------------------------------------------------------------------------------------------------
 template <class TR>
 __global__ __launch_bounds__(BT) void policyFinalKernel(const PolicyArgs a) {
-  extern __shared__ float sm[];
+  HIP_DYNAMIC_SHARED(float, sm)
   float* hidden = sm;  // passHidden floats
   const int n = blockIdx.x, tid = threadIdx.x;
   const int S = a.X * a.Y, P = a.P, NP = a.NP;
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(BT) void policyFinalKernel(const PolicyArgs a) {
 // ------------------------------------------------------------------------------------------------
 template <class TR>
 __global__ __launch_bounds__(BT) void valueFinalKernel(const ValueArgs a) {
-  extern __shared__ float sm[];
+  HIP_DYNAMIC_SHARED(float, sm)
   // layout: part[BT], feat[3*V1], h[V2]
   float* part = sm;
   float* feat = sm + BT;
@@ -460,7 +460,7 @@ template <class TR>
 __global__ __launch_bounds__(BT) void policyFinalVecKernel(const PolicyArgs a) {
   typedef typename TR::T T;
   typedef typename TR::V8 V8;
-  extern __shared__ float sm[];
+  HIP_DYNAMIC_SHARED(float, sm)
   const int n = blockIdx.x, tid = threadIdx.x;
   const int S = a.X * a.Y, P = a.P, NP = a.NP, H = a.passHidden;
   float* w2s = sm;               // [P][NP]
@@ -531,7 +531,7 @@ template <class TR>
 __global__ __launch_bounds__(BT) void valueFinalVecKernel(const ValueArgs a) {
   typedef typename TR::T T;
   typedef typename TR::V8 V8;
-  extern __shared__ float sm[];
+  HIP_DYNAMIC_SHARED(float, sm)
   const int n = blockIdx.x, tid = threadIdx.x;
   const int S = a.X * a.Y, V1 = a.V1, V2 = a.V2;
   const int NG = V1 / 8;          // channel groups of 8

@@ -8,44 +8,7 @@
 
 #include "../../katago_amd/csrc/transformer_kernels.hip"
 
-namespace emu {
-thread_local Idx tIdx, bIdx, bDim, gDim;
-thread_local Block* cur = nullptr;
-thread_local bool dropped = false;
-void* dynLds() {
-  alignas(256) static unsigned char lds[160 * 1024];
-  return lds;
-}
-void launchImpl(dim3 grid, dim3 block, const std::function<void()>& body) {
-  const unsigned nt = block.x;
-  for(unsigned bz = 0; bz < grid.z; bz++)
-    for(unsigned by = 0; by < grid.y; by++)
-      for(unsigned bx = 0; bx < grid.x; bx++) {
-        Block blk;
-        blk.bar.reset(new std::barrier<>(nt));
-        blk.waves.resize((nt + 63) / 64);
-        for(unsigned w = 0; w < blk.waves.size(); w++) {
-          const unsigned lanes = nt - w * 64 < 64 ? nt - w * 64 : 64;
-          blk.waves[w].bar.reset(new std::barrier<>(lanes));
-        }
-        std::vector<std::thread> threads;
-        threads.reserve(nt);
-        for(unsigned t = 0; t < nt; t++)
-          threads.emplace_back([&, t] {
-            tIdx = Idx{t, 0, 0};
-            bIdx = Idx{bx, by, bz};
-            bDim = Idx{nt, 1, 1};
-            gDim = Idx{grid.x, grid.y, grid.z};
-            cur = &blk;
-            body();
-            // a thread that has left the kernel no longer takes part in barriers or shuffles
-            blk.bar->arrive_and_drop();
-            blk.waves[t >> 6].bar->arrive_and_drop();
-          });
-        for(std::thread& th : threads) th.join();
-      }
-}
-}  // namespace emu
+#include "emul/emu_runtime.inc"
 
 namespace {
 using namespace kmx;

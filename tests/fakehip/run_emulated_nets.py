@@ -1,0 +1,80 @@
+"""Runs whole nets through the CPU-emulated build of libkatamx (tests/fakehip/emulate_engine.cpp) and prints, as JSON, the
+largest deviation of each output from the reference values (PyTorch goldens or the oracle). Own process: it replaces the
+library handle of katago_amd.capi, which must not leak into other tests.
+    python run_emulated_nets.py <libkatamx_emu.so> <case> [<case> ...]"""
+import json
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+from katago_amd import capi  # noqa: E402
+
+capi._lib = capi.load_library(path=sys.argv[1])
+from conftest import make_rows  # noqa: E402
+from katago_amd import modelgen, nninterface as nn  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+REF_MODELS = os.path.join(REPO, "oracle", "_ref", "models")
+
+
+def deviations(got, want, mask):
+    n = mask.shape[0]
+    full = np.concatenate([mask, np.ones((n, 1), bool)], axis=1)
+    return {
+        "policy": [float(np.abs(got["policy"] - want["policy"])[full].max()), float(np.abs(want["policy"][full]).max())],
+        "value": [float(np.abs(got["value"] - want["value"]).max()), float(np.abs(want["value"]).max())],
+        "score": [float(np.abs(got["score"] - want["score"]).max()), float(np.abs(want["score"]).max())],
+        "ownership": [float(np.abs(got["ownership"] - want["ownership"])[mask].max()), float(np.abs(want["ownership"][mask]).max())],
+        "finite": bool(all(np.isfinite(got[k]).all() for k in got)),
+    }
+
+
+def golden_case(ctx, name, with_meta=False):
+    v = np.load(os.path.join(GOLD, name + "_vectors.npz"))
+    h = nn.createComputeHandle(ctx, nn.loadModelFile(os.path.join(GOLD, name + ".bin.gz")), 8)
+    n = v["glob"].shape[0]
+    got = nn.getOutput(h, v["spatial_nhwc"], v["glob"], None, np.zeros(n, np.float32), rowMeta=v["meta"] if with_meta else None)
+    want = dict(policy=v["policy"][:, 0, :], value=v["value"], score=v["score"], ownership=v["ownership"])
+    h.close()
+    return deviations(got, want, v["spatial_nhwc"][:, :, 0] > 0)
+
+
+def oracle_case(ctx, path, n, sizes, seed):
+    rng = np.random.default_rng(seed)
+    sp, gl = make_rows(rng, n, 19, sizes)
+    sym = (np.arange(n) * 3 % 8).astype(np.int32)
+    opt = np.linspace(0.0, 1.0, n).astype(np.float32)
+    want = oracle.getOutput(oracle.loadModelFile(path), 19, 19, sp, gl, sym, opt)
+    h = nn.createComputeHandle(ctx, nn.loadModelFile(path), n)
+    got = nn.getOutput(h, sp, gl, sym, opt)
+    h.close()
+    return deviations(got, want, sp[:, :, 0] > 0)
+
+
+def main():
+    nn.globalInitialize()
+    out = {}
+    for case in sys.argv[2:]:
+        dtype, what = case.split(":")
+        ctx = nn.createComputeContext([0], 19, 19, precision=dtype)
+        if what in ("torch_nbt", "torch_tfa", "torch_tfb"):
+            out[case] = golden_case(ctx, what)
+        elif what == "torch_meta":
+            out[case] = golden_case(ctx, what, with_meta=True)
+        elif what.startswith("gen_"):  # gen_<arch>_v<version>
+            _, arch, ver = what.split("_")
+            p = os.path.join(os.environ.get("TMPDIR", "/tmp"), "kmx_emu_%s_%s.bin" % (arch, ver))
+            modelgen.write_model(p, arch, seed=11, version=int(ver[1:]))
+            out[case] = oracle_case(ctx, p, 3, [(19, 19), (13, 9), (9, 9)], 1)
+        else:  # a file under oracle/_ref/models
+            out[case] = oracle_case(ctx, os.path.join(REF_MODELS, what), 2, [(19, 19), (9, 9)], 2)
+    print("RESULT " + json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
