@@ -13,6 +13,7 @@
 #include "device_common.h"
 
 #include <atomic>
+#include <cstdlib>
 
 namespace kmx {
 
@@ -196,6 +197,161 @@ __global__ __launch_bounds__(192) void attentionKernel(AttentionArgs a) {
   }
 }
 
+// The same attention on the matrix cores. One work-group (4 waves) per (head, board); K (rotated) as T[SP][QDP] and V
+// TRANSPOSED as T[VDP][SP] in LDS, SP = 384 padded cells. A wave owns query tiles of 32; per key tile of 32:
+//   S^T[key][query] = K Q^T          QDP/16 MFMAs: A = K rows from LDS (one 16-byte read), B = the wave's Q fragments
+//   running-max softmax per query    a query is a lane column; its 32 keys sit in the two lane halves: one
+//                                    __shfl_xor(., 32) for the max, one for the sum
+//   O^T[vd][query] += V^T P^T        2 MFMAs per 32-channel vd tile: B = P straight from the S^T accumulators — the
+//                                    accumulator layout of a 32x32 tile is a valid B layout for two 16-deep MFMAs
+//                                    under the key permutation  slot (half, i) -> key 4*half + (i & 3) + 8*(i >> 2)
+//                                    (+16 for the second MFMA), which the A operand follows by reading V^T rows as
+//                                    two 8-byte runs of 4 keys
+// so the probabilities never leave registers. Scores are scaled in fp32 after the MFMA; P is rounded to T for the second
+// product (as every flash-attention kernel does).
+template <class TR, int QDP, int VDP>
+__global__ __launch_bounds__(256) void attentionMfmaKernel(AttentionArgs a) {
+  typedef typename TR::T T;
+  typedef typename TR::V8 V8;
+  typedef typename TR::V4 V4;
+  constexpr int SP = 384, KT = SP / 32, NQF = QDP / 16, NVT = VDP / 32;
+  HIP_DYNAMIC_SHARED(f32x4, smemAttn)
+  const int S = a.S, h = blockIdx.x, n = blockIdx.y;
+  const int kvh = h / (a.H / a.KVH);
+  T* const Ks = (T*)smemAttn;                         // [SP][QDP]
+  T* const Vt = Ks + (size_t)SP * QDP;                // [VDP][SP]
+  float* const Ms = (float*)(Vt + (size_t)VDP * SP);  // [SP]; zero beyond the board buffer
+  const T* const base = (const T*)a.qkv + (size_t)n * S * a.stride;
+  const int numPairs = a.QD / 2;
+  const size_t tableHead = (size_t)(a.ropeHeads > 1 ? kvh : 0) * numPairs * S;
+  const float* const cosT = a.ropeCos != nullptr ? a.ropeCos + tableHead : nullptr;
+  const float* const sinT = a.ropeSin != nullptr ? a.ropeSin + tableHead : nullptr;
+
+  for(int idx = threadIdx.x; idx < SP * (QDP / 2); idx += blockDim.x) {
+    const int j = idx / (QDP / 2), p = idx % (QDP / 2);
+    float k0 = 0.0f, k1 = 0.0f;
+    if(j < S) {
+      const T* kp = base + (size_t)j * a.stride + a.kOff + kvh * a.QD;
+      if(2 * p < a.QD) k0 = TR::toFloat(kp[2 * p]);
+      if(2 * p + 1 < a.QD) k1 = TR::toFloat(kp[2 * p + 1]);
+      if(cosT != nullptr && p < numPairs) {
+        const float c = cosT[(size_t)p * S + j], sn = sinT[(size_t)p * S + j];
+        const float r0 = k0 * c - k1 * sn, r1 = k0 * sn + k1 * c;
+        k0 = r0;
+        k1 = r1;
+      }
+    }
+    Ks[(size_t)j * QDP + 2 * p] = TR::fromFloat(k0);
+    Ks[(size_t)j * QDP + 2 * p + 1] = TR::fromFloat(k1);
+  }
+  for(int idx = threadIdx.x; idx < SP * VDP; idx += blockDim.x) {
+    const int j = idx / VDP, d = idx % VDP;
+    Vt[(size_t)d * SP + j] = (j < S && d < a.VD) ? base[(size_t)j * a.stride + a.vOff + kvh * a.VD + d] : TR::fromFloat(0.0f);
+  }
+  for(int j = threadIdx.x; j < SP; j += blockDim.x) Ms[j] = j < S ? a.mask[(size_t)n * S + j] : 0.0f;
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, hh = lane >> 5;
+  const float qscale = a.scale * LOG2E;
+  for(int qt = wave; qt < KT; qt += 4) {
+    const int q = qt * 32 + col;
+    const bool qIn = q < S;
+    const bool qOn = qIn && Ms[q] != 0.0f;
+    V8 qf[NQF];
+#pragma unroll
+    for(int kk = 0; kk < NQF; kk++)
+#pragma unroll
+      for(int i = 0; i < 8; i += 2) {
+        const int d = 16 * kk + 8 * hh + i, p = d >> 1;
+        float q0 = 0.0f, q1 = 0.0f;
+        if(qIn) {
+          const T* qp = base + (size_t)q * a.stride + h * a.QD;
+          if(d < a.QD) q0 = TR::toFloat(qp[d]);
+          if(d + 1 < a.QD) q1 = TR::toFloat(qp[d + 1]);
+          if(cosT != nullptr && p < numPairs) {
+            const float c = cosT[(size_t)p * S + q], sn = sinT[(size_t)p * S + q];
+            const float r0 = q0 * c - q1 * sn, r1 = q0 * sn + q1 * c;
+            q0 = r0;
+            q1 = r1;
+          }
+        }
+        qf[kk][i] = TR::fromFloat(q0);
+        qf[kk][i + 1] = TR::fromFloat(q1);
+      }
+    float m = -INFINITY, l = 0.0f;
+    f32x16 o[NVT];
+#pragma unroll
+    for(int vt = 0; vt < NVT; vt++)
+#pragma unroll
+      for(int v = 0; v < 16; v++) o[vt][v] = 0.0f;
+    for(int kt = 0; kt < KT; kt++) {
+      f32x16 s;
+#pragma unroll
+      for(int v = 0; v < 16; v++) s[v] = 0.0f;
+#pragma unroll
+      for(int kk = 0; kk < NQF; kk++) {
+        const V8 kf = *(const V8*)(Ks + (size_t)(kt * 32 + col) * QDP + 16 * kk + 8 * hh);
+        s = TR::mfma(kf, qf[kk], s);
+      }
+      // element v of this lane: key kt*32 + (v/4)*8 + hh*4 + v%4, query `col`
+      float sv[16];
+      float mx = -INFINITY;
+#pragma unroll
+      for(int v = 0; v < 16; v++) {
+        const int key = kt * 32 + (v >> 2) * 8 + hh * 4 + (v & 3);
+        sv[v] = Ms[key] != 0.0f ? s[v] * qscale : -INFINITY;
+        mx = fmaxf(mx, sv[v]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float mNew = fmaxf(m, mx);
+      const float mSafe = mNew == -INFINITY ? 0.0f : mNew;  // nothing on the board so far: every exponent below is -inf -> 0
+      const float corr = __builtin_amdgcn_exp2f(m - mSafe);
+      float ps = 0.0f;
+      V8 pf0, pf1;
+#pragma unroll
+      for(int v = 0; v < 8; v++) {
+        const float p0 = __builtin_amdgcn_exp2f(sv[v] - mSafe), p1 = __builtin_amdgcn_exp2f(sv[v + 8] - mSafe);
+        ps += p0 + p1;
+        pf0[v] = TR::fromFloat(p0);
+        pf1[v] = TR::fromFloat(p1);
+      }
+      ps += __shfl_xor(ps, 32);
+      l = l * corr + ps;
+      m = mNew;
+#pragma unroll
+      for(int vt = 0; vt < NVT; vt++) {
+#pragma unroll
+        for(int v = 0; v < 16; v++) o[vt][v] *= corr;
+        const T* vrow = Vt + (size_t)(vt * 32 + col) * SP + kt * 32 + hh * 4;
+        V8 af0, af1;
+        const V4 a00 = *(const V4*)(vrow), a01 = *(const V4*)(vrow + 8), a10 = *(const V4*)(vrow + 16), a11 = *(const V4*)(vrow + 24);
+#pragma unroll
+        for(int i = 0; i < 4; i++) {
+          af0[i] = a00[i];
+          af0[4 + i] = a01[i];
+          af1[i] = a10[i];
+          af1[4 + i] = a11[i];
+        }
+        o[vt] = TR::mfma(af0, pf0, o[vt]);
+        o[vt] = TR::mfma(af1, pf1, o[vt]);
+      }
+    }
+    if(!qIn) continue;
+    T* const outp = (T*)a.out + ((size_t)n * S + q) * a.outStride + h * a.VD;
+    const float inv = qOn ? 1.0f / l : 0.0f;  // masked queries contribute nothing (eigenbackend.cpp:1503-1508)
+#pragma unroll
+    for(int vt = 0; vt < NVT; vt++)
+#pragma unroll
+      for(int g = 0; g < 4; g++) {
+        const int vd0 = vt * 32 + g * 8 + hh * 4;
+#pragma unroll
+        for(int i = 0; i < 4; i++)
+          if(vd0 + i < a.VD) outp[vd0 + i] = TR::fromFloat(qOn ? o[vt][4 * g + i] * inv : 0.0f);
+      }
+  }
+}
+
 // SwiGLU: h[c] = silu(a[c]) * g[c], a = channels [0, F), g = channels [gOff, gOff + F) of the fused projection
 template <class TR>
 __global__ __launch_bounds__(256) void swiGluKernel(SwiGluArgs a) {
@@ -265,6 +421,37 @@ hipError_t launchAttentionQ(int qdp, int vdp, const AttentionArgs& a, hipStream_
   }
 }
 
+template <class TR, int QDP, int VDP>
+hipError_t launchAttentionMfmaOne(const AttentionArgs& a, hipStream_t stream) {
+  const size_t lds = (size_t)384 * QDP * 2 + (size_t)VDP * 384 * 2 + (size_t)384 * sizeof(float);
+  auto kern = attentionMfmaKernel<TR, QDP, VDP>;
+  if(lds > 64 * 1024) {
+    constexpr int MAX_DEVICES = 64;
+    static std::atomic<bool> attrSet[MAX_DEVICES];
+    int dev = 0;
+    hipError_t de = hipGetDevice(&dev);
+    if(de != hipSuccess) return de;
+    if(dev < 0 || dev >= MAX_DEVICES) return hipErrorInvalidDevice;
+    if(!attrSet[dev].load(std::memory_order_acquire)) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if(e != hipSuccess) return e;
+      attrSet[dev].store(true, std::memory_order_release);
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(a.H, a.N), dim3(256), lds, stream, a);
+  return hipGetLastError();
+}
+template <class TR>
+hipError_t launchAttentionMfmaQ(int qdp, int vdp, const AttentionArgs& a, hipStream_t stream) {
+  if(qdp == 16 && vdp == 32) return launchAttentionMfmaOne<TR, 16, 32>(a, stream);
+  if(qdp == 32 && vdp == 32) return launchAttentionMfmaOne<TR, 32, 32>(a, stream);
+  if(qdp == 64 && vdp == 32) return launchAttentionMfmaOne<TR, 64, 32>(a, stream);
+  if(qdp == 16 && vdp == 64) return launchAttentionMfmaOne<TR, 16, 64>(a, stream);
+  if(qdp == 32 && vdp == 64) return launchAttentionMfmaOne<TR, 32, 64>(a, stream);
+  if(qdp == 64 && vdp == 64) return launchAttentionMfmaOne<TR, 64, 64>(a, stream);
+  return hipErrorInvalidValue;
+}
+
 }  // namespace
 
 bool attentionDimsSupported(int qHeadDim, int vHeadDim) { return padDim(qHeadDim) > 0 && padDim(vHeadDim) > 0; }
@@ -294,6 +481,14 @@ hipError_t launchAttention(int dtype, const AttentionArgs& a, hipStream_t stream
   const int qdp = padDim(a.QD), vdp = padDim(a.VD);
   if(qdp < 0 || vdp < 0 || a.H < 1 || a.KVH < 1 || a.H % a.KVH != 0) return hipErrorInvalidValue;
   if(a.ropeCos != nullptr && a.QD % 2 != 0) return hipErrorInvalidValue;
+  // matrix-core version unless KMX_ATTENTION_VALU=1 (the plain kernel is kept as the cross-check of the other)
+  const char* valu = getenv("KMX_ATTENTION_VALU");
+  if(a.S <= 384 && !(valu != nullptr && valu[0] == '1')) {
+    const int q16 = qdp < 16 ? 16 : qdp, v32 = vdp < 32 ? 32 : vdp;
+    if(dtype == DT_F16) return launchAttentionMfmaQ<TraitsF16>(q16, v32, a, stream);
+    if(dtype == DT_BF16) return launchAttentionMfmaQ<TraitsBF16>(q16, v32, a, stream);
+    return hipErrorInvalidValue;
+  }
   if(dtype == DT_F16) return launchAttentionQ<TraitsF16>(qdp, vdp, a, stream);
   if(dtype == DT_BF16) return launchAttentionQ<TraitsBF16>(qdp, vdp, a, stream);
   return hipErrorInvalidValue;

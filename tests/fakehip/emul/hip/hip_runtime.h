@@ -61,6 +61,7 @@ namespace emu {
 struct Idx { unsigned x, y, z; };
 struct Wave {
   float buf[64];
+  float opA[64][8], opB[64][8];
   std::unique_ptr<std::barrier<>> bar;
 };
 struct Block {
@@ -86,12 +87,36 @@ void launchImpl(dim3 grid, dim3 block, const std::function<void()>& body);
 #define __launch_bounds__(...)
 #define HIP_DYNAMIC_SHARED(type, var) type* const var = (type*)emu::dynLds();
 #define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) emu::launchImpl(grid, block, [&] { kern(__VA_ARGS__); })
-// matrix-core builtins appear in the element traits (device_common.h) but are never called by the emulated kernels
-#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) (c)
-#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) (c)
+// v_mfma_f32_32x32x16_{f16,bf16} as a wave-collective on the CPU: D[32x32] = A[32x16] B[16x32] + C with the register
+// layout of the hardware (the layout the GPU-verified convolution kernel relies on): lane l holds A[l%32][8*(l/32)..+7],
+// B[8*(l/32)..+7][l%32], and C/D element v of lane l is row (v/4)*8 + (l/32)*4 + v%4, column l%32.
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu::mfma16(a, b, c)
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu::mfma16(a, b, c)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+
+namespace emu {
+template <class V8, class F16>
+inline F16 mfma16(V8 a, V8 b, F16 c) {
+  Wave& w = cur->waves[tIdx.x >> 6];
+  const unsigned lane = tIdx.x & 63;
+  for(int i = 0; i < 8; i++) {
+    w.opA[lane][i] = (float)a[i];
+    w.opB[lane][i] = (float)b[i];
+  }
+  w.bar->arrive_and_wait();
+  const unsigned col = lane & 31, half = lane >> 5;
+  for(int v = 0; v < 16; v++) {
+    const unsigned row = (v / 4) * 8 + half * 4 + (v % 4);
+    float sum = 0.0f;
+    for(int k = 0; k < 16; k++) sum += w.opA[row + 32 * (k / 8)][k % 8] * w.opB[col + 32 * (k / 8)][k % 8];
+    c[v] += sum;
+  }
+  w.bar->arrive_and_wait();
+  return c;
+}
+}  // namespace emu
 
 inline void __syncthreads() { emu::cur->bar->arrive_and_wait(); }
 inline float __shfl_xor(float v, int laneMask) {

@@ -53,7 +53,7 @@ size_t argBytes(const std::string& name) {
   if(name.find("bnActKernel") != std::string::npos) return sizeof(BnActArgs);
 #ifdef KMX_FAKEHIP_TRANSFORMER
   if(name.find("rmsNormKernel") != std::string::npos) return sizeof(RmsNormArgs);
-  if(name.find("attentionKernel") != std::string::npos) return sizeof(AttentionArgs);
+  if(name.find("attentionKernel") != std::string::npos || name.find("attentionMfmaKernel") != std::string::npos) return sizeof(AttentionArgs);
   if(name.find("swiGluKernel") != std::string::npos) return sizeof(SwiGluArgs);
 #endif
   return 0;  // several scalar arguments: not dumped

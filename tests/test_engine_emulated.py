@@ -42,11 +42,17 @@ def emu_lib(tmp_path_factory):
     return so
 
 
-def run_cases(emu_lib, cases, transformer=False):
+def run_cases(emu_lib, cases, transformer=False, attention="valu"):
+    """attention: which of the two attention kernels the transformer nets use. Emulating a matrix-core instruction costs two
+    thread barriers per MFMA and wave, so the whole-net runs use the plain kernel except where stated; the matrix-core
+    kernel is checked alone, shape by shape, in tests/test_transformer_kernels_emulated.py."""
     env = dict(os.environ)
     env.pop("KMX_EXPERIMENTAL_TRANSFORMER", None)
+    env.pop("KMX_ATTENTION_VALU", None)
     if transformer:
         env["KMX_EXPERIMENTAL_TRANSFORMER"] = "1"
+        if attention == "valu":
+            env["KMX_ATTENTION_VALU"] = "1"
     p = subprocess.run([sys.executable, os.path.join(FAKE, "run_emulated_nets.py"), emu_lib] + cases, capture_output=True, text=True, timeout=1800, env=env)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     return json.loads(p.stdout.split("RESULT ")[1])
@@ -77,6 +83,10 @@ def test_transformer_nets_emulated(emu_lib):
     check({k: v for k, v in res.items() if k.startswith("fp16")}, 0.03, 0.02)
     # fp16 keeps 11 bits: the path is not merely "within tolerance", it tracks the fp32 reference to ~1e-3
     assert res["fp16:torch_tfa"]["policy"][0] < 5e-3 and res["fp16:torch_tfb"]["policy"][0] < 5e-3
+    # the default (matrix-core) attention kernel inside a whole net
+    res = run_cases(emu_lib, ["fp16:torch_tfa"], transformer=True, attention="mfma")
+    check(res, 0.03, 0.02)
+    assert res["fp16:torch_tfa"]["policy"][0] < 5e-3
 
 
 def test_reference_transformer_nets_emulated(emu_lib):

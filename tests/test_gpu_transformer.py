@@ -152,10 +152,16 @@ def _rope(t, cos, sin, heads_of_table):
     return out
 
 
+@pytest.mark.parametrize("kernel", ["mfma", "valu"])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("H,KVH,QD,VD,rope", [(4, 4, 8, 8, "fixed"), (4, 2, 8, 4, "learnable"), (3, 3, 32, 32, "fixed"),
                                                (6, 3, 32, 16, "learnable"), (2, 1, 64, 64, "none"), (2, 2, 16, 32, "none")])
-def test_attention_kernel(dtype, H, KVH, QD, VD, rope):
+def test_attention_kernel(monkeypatch, kernel, dtype, H, KVH, QD, VD, rope):
+    """Both attention kernels: matrix-core (default) and plain (KMX_ATTENTION_VALU=1, read at every launch)."""
+    if kernel == "valu":
+        monkeypatch.setenv("KMX_ATTENTION_VALU", "1")
+    else:
+        monkeypatch.delenv("KMX_ATTENTION_VALU", raising=False)
     lib = capi.load_library()
     rng = np.random.default_rng(H * 100 + QD)
     n, X, Y = 3, 19, 19

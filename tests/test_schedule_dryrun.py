@@ -89,15 +89,13 @@ def test_transformer_schedule_is_consistent(name, C, H, KVH, QD, VD, F, blocks, 
     n = 3
     log = dry_run(fake_so, model, 8, [n], str(tmp_path / "tf.log"), {"KMX_EXPERIMENTAL_TRANSFORMER": "1"})
     launches = [_fields(l) for l in log.splitlines() if l.startswith("launch ")]
-    kinds = [("attention" if "attentionKernel" in k else "rmsnorm" if "rmsNormKernel" in k else "boardrms" if "boardRmsKernel" in k else
+    kinds = [("attention" if "attentionMfmaKernel" in k else "rmsnorm" if "rmsNormKernel" in k else "boardrms" if "boardRmsKernel" in k else
               "swiglu" if "swiGluKernel" in k else "conv" if "convMfmaKernel" in k else "other") for k, *_ in launches]
     S = 361
     att = [l for l, k in zip(launches, kinds) if k == "attention"]
     assert att
     for kname, grid, block, lds, args in att:
-        if name == "torch_tfb" and "Li8ELi8E" not in kname:
-            continue  # the nested transformer block of tfb runs at c_mid with its own head dims
-        assert grid[1] == n and block == 192
+        assert grid[1] == n and block == 256 and "Li16ELi32E" in kname  # head dims 8 / 4..8 padded to 16 / 32 for the MFMA tiles
     if blocks is not None:
         # per block: rmsnorm, fused projection conv, attention|swiglu, residual conv; then the tip rmsnorm
         body = kinds[2:2 + 4 * len(blocks)]
@@ -106,7 +104,7 @@ def test_transformer_schedule_is_consistent(name, C, H, KVH, QD, VD, F, blocks, 
             want += ["rmsnorm", "conv", "attention" if b == "attn" else "swiglu", "conv"]
         assert body == want and kinds[2 + 4 * len(blocks)] == "rmsnorm"
         kname, grid, block, lds, args = att[0]
-        assert grid == (H, n, 1) and lds == S * (8 + 8) * 2 + S * 4
+        assert grid == (H, n, 1) and lds == 384 * 16 * 2 + 32 * 384 * 2 + 384 * 4  # K[384][16], V^T[32][384], mask
         qkv_stride = int(args[1], 16) & 0xFFFFFFFF
         k_off = int(args[1], 16) >> 32
         v_off = int(args[2], 16) & 0xFFFFFFFF
@@ -130,10 +128,13 @@ def test_reference_transformer_nets_build_a_schedule(fake_so, tmp_path):
     nets = [os.path.join(d, f) for f in ("b7c96h3tfrs-test5-cnorm.bin.gz", "b7c96h6kv3qk32v16tflrs-fson-bnh.bin.gz")]
     if not all(os.path.exists(p) for p in nets):
         pytest.skip("reference test nets not packaged")
-    for p, head in zip(nets, ("Li32ELi32E", "Li32ELi16E")):
+    for p in nets:  # q/k dim 32, v dim 32 or 16 (padded to 32)
         log = dry_run(fake_so, p, 16, [16], str(tmp_path / "ref.log"), {"KMX_EXPERIMENTAL_TRANSFORMER": "1"})
-        att = [l for l in log.splitlines() if l.startswith("launch ") and "attentionKernel" in l]
-        assert len(att) == 7 and all(head in l for l in att)
+        att = [l for l in log.splitlines() if l.startswith("launch ") and "attentionMfmaKernel" in l]
+        assert len(att) == 7 and all("Li32ELi32E" in l for l in att)
+    log = dry_run(fake_so, nets[1], 16, [16], str(tmp_path / "valu.log"), {"KMX_EXPERIMENTAL_TRANSFORMER": "1", "KMX_ATTENTION_VALU": "1"})
+    att = [l for l in log.splitlines() if l.startswith("launch ") and "attentionKernel" in l]
+    assert len(att) == 7 and all("Li32ELi16E" in l and "block 192" in l for l in att)  # the plain kernel, selected by the environment
     # and without the opt-in the loader refuses them, dry run or not
     env = dict(os.environ, LD_PRELOAD=fake_so, KMX_FAKEHIP_LOG=str(tmp_path / "no.log"))
     env.pop("KMX_EXPERIMENTAL_TRANSFORMER", None)

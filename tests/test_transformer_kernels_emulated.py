@@ -69,14 +69,23 @@ def test_rmsnorm_kernel_emulated(emu, dtype, C, per_board, with_beta, act):
     assert np.all(got[mask == 0] == 0)
 
 
+@pytest.mark.parametrize("kernel", ["mfma", "valu"])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("H,KVH,QD,VD,rope", [(4, 4, 8, 8, "fixed"), (4, 2, 8, 4, "learnable"), (3, 3, 32, 32, "fixed"),
                                                (6, 3, 32, 16, "learnable"), (2, 1, 64, 64, "none"), (2, 2, 16, 32, "none"), (1, 1, 7, 3, "none")])
-def test_attention_kernel_emulated(emu, dtype, H, KVH, QD, VD, rope):
+def test_attention_kernel_emulated(emu, monkeypatch, kernel, dtype, H, KVH, QD, VD, rope):
+    """Both attention kernels: the matrix-core one (default; v_mfma_f32_32x32x16 is emulated as a wave-collective with the
+    hardware's register layout) and the plain one (KMX_ATTENTION_VALU=1)."""
+    if kernel == "valu":
+        monkeypatch.setenv("KMX_ATTENTION_VALU", "1")
+    else:
+        monkeypatch.delenv("KMX_ATTENTION_VALU", raising=False)
+    if kernel == "mfma" and dtype == "fp16" and (H, QD) in ((3, 32), (2, 64)):
+        pytest.skip("emulating MFMAs is slow: the large shapes run once, in bf16")
     rng = np.random.default_rng(H * 100 + QD)
     n, X, Y = 2, 19, 19
     S = X * Y
-    mask = _masks(rng, n, X, Y)
+    mask = _masks(rng, n, X, Y)[::-1].copy()  # board 0 partial, board 1 full
     q = _q16(rng.normal(0, 1.0, (n, S, H, QD)), dtype)
     k = _q16(rng.normal(0, 1.0, (n, S, KVH, QD)), dtype)
     v = _q16(rng.normal(0, 1.0, (n, S, KVH, VD)), dtype)
@@ -102,6 +111,7 @@ def test_attention_kernel_emulated(emu, dtype, H, KVH, QD, VD, rope):
                            _p(np.ascontiguousarray(v.reshape(n, S, -1))), _p(mask), _p(got))
     assert rc == 0
     err = np.abs(got.reshape(n, S, H, VD) - want)
+    print("%s %s max err %.4g" % (kernel, dtype, err.max()))
     assert np.isfinite(got).all() and err.max() <= 3 * _tol(dtype) * max(1.0, np.abs(want).max()), err.max()
     assert np.all(got[mask == 0] == 0)
 
