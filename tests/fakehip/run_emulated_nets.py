@@ -56,12 +56,50 @@ def oracle_case(ctx, path, n, sizes, seed):
     return deviations(got, want, sp[:, :, 0] > 0)
 
 
+def api_variants(ctx):
+    """The entry points that must give the SAME bits as kmx_eval: bit-packed rows, a handle that splits the batch over two
+    engines (KMX_SPLIT_MIN forces it at 4 rows here), rows evaluated alone, the counters."""
+    p = os.path.join(os.environ.get("TMPDIR", "/tmp"), "kmx_emu_variants.bin")
+    modelgen.write_model(p, "b2c32nbt", seed=5)
+    rng = np.random.default_rng(9)
+    n = 7
+    sp, gl = make_rows(rng, n, 19, [(19, 19), (13, 9), (9, 9), (19, 19), (7, 7), (19, 19), (9, 13)])
+    sym = (np.arange(n) % 8).astype(np.int32)
+    opt = np.linspace(0.0, 1.0, n).astype(np.float32)
+    model = nn.loadModelFile(p)
+    h = nn.createComputeHandle(ctx, model, n)
+    base = nn.getOutput(h, sp, gl, sym, opt)
+    packed = nn.getOutputPacked(h, nn.packRows(sp, 19, 19), gl, sym, opt)
+    alone = nn.getOutput(h, sp[4:5], gl[4:5], sym[4:5], opt[4:5])
+    rows, batches = h.stats()
+    h.close()
+    os.environ["KMX_SPLIT_MIN"] = "4"
+    h2 = nn.createComputeHandle(ctx, model, n)
+    del os.environ["KMX_SPLIT_MIN"]
+    split = nn.getOutput(h2, sp, gl, sym, opt)
+    small = nn.getOutput(h2, sp[:3], gl[:3], sym[:3], opt[:3])  # below the threshold: one engine
+    rows2, batches2 = h2.stats()
+    h2.close()
+    keys = ("policy", "value", "score", "ownership")
+    return {
+        "packed_equal": bool(all(np.array_equal(base[k], packed[k]) for k in keys)),
+        "alone_equal": bool(all(np.array_equal(base[k][4], alone[k][0]) for k in keys)),
+        "split_equal": bool(all(np.array_equal(base[k], split[k]) for k in keys)),
+        "small_equal": bool(all(np.array_equal(base[k][:3], small[k]) for k in keys)),
+        "stats": [int(rows), int(batches), int(rows2), int(batches2)],
+        "finite": bool(all(np.isfinite(base[k]).all() for k in keys)),
+    }
+
+
 def main():
     nn.globalInitialize()
     out = {}
     for case in sys.argv[2:]:
         dtype, what = case.split(":")
         ctx = nn.createComputeContext([0], 19, 19, precision=dtype)
+        if what == "api_variants":
+            out[case] = api_variants(ctx)
+            continue
         if what in ("torch_nbt", "torch_tfa", "torch_tfb"):
             out[case] = golden_case(ctx, what)
         elif what == "torch_meta":

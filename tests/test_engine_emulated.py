@@ -74,6 +74,13 @@ def test_convolutional_nets_emulated(emu_lib):
     check({k: v for k, v in res.items() if k.startswith("fp16")}, 0.03, 0.02)
 
 
+def test_entry_point_variants_emulated(emu_lib):
+    """kmx_eval_packed, the two-engine split of a batch, single rows: bit-identical to kmx_eval; counters add up."""
+    res = run_cases(emu_lib, ["bf16:api_variants"])["bf16:api_variants"]
+    assert res["finite"] and res["packed_equal"] and res["alone_equal"] and res["split_equal"] and res["small_equal"], res
+    assert res["stats"] == [7 + 7 + 1, 3, 7 + 3, 2], res
+
+
 def test_transformer_nets_emulated(emu_lib):
     """The transformer device path against the reference PyTorch goldens: attention + SwiGLU FFN trunk with fixed RoPE and a
     per-cell RMSNorm tip (tfa); grouped-query attention, learnable RoPE, a nested transformer bottleneck beside a
