@@ -92,6 +92,10 @@ void launchImpl(dim3 grid, dim3 block, const std::function<void()>& body);
 // B[8*(l/32)..+7][l%32], and C/D element v of lane l is row (v/4)*8 + (l/32)*4 + v%4, column l%32.
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu::mfma16(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu::mfma16(a, b, c)
+// wave / work-group builtins of the convolution kernel (emulate_engine.cpp, "real convolution" build)
+#define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_s_barrier() __syncthreads()
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
@@ -119,6 +123,18 @@ inline F16 mfma16(V8 a, V8 b, F16 c) {
 }  // namespace emu
 
 inline void __syncthreads() { emu::cur->bar->arrive_and_wait(); }
+namespace emu {
+// Lanes of a wave execute in lockstep on the hardware, so a wave may write LDS and read other lanes' values back without a
+// barrier; OS threads do not. Kernels that rely on it get this call injected at those points (see the convolution's
+// epilogue in tests/test_engine_emulated.py).
+inline void waveSync() { cur->waves[tIdx.x >> 6].bar->arrive_and_wait(); }
+// global_load_lds: every lane copies `size` bytes from its own global address to (wave-uniform LDS base) + lane * size.
+// Immediate here; on the hardware it completes asynchronously (s_waitcnt vmcnt), which emulation therefore cannot check.
+template <class G, class L>
+inline void globalLoadLds(G gsrc, L ldsBase, int size, int, int) {
+  memcpy((char*)(uintptr_t)ldsBase + (tIdx.x & 63) * size, (const void*)(uintptr_t)gsrc, (size_t)size);
+}
+}  // namespace emu
 inline float __shfl_xor(float v, int laneMask) {
   emu::Wave& w = emu::cur->waves[emu::tIdx.x >> 6];
   const unsigned lane = emu::tIdx.x & 63;

@@ -14,11 +14,14 @@
 
 namespace kmx {
 
+#ifndef KMX_EMU_REAL_CONV
 int chooseConvCfg(int, int, int) { return 11; }
 bool convCfgInstantiated(int, int) { return true; }
+#endif
 double benchConv(int, int, int, int, int, int, int, int, int, int) { return 0.0; }
 double benchMfma(int, int, int, int, int, double*, double*) { return 0.0; }
 
+#ifndef KMX_EMU_REAL_CONV  // the "real convolution" build compiles a transformed copy of conv_mfma.hip / conv_kernel.h instead
 namespace {
 template <class TR>
 hipError_t convRef(int ks, const ConvArgs& a) {
@@ -72,5 +75,6 @@ hipError_t launchConv(int dtype, int ks, int cfg, const ConvArgs& a, hipStream_t
   if(dtype == DT_BF16) return convRef<TraitsBF16>(ks, a);
   return hipErrorInvalidValue;
 }
+#endif
 
 }  // namespace kmx

@@ -42,6 +42,102 @@ def emu_lib(tmp_path_factory):
     return so
 
 
+# ---- the "real convolution" build: conv_mfma.hip / conv_kernel.h themselves, emulated -----------------------------------
+# The kernel source is used as it is except for the statements that only exist on the GPU, which are rewritten at test time
+# (the product file is not touched): s_waitcnt / register-class asm statements are dropped, the dynamic LDS declaration
+# becomes the emulator's buffer, global_load_lds becomes an immediate per-lane copy, and a wave-level sync is injected at the
+# two places of the epilogue where a wave reads back what its other lanes wrote to LDS (lockstep on the hardware, not
+# between OS threads). v_mfma_f32_32x32x16 runs as a wave-collective in the hardware's register layout. What this cannot
+# show is anything about asynchronous completion (the s_waitcnt / ring-depth logic): the copies are immediate here.
+CONV_REWRITES = [
+    (r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\(N\) : "memory"\);', ";", 1),
+    (r'asm volatile\("" : "\+s"\(sTap\)\);', ";", 1),
+    (r'asm volatile\("" ::"v"\(touch\)\);', ";", 1),
+    (r'asm volatile\("" ::"v"\(o\)\);', ";", 2),
+    (r'extern __shared__ __attribute__\(\(aligned\(256\)\)\) char smem\[\];', "char* const smem = (char*)emu::dynLds();", 1),
+    (r'__builtin_amdgcn_global_load_lds\(', "emu::globalLoadLds(", 2),
+    (r'__attribute__\(\(amdgpu_waves_per_eu\(2, 2\)\)\)', "", 1),
+    (r'(\n    // \(a\) accumulators -> LDS, \[cell\]\[channel\] fp32)', r"\n    emu::waveSync();\1", 1),
+    (r'(\n    // \(b\) row-wise walk: lane -> \(cell pc of this group, 8 channels pk\))', r"\n    emu::waveSync();\1", 1),
+]
+
+
+@pytest.fixture(scope="module")
+def emu_full_lib(tmp_path_factory):
+    import re
+    import shutil
+
+    d = str(tmp_path_factory.mktemp("emufull"))
+    src = open(os.path.join(CSRC, "conv_kernel.h")).read()
+    for pat, rep, count in CONV_REWRITES:
+        src, k = re.subn(pat, rep, src)
+        assert k == count, "conv_kernel.h changed: %r matched %d times, expected %d" % (pat, k, count)
+    open(os.path.join(d, "conv_kernel.h"), "w").write(src)
+    shutil.copy(os.path.join(CSRC, "conv_mfma.hip"), os.path.join(d, "conv_mfma.hip"))
+    cxx = ["/opt/rocm/lib/llvm/bin/clang++", "-x", "c++", "-std=c++20", "-O2", "-fPIC", "-pthread", "-I" + os.path.join(FAKE, "emul"), "-I" + FAKE,
+           "-I" + CSRC, "-DKMX_EMU_REAL_CONV"]
+    procs, objs = [], []
+    for src_file in [os.path.join(d, "conv_mfma.hip")] + SOURCES:
+        obj = os.path.join(d, os.path.splitext(os.path.basename(src_file))[0] + ".o")
+        objs.append(obj)
+        procs.append((src_file, subprocess.Popen(cxx + ["-c", src_file, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src_file, p in procs:
+        out, _ = p.communicate()
+        assert p.returncode == 0, "%s:\n%s" % (src_file, out[-3000:])
+    so = os.path.join(d, "libkatamx_emufull.so")
+    r = subprocess.run(["/opt/rocm/lib/llvm/bin/clang++", "-shared", "-fPIC", "-pthread", "-o", so] + objs + ["-lz"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return so
+
+
+def test_real_convolution_kernel_emulated(emu_full_lib):
+    """conv_kernel.h itself on the CPU: 1x1 / 3x3 / 5x5, 4-wave and 8-wave shapes, channel counts that are not multiples of
+    the tile, a masked small board — against torch.nn.functional.conv2d on the 16-bit-rounded operands; then a whole small
+    net (every launch through the real kernel) against the oracle."""
+    code = r"""
+import sys, json
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+from katago_amd import capi
+capi._lib = capi.load_library(path=sys.argv[1])
+from katago_amd import nninterface as nn, modelgen
+from oracle import oracle
+from conftest import make_rows
+rng = np.random.default_rng(0)
+out = {}
+for (ks, cin, cout, X, Y, n) in ((3, 32, 32, 9, 9, 1), (1, 64, 96, 19, 19, 1), (3, 40, 200, 19, 19, 1), (5, 22, 64, 13, 9, 1), (3, 64, 128, 19, 19, 2)):
+    w = (rng.normal(size=(cout, cin, ks, ks)) * 0.1).astype(np.float32)
+    x = rng.normal(size=(n, Y * X, cin)).astype(np.float32)
+    got = np.asarray(nn.testEvaluateConv(w, n, X, Y, True, x))
+    xt = torch.from_numpy(x.reshape(n, Y, X, cin).transpose(0, 3, 1, 2)).to(torch.bfloat16).float()
+    wt = torch.from_numpy(w).to(torch.bfloat16).float()
+    want = torch.nn.functional.conv2d(xt, wt, padding=ks // 2).numpy().transpose(0, 2, 3, 1).reshape(n, Y * X, cout)
+    out["conv%%d_%%d_%%d" %% (ks, cin, cout)] = [float(np.abs(got.reshape(want.shape) - want).max()), float(np.abs(want).max())]
+nn.globalInitialize()
+ctx = nn.createComputeContext([0], 19, 19, precision="bf16")
+p = "/tmp/kmx_emufull_b2c32nbt.bin"
+modelgen.write_model(p, "b2c32nbt", seed=4)
+sp, gl = make_rows(rng, 2, 19, [(19, 19), (9, 13)])
+sym = np.array([3, 6], np.int32); opt = np.array([0.0, 1.0], np.float32)
+h = nn.createComputeHandle(ctx, nn.loadModelFile(p), 2)
+got = nn.getOutput(h, sp, gl, sym, opt)
+want = oracle.getOutput(oracle.loadModelFile(p), 19, 19, sp, gl, sym, opt)
+mask = sp[:, :, 0] > 0; full = np.concatenate([mask, np.ones((2, 1), bool)], axis=1)
+out["net"] = {"policy": [float(np.abs(got["policy"] - want["policy"])[full].max()), float(np.abs(want["policy"][full]).max())],
+              "value": [float(np.abs(got["value"] - want["value"]).max()), float(np.abs(want["value"]).max())],
+              "ownership": [float(np.abs(got["ownership"] - want["ownership"])[mask].max()), float(np.abs(want["ownership"][mask]).max())]}
+print("RESULT " + json.dumps(out))
+""" % (REPO, os.path.join(REPO, "tests"))
+    p = subprocess.run([sys.executable, "-c", code, emu_full_lib], capture_output=True, text=True, timeout=1800)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    res = json.loads(p.stdout.split("RESULT ")[1])
+    for k, v in res.items():
+        if k.startswith("conv"):
+            assert v[0] <= 2.0 ** -7 * max(1.0, v[1]) * 1.5, (k, v)  # one bf16 rounding of the output
+    for k, (err, scale) in res["net"].items():
+        assert err <= 0.08 + 0.03 * scale, (k, err, scale)
+
+
 def run_cases(emu_lib, cases, transformer=False, attention="valu"):
     """attention: which of the two attention kernels the transformer nets use. Emulating a matrix-core instruction costs two
     thread barriers per MFMA and wave, so the whole-net runs use the plain kernel except where stated; the matrix-core
