@@ -59,9 +59,15 @@ constexpr int MAXLEN = 19;
 // ablation switches (conv_bench.hip only; 0 in the product)
 enum { ABL_NO_EPILOGUE = 1, ABL_NO_COMPUTE = 2, ABL_NO_DMA = 4, ABL_NO_LDS_READ = 8, ABL_NO_VMWAIT = 16, ABL_NO_W_DMA = 32, ABL_NO_A_DMA = 64,
        ABL_EPI_NOACT = 512, ABL_EPI_NOSTORE = 1024,
-       ABL_TIMING = 2048 /* s_memtime stamps between the segments of a step, summed per wave into ConvArgs::dbg */ };
+       ABL_TIMING = 2048 /* s_memtime stamps between the segments of a step, summed per wave into ConvArgs::dbg */,
+       ABL_BP2 = 4096 /* EXPERIMENT, not an ablation: work-group barrier on even taps only (Geom::BP = 2). Carried in this
+                         parameter so that the product kernels (ABL = 0) keep their symbols and their code. */ };
 
-template <int KS, int WN, int WNW, int D>
+// BP = barrier period in taps (experiment; 1 in the product): with BP = 2 the work-group synchronises on even taps only.
+// A slab is then overwritten two steps after its last read with possibly no barrier in between, so the ring holds one
+// slot more (D + 2), and at a barrier the slabs of the next TWO steps must have landed (one when the next step has a
+// barrier of its own, i.e. at the last tap of a chunk).
+template <int KS, int WN, int WNW, int D, int BP = 1>
 struct Geom {
   static constexpr int NWAVES = 4 * WNW;
   static constexpr int NTHREADS = NWAVES * 64;
@@ -93,7 +99,9 @@ struct Geom {
   static constexpr int PPS = SPREAD ? pickPPS() : NPA;
   static constexpr int LS = (NPA + PPS - 1) / PPS;
   static constexpr int NSA = SPREAD ? 2 : D + 1;
-  static constexpr int NSW = D + 1;
+  static constexpr int NSW = D + BP;
+  static_assert(BP == 1 || (BP == 2 && WNW == 2 && KS * KS > 1 && (KS * KS) % 2 == 1 && D >= 3),
+                "the even-tap barrier variant exists for the 8-wave 3x3 / 5x5 shapes with a ring of at least 3 requests");
   static constexpr int SLACK_BYTES = NWAVES * 1024;
   static constexpr int NPM = (384 + NTHREADS - 1) / NTHREADS;          // 4-byte DMA instructions per wave for the mask
   static constexpr int MASK_BYTES = NPM * NTHREADS * 4;
@@ -108,6 +116,7 @@ struct Geom {
   static constexpr int VMCNT_PRO = SPREAD ? PPS + (D - 1) * (NPW + PPS) : (D - 1) * (NPW + NPA);
   // ROLES: a weight wave has only slabs in flight, an image wave only image pieces
   static constexpr int VMCNT_W = (D - 2) * NPW, VMCNT_PRO_W = (D - 1) * NPW;
+  static constexpr int VMCNT_W2 = D >= 3 ? (D - 3) * NPW : 0;  // BP == 2, a barrier whose next step has none: slabs s+1 AND s+2 landed
   static constexpr int VMCNT_A1 = (D - 2) * NPA, VMCNT_PRO_A1 = (D - 1) * NPA;  // 1x1: whole images ride the ring
 };
 
@@ -125,7 +134,8 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   typedef typename TR::T T;
   typedef typename TR::V8 V8;
   typedef typename TR::V4 V4;
-  typedef Geom<KS, WN, WNW, D> G;
+  constexpr int BP = (ABL & ABL_BP2) ? 2 : 1;
+  typedef Geom<KS, WN, WNW, D, BP> G;
   constexpr int HALO = G::HALO, NT = G::NT, NPA = G::NPA, NPW = G::NPW, NWAVES = G::NWAVES;
   constexpr bool SPREAD = G::SPREAD;
 
@@ -423,7 +433,13 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   auto waitStep = [&](int t) {
     if(ABL & (ABL_NO_DMA | ABL_NO_VMWAIT | ABL_NO_W_DMA | ABL_NO_A_DMA)) return;
     if(!ROLES) waitVm<G::VMCNT>();
-    else if(wLoader) waitVm<G::VMCNT_W>();
+    else if(wLoader) {
+      if constexpr(BP == 2) {
+        if(t + 1 < NT) waitVm<G::VMCNT_W2>();  // the next step has no barrier: publish two slabs
+        else waitVm<G::VMCNT_W>();
+      }
+      else waitVm<G::VMCNT_W>();
+    }
     else if(!SPREAD) waitVm<G::VMCNT_A1>();
     else if(t == NT - 1) waitVm<0>();  // the next chunk's image, first read at the end of this step
   };
@@ -454,9 +470,11 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
     const unsigned nextA = (unsigned)((chunk + 1) % G::NSA) * G::ACT_BYTES;
 #pragma unroll
     for(int t = 0; t < NT; t++, step++) {
-      waitStep(t);
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
+      if(BP == 1 || t % 2 == 0) {
+        waitStep(t);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
       stamp(0);
       // The compiler's own s_waitcnt before an MFMA drains ALL outstanding LDS reads (lgkmcnt(0)), so each batch of
       // reads is issued right AFTER the first MFMA of the other fragment set: the wait it causes then only covers
@@ -599,7 +617,7 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
 
 template <class TR, int KS, int WN, int WNW, int D, int ABL>
 hipError_t launchOne(const ConvArgs& a, hipStream_t stream) {
-  typedef Geom<KS, WN, WNW, D> G;
+  typedef Geom<KS, WN, WNW, D, (ABL & ABL_BP2) ? 2 : 1> G;
   constexpr int ldsBytes = G::LDS_BYTES;
   static_assert(ldsBytes <= 160 * 1024, "LDS budget exceeded");
   static_assert(!G::SPREAD || G::LS + (G::ROLES ? 1 : D) <= G::NT, "image pieces must land within their chunk");

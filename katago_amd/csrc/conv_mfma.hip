@@ -20,8 +20,22 @@ using namespace convk;
   X(5, 1, 1, 2) X(5, 1, 2, 2) X(5, 1, 3, 2)  \
   X(5, 2, 2, 2)
 
+// EXPERIMENT (off unless KMX_CONV_BP2=1): the 8-wave 3x3 shapes with a work-group barrier on even
+// taps only and a ring of D + 2 slabs. Not yet run on hardware.
+bool evenTapBarriers() {
+  static const bool on = [] {
+    const char* e = getenv("KMX_CONV_BP2");
+    return e != nullptr && e[0] == '1';
+  }();
+  return on;
+}
+
 template <class TR>
 hipError_t launchT(int ks, int cfg, const ConvArgs& a, hipStream_t stream) {
+  if(ks == 3 && (cfg == 22 || cfg == 23) && evenTapBarriers()) {
+    if(cfg == 22) return launchOne<TR, 3, 2, 2, 3, ABL_BP2>(a, stream);
+    return launchOne<TR, 3, 3, 2, 3, ABL_BP2>(a, stream);
+  }
 #define KMX_CFG(KS_, WNW_, WN_, D_) \
   if(ks == KS_ && cfg == 10 * WNW_ + WN_) return launchOne<TR, KS_, WN_, WNW_, D_, 0>(a, stream);
   KMX_CFG_LIST(KMX_CFG)

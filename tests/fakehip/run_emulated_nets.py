@@ -34,14 +34,15 @@ def deviations(got, want, mask):
     }
 
 
-def golden_case(ctx, name, with_meta=False):
+def golden_case(ctx, name, with_meta=False, rows=None):
     v = np.load(os.path.join(GOLD, name + "_vectors.npz"))
     h = nn.createComputeHandle(ctx, nn.loadModelFile(os.path.join(GOLD, name + ".bin.gz")), 8)
-    n = v["glob"].shape[0]
-    got = nn.getOutput(h, v["spatial_nhwc"], v["glob"], None, np.zeros(n, np.float32), rowMeta=v["meta"] if with_meta else None)
-    want = dict(policy=v["policy"][:, 0, :], value=v["value"], score=v["score"], ownership=v["ownership"])
+    sel = slice(None) if rows is None else rows  # e.g. [2]: only the 13x9 board of the fixture
+    n = v["glob"][sel].shape[0]
+    got = nn.getOutput(h, v["spatial_nhwc"][sel], v["glob"][sel], None, np.zeros(n, np.float32), rowMeta=v["meta"][sel] if with_meta else None)
+    want = dict(policy=v["policy"][sel][:, 0, :], value=v["value"][sel], score=v["score"][sel], ownership=v["ownership"][sel])
     h.close()
-    return deviations(got, want, v["spatial_nhwc"][:, :, 0] > 0)
+    return deviations(got, want, v["spatial_nhwc"][sel][:, :, 0] > 0)
 
 
 def oracle_case(ctx, path, n, sizes, seed):
@@ -100,8 +101,9 @@ def main():
         if what == "api_variants":
             out[case] = api_variants(ctx)
             continue
-        if what in ("torch_nbt", "torch_tfa", "torch_tfb"):
-            out[case] = golden_case(ctx, what)
+        if what.split("@")[0] in ("torch_nbt", "torch_tfa", "torch_tfb"):
+            name, _, rows = what.partition("@")  # torch_tfa@2 = row 2 only
+            out[case] = golden_case(ctx, name, rows=[int(r) for r in rows.split(",")] if rows else None)
         elif what == "torch_meta":
             out[case] = golden_case(ctx, what, with_meta=True)
         elif what.startswith("gen_"):  # gen_<arch>_v<version>
@@ -110,7 +112,7 @@ def main():
             modelgen.write_model(p, arch, seed=11, version=int(ver[1:]))
             out[case] = oracle_case(ctx, p, 3, [(19, 19), (13, 9), (9, 9)], 1)
         else:  # a file under oracle/_ref/models
-            out[case] = oracle_case(ctx, os.path.join(REF_MODELS, what), 2, [(19, 19), (9, 9)], 2)
+            out[case] = oracle_case(ctx, os.path.join(REF_MODELS, what), 1, [(13, 13)], 2)
     print("RESULT " + json.dumps(out))
 
 

@@ -138,6 +138,39 @@ print("RESULT " + json.dumps(out))
         assert err <= 0.08 + 0.03 * scale, (k, err, scale)
 
 
+def test_even_tap_barrier_variant_emulated(emu_full_lib):
+    """The experimental 8-wave 3x3 kernels that synchronise on even taps only (KMX_CONV_BP2=1; ring of D + 2 slabs) and, for
+    comparison, the product's 8-wave shapes, both forced at a small batch with KMX_MIN_WGS8=1: same answers as conv2d.
+    (Index arithmetic and ring-slot bookkeeping only: copies are immediate under emulation, so the s_waitcnt counts of the
+    variant are NOT exercised here - that needs the GPU.)"""
+    code = r"""
+import sys, json
+sys.path.insert(0, %r)
+import numpy as np, torch
+from katago_amd import capi
+capi._lib = capi.load_library(path=sys.argv[1])
+from katago_amd import nninterface as nn
+rng = np.random.default_rng(1)
+out = {}
+for (cin, cout, X, Y, n) in ((64, 192, 19, 19, 1), (96, 128, 13, 9, 1)):
+    w = (rng.normal(size=(cout, cin, 3, 3)) * 0.1).astype(np.float32)
+    x = rng.normal(size=(n, Y * X, cin)).astype(np.float32)
+    got = np.asarray(nn.testEvaluateConv(w, n, X, Y, True, x))
+    xt = torch.from_numpy(x.reshape(n, Y, X, cin).transpose(0, 3, 1, 2)).to(torch.bfloat16).float()
+    wt = torch.from_numpy(w).to(torch.bfloat16).float()
+    want = torch.nn.functional.conv2d(xt, wt, padding=1).numpy().transpose(0, 2, 3, 1).reshape(n, Y * X, cout)
+    out["%%d_%%d" %% (cin, cout)] = [float(np.abs(got.reshape(want.shape) - want).max()), float(np.abs(want).max())]
+print("RESULT " + json.dumps(out))
+""" % (REPO,)
+    for bp2 in ("0", "1"):
+        env = dict(os.environ, KMX_MIN_WGS8="1", KMX_CONV_BP2=bp2)
+        p = subprocess.run([sys.executable, "-c", code, emu_full_lib], capture_output=True, text=True, timeout=1800, env=env)
+        assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+        res = json.loads(p.stdout.split("RESULT ")[1])
+        for k, v in res.items():
+            assert v[0] <= 2.0 ** -7 * max(1.0, v[1]) * 1.5, (bp2, k, v)
+
+
 def run_cases(emu_lib, cases, transformer=False, attention="valu"):
     """attention: which of the two attention kernels the transformer nets use. Emulating a matrix-core instruction costs two
     thread barriers per MFMA and wave, so the whole-net runs use the plain kernel except where stated; the matrix-core
@@ -181,15 +214,15 @@ def test_transformer_nets_emulated(emu_lib):
     """The transformer device path against the reference PyTorch goldens: attention + SwiGLU FFN trunk with fixed RoPE and a
     per-cell RMSNorm tip (tfa); grouped-query attention, learnable RoPE, a nested transformer bottleneck beside a
     convolutional one, per-board RMSNorm tip (tfb)."""
-    res = run_cases(emu_lib, ["bf16:torch_tfa", "bf16:torch_tfb", "fp16:torch_tfa", "fp16:torch_tfb"], transformer=True)
+    res = run_cases(emu_lib, ["bf16:torch_tfa", "fp16:torch_tfb"], transformer=True)
     check({k: v for k, v in res.items() if k.startswith("bf16")}, 0.03, 0.08)
     check({k: v for k, v in res.items() if k.startswith("fp16")}, 0.03, 0.02)
     # fp16 keeps 11 bits: the path is not merely "within tolerance", it tracks the fp32 reference to ~1e-3
-    assert res["fp16:torch_tfa"]["policy"][0] < 5e-3 and res["fp16:torch_tfb"]["policy"][0] < 5e-3
+    assert res["fp16:torch_tfb"]["policy"][0] < 5e-3
     # the default (matrix-core) attention kernel inside a whole net
-    res = run_cases(emu_lib, ["fp16:torch_tfa"], transformer=True, attention="mfma")
+    res = run_cases(emu_lib, ["fp16:torch_tfa@2"], transformer=True, attention="mfma")  # the 13x9 board only: MFMA emulation is slow
     check(res, 0.03, 0.02)
-    assert res["fp16:torch_tfa"]["policy"][0] < 5e-3
+    assert res["fp16:torch_tfa@2"]["policy"][0] < 5e-3
 
 
 def test_reference_transformer_nets_emulated(emu_lib):
