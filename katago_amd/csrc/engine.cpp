@@ -659,7 +659,7 @@ void Engine::runSchedule(int n, const float* dSpatial, const unsigned char* dPac
     return;
   }
   for(const Op& op : ops_) {
-    Pending p;
+    Pending p = {};
     for(hipEvent_t* e : {&p.a, &p.b}) {
       if(eventPool_.empty()) hipCheck(hipEventCreate(e), "hipEventCreate");
       else {

@@ -88,7 +88,10 @@ std::vector<unsigned char> readWholeFile(const std::string& path) {
   std::vector<unsigned char> data;
   unsigned char chunk[1 << 16];
   size_t n;
-  while((n = fread(chunk, 1, sizeof(chunk), f)) > 0) data.insert(data.end(), chunk, chunk + n);
+  while((n = fread(chunk, 1, sizeof(chunk), f)) > 0) {
+    data.insert(data.end(), chunk, chunk + n);
+    if(n < sizeof(chunk)) break;  // end of file or error: do not read again
+  }
   bool err = ferror(f) != 0;
   fclose(f);
   if(err) throw ModelError(KMX_ERR_IO, "error while reading model file " + path);

@@ -165,7 +165,7 @@ static float rd_float(Rd* r, const char* what) {
 }
 /* readFloats (desc.cpp:40-90): text tokens, or "@BIN@" + little-endian fp32 block */
 static float* rd_floats(Rd* r, size_t n, const char* name) {
-  float* out = (float*)malloc(sizeof(float) * (n ? n : 1));
+  float* out = (float*)calloc(n ? n : 1, sizeof(float)); /* zeros, not garbage, if parsing fails half-way */
   if(r->err) return out;
   if(!r->binary) {
     for(size_t i = 0; i < n; i++) out[i] = rd_float(r, name);
