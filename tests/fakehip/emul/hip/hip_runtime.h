@@ -1,9 +1,10 @@
 // TEST INFRASTRUCTURE: a host-side stand-in for <hip/hip_runtime.h> under which the plain-C++ device kernels of
 // katago_amd/csrc/transformer_kernels.hip compile for x86 and RUN on the CPU (tests/fakehip/emulate_transformer.cpp):
-// a work-group is a set of OS threads, __syncthreads a std::barrier, __shfl_xor an exchange through a per-wave array,
+// a work-group is a set of OS threads, __syncthreads a barrier (emu::Barrier), __shfl_xor an exchange through a per-wave array,
 // dynamic LDS a static buffer, work-groups run one after the other. Only what those kernels use is provided.
 #pragma once
-#include <barrier>
+#include <condition_variable>
+#include <mutex>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
@@ -59,13 +60,41 @@ inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms =
 
 namespace emu {
 struct Idx { unsigned x, y, z; };
+// A barrier whose participants may leave (a thread that returns from the kernel). Mutex + condition variable on purpose:
+// std::barrier of libstdc++ waits through a shared pool of atomics, which both costs a lot with hundreds of threads and
+// makes ThreadSanitizer see synchronisation between unrelated barriers.
+class Barrier {
+ public:
+  explicit Barrier(unsigned n) : expected_(n) {}
+  void arrive_and_wait() {
+    std::unique_lock<std::mutex> l(m_);
+    const unsigned ph = phase_;
+    if(++arrived_ == expected_) release();
+    else cv_.wait(l, [&] { return phase_ != ph; });
+  }
+  void arrive_and_drop() {
+    std::lock_guard<std::mutex> l(m_);
+    --expected_;
+    if(expected_ > 0 && arrived_ == expected_) release();
+  }
+
+ private:
+  void release() {
+    arrived_ = 0;
+    ++phase_;
+    cv_.notify_all();
+  }
+  std::mutex m_;
+  std::condition_variable cv_;
+  unsigned expected_, arrived_ = 0, phase_ = 0;
+};
 struct Wave {
   float buf[64];
   float opA[64][8], opB[64][8];
-  std::unique_ptr<std::barrier<>> bar;
+  std::unique_ptr<Barrier> bar;
 };
 struct Block {
-  std::unique_ptr<std::barrier<>> bar;
+  std::unique_ptr<Barrier> bar;
   std::vector<Wave> waves;
 };
 extern thread_local Idx tIdx, bIdx, bDim, gDim;
