@@ -146,6 +146,9 @@ def main():
     d_sc = torch.empty((B, 6), device="cuda")
     d_own = torch.empty((B, S), device="cuda")
     torch.cuda.synchronize()
+    if os.environ.get("KMX_DEBUG_ALLOC"):  # fault triage: the caller's buffers beside the library's own ([kmx alloc] lines)
+        for nm, t in (("d_sp", d_sp), ("d_gl", d_gl), ("d_pol", d_pol), ("d_val", d_val), ("d_sc", d_sc), ("d_own", d_own)):
+            print("[bench alloc] %s 0x%x .. 0x%x" % (nm, t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()), file=sys.stderr, flush=True)
     sym_p = sym.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
     opt_p = opt.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
 
@@ -195,7 +198,7 @@ def main():
         capi.check(lib.kmx_handle_get_profile(handle._p, ent, 32, ctypes.byref(cnt)), lib)
         prof_entries = {ent[i].name.decode(): (ent[i].launches, ent[i].total_ms, ent[i].flops, ent[i].bytes) for i in range(cnt.value)}
         capi.check(lib.kmx_handle_set_profiling(handle._p, 0), lib)
-        capi.check(lib.kmx_handle_set_split_min(handle._p, 224), lib)
+        capi.check(lib.kmx_handle_set_split_min(handle._p, -1), lib)  # back to the creation value (KMX_SPLIT_MIN or the default)
 
     host_rate = host_packed_rate = None
     if args.host_buffers and rank == 0:

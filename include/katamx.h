@@ -32,8 +32,11 @@ extern "C" {
 
 /* 2: + kmx_eval_meta / kmx_eval_device_meta (sgf-metadata nets), kmx_eval_packed / kmx_pack_row (bit-packed inputs),
  *    kmx_handle_set_split_min; kmx_model_info.reserved0 became meta_encoder_version. Additive over 1.
- * 3: + kmx_test_rmsnorm / kmx_test_attention / kmx_test_swiglu (experimental unit hooks). Additive over 2. */
-#define KMX_ABI_VERSION 3
+ * 3: + kmx_test_rmsnorm / kmx_test_attention / kmx_test_swiglu (experimental unit hooks). Additive over 2.
+ * 4: + kmx_handle_set_graphs / kmx_handle_graph_stats (hipGraph replay of the launch schedule); kmx_handle_set_split_min
+ *    accepts a negative value (restore the creation value); the handle stream orders both halves of a split batch.
+ *    Additive over 3. */
+#define KMX_ABI_VERSION 4
 
 typedef enum kmx_status {
   KMX_OK = 0,
@@ -179,9 +182,10 @@ int kmx_eval_packed(kmx_handle* handle, int n_rows,
                     float* const* out_policy, float* out_value, float* out_score,
                     float* const* out_ownership);
 int kmx_pack_row(const float* row_spatial_nhwc, int nn_x_len, int nn_y_len, int num_channels, uint8_t* out_packed);
-/* hipStream_t the handle launches on. A handle that splits a batch (kmx_handle_set_split_min below) launches the second
- * half on a stream of its own: after an asynchronous kmx_eval_device (sync = 0) of such a batch, work enqueued on this
- * stream is ordered after the FIRST half only — wait with kmx_handle_sync, which covers both, or turn splitting off. */
+/* hipStream_t the handle launches on. It is an ordering point for a whole batch, split or not: a handle that splits a
+ * batch (kmx_handle_set_split_min below) launches the second half on a stream of its own, forked from this stream by an
+ * event at entry and joined back into it after its last launch. So inputs enqueued on this stream before an asynchronous
+ * kmx_eval_device (sync = 0) are complete for both halves, and work enqueued on it afterwards sees all outputs. */
 void* kmx_handle_stream(kmx_handle* handle);
 int kmx_handle_sync(kmx_handle* handle);
 
@@ -205,9 +209,16 @@ typedef struct kmx_profile_entry {
 /* Large batches are evaluated as two halves on two HIP streams (two engines inside the handle) when the handle was
  * created with max_batch_size >= the split threshold (default 224 rows, environment KMX_SPLIT_MIN at creation; 0 = off):
  * one half's memory-bound phases overlap the other's MFMA loops. min_rows = 0 turns splitting off for later calls (used
- * to time a kernel with the chip to itself), any other value sets the smallest batch that is split. */
+ * to time a kernel with the chip to itself), a positive value sets the smallest batch that is split, a negative value
+ * restores the threshold the handle was created with. */
 int kmx_handle_set_split_min(kmx_handle* handle, int min_rows);
 int kmx_handle_set_profiling(kmx_handle* handle, int enabled); /* resets the accumulated profile */
+/* hipGraph replay (default on; environment KMX_GRAPHS=0 at creation turns it off): the ~130 kernel launches of a pass are
+ * captured the second time a (row count, buffer pointers) combination occurs and replayed with one hipGraphLaunch from
+ * then on - what NNEvaluator's warm-up evaluations (setIsWarmup, nneval.cpp:487-560) prepare. Same kernels, arguments
+ * and order as direct launches: bit-identical results. graph_launches counts replayed passes (all engines of a handle). */
+int kmx_handle_set_graphs(kmx_handle* handle, int enabled);
+int kmx_handle_graph_stats(const kmx_handle* handle, uint64_t* graph_launches);
 int kmx_handle_get_profile(kmx_handle* handle, kmx_profile_entry* entries, int max_entries, int* n_entries);
 /* Average duration (ms, hipEvents) of one launch of the bf16 convolution kernel on synthetic data: kernel size ks,
  * wn = 32-channel tiles per wave, variant = 0 (product kernel) or depth*1000 + ablation mask (conv_kernel.h),

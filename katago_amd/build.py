@@ -35,7 +35,34 @@ def _compile(src):
     return obj
 
 
+def _source_hash():
+    """sha256 over every source and header (and the flags): what the shipped library was built from."""
+    import hashlib
+
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for rel in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, rel), "rb") as f:
+            h.update(rel.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+STAMP = LIB + ".srchash"
+
+
+def up_to_date():
+    """True when libkatamx.so exists and was built from exactly the sources in the tree. Decided by content, not by
+    mtimes: the object directory does not travel to the GPU box (.gpurunignore) and a copied tree's mtimes mean
+    nothing, so tests (conftest) and bench.py both load the SAME shipped binary instead of one of them rebuilding it."""
+    try:
+        with open(STAMP) as f:
+            return os.path.exists(LIB) and f.read().strip() == _source_hash()
+    except OSError:
+        return False
+
+
 def build(force=False, verbose=True):
+    if not force and up_to_date():
+        return LIB
     os.makedirs(OBJDIR, exist_ok=True)
     newest_header = max(_mtime(os.path.join(CSRC, h)) for h in HEADERS)
     todo = []
@@ -57,6 +84,8 @@ def build(force=False, verbose=True):
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
         if verbose:
             print("[katago_amd.build] linked", LIB, flush=True)
+    with open(STAMP, "w") as f:
+        f.write(_source_hash() + "\n")
     return LIB
 
 

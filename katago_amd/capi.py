@@ -111,6 +111,8 @@ SIGNATURES = {
     "kmx_handle_sync": (ctypes.c_int, [ctypes.c_void_p]),
     "kmx_handle_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "kmx_handle_set_profiling": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "kmx_handle_set_graphs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "kmx_handle_graph_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]),
     "kmx_handle_get_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ProfileEntry), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "kmx_handle_set_split_min": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "kmx_bench_conv": (ctypes.c_int, [ctypes.c_int] * 10 + [ctypes.POINTER(ctypes.c_double)]),
@@ -133,7 +135,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("KMX_LIBRARY") or LIB_PATH  # KMX_LIBRARY: A/B against another build of the same ABI
     # torch wheels bundle their own ROCm runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7). Two HIP
     # runtimes in one process cannot both own the GPU, so torch's must be loaded first: libkatamx.so then binds
     # to the already-loaded soname. (torch is only plumbing here: device buffers, streams, torch.distributed.)

@@ -574,25 +574,27 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
         else *(V8*)((T*)a.rawOut + gcell * a.rawC + (c8 - a.rawBegin)) = o;
       }
       if(inAct) {
-        const float maskVal = maskBoard[cell];
+        // a select, not a multiply: the raw residual stream is never masked off the board, and an overflowed fp16 value
+        // there (inf) times a zero mask would put a NaN into the halo of the next 3x3 convolution
+        const bool on = maskBoard[cell] == 1.0f;
         V8 o;
         // the activation kind is uniform for the launch: branch ONCE per row, not per element
         const int kind = (ABL & ABL_EPI_NOACT) ? KMX_ACT_IDENTITY : a.actKind;
         if(kind == KMX_ACT_MISH) {
 #pragma unroll
-          for(int i = 0; i < 8; i++) o[i] = TR::fromFloat(actMish(v[i] * sc[i] + bi[i]) * maskVal);
+          for(int i = 0; i < 8; i++) o[i] = TR::fromFloat(on ? actMish(v[i] * sc[i] + bi[i]) : 0.0f);
         }
         else if(kind == KMX_ACT_RELU) {
 #pragma unroll
-          for(int i = 0; i < 8; i++) o[i] = TR::fromFloat(fmaxf(v[i] * sc[i] + bi[i], 0.0f) * maskVal);
+          for(int i = 0; i < 8; i++) o[i] = TR::fromFloat(on ? fmaxf(v[i] * sc[i] + bi[i], 0.0f) : 0.0f);
         }
         else if(kind == KMX_ACT_SILU) {
 #pragma unroll
-          for(int i = 0; i < 8; i++) o[i] = TR::fromFloat(actSilu(v[i] * sc[i] + bi[i]) * maskVal);
+          for(int i = 0; i < 8; i++) o[i] = TR::fromFloat(on ? actSilu(v[i] * sc[i] + bi[i]) : 0.0f);
         }
         else {
 #pragma unroll
-          for(int i = 0; i < 8; i++) o[i] = TR::fromFloat((v[i] * sc[i] + bi[i]) * maskVal);
+          for(int i = 0; i < 8; i++) o[i] = TR::fromFloat(on ? v[i] * sc[i] + bi[i] : 0.0f);
         }
         if(ABL & ABL_EPI_NOSTORE) asm volatile("" ::"v"(o));
         else *(V8*)((T*)a.actOut + gcell * a.actC + (c8 - a.actBegin)) = o;

@@ -3,6 +3,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace kmx {
@@ -16,7 +18,11 @@ DevBuf::DevBuf(size_t bytes, bool zero) : p_(nullptr), bytes_(bytes) {
   // DEVBUF_TAIL readable bytes follow every allocation: the convolution's DMA pointers run up to D chunks (64 bytes
   // each) past the last channel chunk of the last cell; those requests land in a scratch area and are never used.
   hipCheck(hipMalloc(&p_, bytes + DEVBUF_TAIL), "hipMalloc");
-  if(zero) hipCheck(hipMemset(p_, 0, bytes + DEVBUF_TAIL), "hipMemset");
+  // The zero fill runs on the null stream; the engine's work runs on hipStreamNonBlocking streams, which do not
+  // synchronise with it: Engine::construct ends with hipDeviceSynchronize() so that no launch can overtake a fill.
+  if(zero) hipCheck(hipMemsetAsync(p_, 0, bytes + DEVBUF_TAIL, nullptr), "hipMemset");
+  static const bool debugAlloc = getenv("KMX_DEBUG_ALLOC") != nullptr;  // fault triage: which buffer does an address belong to
+  if(debugAlloc) fprintf(stderr, "[kmx alloc] %p .. %p (%zu + %zu bytes)\n", p_, (char*)p_ + bytes + DEVBUF_TAIL, bytes, DEVBUF_TAIL);
 }
 DevBuf::~DevBuf() {
   if(p_) (void)hipFree(p_);
@@ -152,6 +158,7 @@ Engine::Engine(const ModelDesc& model, int nnXLen, int nnYLen, int maxBatch, int
 void Engine::construct(const ModelDesc& model) {
   hipCheck(hipSetDevice(device_), "hipSetDevice");
   hipCheck(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+  if(const char* e = getenv("KMX_GRAPHS")) useGraphs_ = atoi(e) != 0;
   cin_ = model.numInputChannels;
   gin_ = model.numInputGlobalChannels;
   min_ = model.metaEncoderVersion > 0 ? model.numInputMetaChannels : 0;
@@ -189,12 +196,14 @@ void Engine::construct(const ModelDesc& model) {
   }
   buildSchedule(model);
   hipCheck(hipStreamSynchronize(stream_), "sync after build");
+  hipCheck(hipDeviceSynchronize(), "sync after build");  // the null-stream zero fills and uploads of every DevBuf
 }
 
 Engine::~Engine() { destroy(); }
 
 void Engine::destroy() noexcept {
   if(stream_) (void)hipStreamSynchronize(stream_);
+  dropGraphs();
   for(const Pending& p : pending_) {
     (void)hipEventDestroy(p.a);
     (void)hipEventDestroy(p.b);
@@ -654,11 +663,66 @@ void Engine::runSchedule(int n, const float* dSpatial, const unsigned char* dPac
   curValue_ = dValue;
   curScore_ = dScore;
   curOwnership_ = dOwnership;
+  const int forkAt = forkEv_ == nullptr ? -1 : std::min(forkOps_, (int)ops_.size());
+  if(forkAt == 0) hipCheck(hipEventRecord(forkEv_, stream_), "hipEventRecord");
   if(!profiling_) {
-    for(const Op& op : ops_) op.fn(n, stream_);
+    if(useGraphs_ && forkAt <= 0) {
+      GraphKey key;
+      key.n = n;
+      key.scale = cfgScale_;
+      const void* ptrs[8] = {dSpatial, dPacked, dGlobal, dMeta, dPolicy, dValue, dScore, dOwnership};
+      for(int i = 0; i < 8; i++) key.p[i] = ptrs[i];
+      auto it = graphCache_.find(key);
+      if(it == graphCache_.end()) {
+        // first sight: run directly (also sets the >64 KiB LDS attribute of every kernel shape this pass uses, which
+        // must not happen inside a capture) and remember the key
+        if(graphCache_.size() >= MAX_GRAPHS) {  // evict the least recently used entry
+          auto victim = graphCache_.begin();
+          for(auto j = graphCache_.begin(); j != graphCache_.end(); ++j)
+            if(j->second.lastUse < victim->second.lastUse) victim = j;
+          if(victim->second.exec) (void)hipGraphExecDestroy(victim->second.exec);
+          if(victim->second.graph) (void)hipGraphDestroy(victim->second.graph);
+          graphCache_.erase(victim);
+        }
+        graphCache_[key].lastUse = ++graphClock_;
+        launchOps(n);
+        return;
+      }
+      GraphEntry& g = it->second;
+      g.lastUse = ++graphClock_;
+      if(g.exec == nullptr) {
+        if(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+          // the runtime cannot capture here (e.g. this thread is inside someone else's capture): launch directly from now on
+          (void)hipGetLastError();
+          useGraphs_ = false;
+          launchOps(n);
+          return;
+        }
+        try {
+          launchOps(n);
+        }
+        catch(...) {
+          hipGraph_t dead = nullptr;
+          (void)hipStreamEndCapture(stream_, &dead);
+          if(dead) (void)hipGraphDestroy(dead);
+          graphCache_.erase(it);
+          throw;
+        }
+        hipCheck(hipStreamEndCapture(stream_, &g.graph), "hipStreamEndCapture");
+        hipCheck(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0), "hipGraphInstantiate");
+      }
+      hipCheck(hipGraphLaunch(g.exec, stream_), "hipGraphLaunch");
+      graphLaunches_++;
+      return;
+    }
+    for(size_t i = 0; i < ops_.size(); i++) {
+      ops_[i].fn(n, stream_);
+      if((int)i + 1 == forkAt) hipCheck(hipEventRecord(forkEv_, stream_), "hipEventRecord");
+    }
     return;
   }
-  for(const Op& op : ops_) {
+  for(size_t i = 0; i < ops_.size(); i++) {
+    const Op& op = ops_[i];
     Pending p = {};
     for(hipEvent_t* e : {&p.a, &p.b}) {
       if(eventPool_.empty()) hipCheck(hipEventCreate(e), "hipEventCreate");
@@ -674,7 +738,20 @@ void Engine::runSchedule(int n, const float* dSpatial, const unsigned char* dPac
     op.fn(n, stream_);
     hipCheck(hipEventRecord(p.b, stream_), "hipEventRecord");
     pending_.push_back(p);
+    if((int)i + 1 == forkAt) hipCheck(hipEventRecord(forkEv_, stream_), "hipEventRecord");
   }
+}
+
+void Engine::launchOps(int n) {
+  for(const Op& op : ops_) op.fn(n, stream_);
+}
+
+void Engine::dropGraphs() noexcept {
+  for(auto& kv : graphCache_) {
+    if(kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    if(kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+  }
+  graphCache_.clear();
 }
 
 int Engine::opClass(const std::string& name) {

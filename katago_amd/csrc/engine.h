@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <functional>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -28,6 +29,7 @@ struct Error : std::runtime_error {
 void hipCheck(hipError_t e, const char* what);
 
 constexpr size_t DEVBUF_TAIL = 512;
+constexpr size_t MAX_GRAPHS = 48;  // captured schedules kept per engine (least recently used evicted)
 
 // RAII device allocation
 class DevBuf {
@@ -105,6 +107,16 @@ class Engine {
   // The convolution work-group shape is chosen for `rows * scale` boards: a handle that runs two engines side by side
   // on two streams sets 2, so that each half still uses the 8-wave shape (the other half fills the rest of the chip).
   void setConcurrency(int scale) { cfgScale_ = scale < 1 ? 1 : scale; }
+  // Record `ev` on this engine's stream after the first `afterOps` launches of the next pass (0: at entry, before the
+  // row parameters are staged); null clears it. A second engine's stream waits for it (kmx_api.cpp, split handle).
+  void setForkPoint(int afterOps, hipEvent_t ev) { forkOps_ = afterOps < 0 ? 0 : afterOps; forkEv_ = ev; }
+  // hipGraph replay of the launch schedule: a pass with the same row count, work-group shapes and buffer
+  // pointers as an earlier one is captured once (on its second occurrence: the first runs directly and sets the kernels'
+  // LDS attributes) and then replayed with one hipGraphLaunch instead of ~130 kernel launches. Same kernels, same
+  // arguments, same order: bit-identical results. Off while profiling (per-launch events) or staggering.
+  void setGraphs(bool enabled) { useGraphs_ = enabled; }
+  bool graphs() const { return useGraphs_; }
+  uint64_t graphLaunches() const { return graphLaunches_; }
   uint64_t rowsProcessed() const { return rows_; }
   uint64_t batchesProcessed() const { return batches_; }
   int numLaunchesPerEval() const { return (int)ops_.size(); }
@@ -169,6 +181,31 @@ class Engine {
   int stagingSlot_ = 0;
   bool hostAnyOwner_ = false;
   int cfgScale_ = 1;
+  int forkOps_ = 0;
+  hipEvent_t forkEv_ = nullptr;
+
+  // captured schedules
+  struct GraphKey {
+    int n, scale;
+    const void* p[8];
+    bool operator<(const GraphKey& o) const {
+      if(n != o.n) return n < o.n;
+      if(scale != o.scale) return scale < o.scale;
+      for(int i = 0; i < 8; i++)
+        if(p[i] != o.p[i]) return p[i] < o.p[i];
+      return false;
+    }
+  };
+  struct GraphEntry {
+    hipGraphExec_t exec = nullptr;
+    hipGraph_t graph = nullptr;
+    uint64_t lastUse = 0;
+  };
+  std::map<GraphKey, GraphEntry> graphCache_;
+  bool useGraphs_ = true;
+  uint64_t graphLaunches_ = 0, graphClock_ = 0;
+  void launchOps(int n);   // the ops of one pass, directly on stream_
+  void dropGraphs() noexcept;
   int cin_ = 0, gin_ = 0, min_ = 0;  // spatial, global, sgf-metadata input channels
 
   // pointers the ops read at run time (set by runSchedule)

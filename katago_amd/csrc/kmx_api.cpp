@@ -2,6 +2,7 @@
 // exceptions into a status code + thread-local message; nothing here computes.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -25,19 +26,42 @@ struct kmx_context {
   int nnXLen, nnYLen, precisionMode;
   std::vector<int> gpuIdxs;
 };
-// A handle owns one engine, or — for max_batch >= 2*SPLIT_MIN_HALF — two engines on two streams that each evaluate half
-// of a large batch. The two kernel streams drift apart, so one half's memory-bound phases (1x1 convolutions, residual
-// fetches, epilogue stores) overlap the other half's MFMA loops instead of every work-group of the chip hitting HBM at
-// the same moment: measured +4.5 % evals/s at batch 256 (profiles/r01_final/two_stream.log). Weights are duplicated
-// (60 MB for b18c384nbt); activation memory is the same in total.
+// A handle owns one engine, or - for max_batch >= the split threshold - K engines on K streams that each evaluate 1/K
+// of a large batch. The kernel streams run out of phase, so one part's memory-bound phases (1x1 convolutions, residual
+// fetches, epilogue stores) overlap another part's MFMA loops instead of every work-group of the chip hitting HBM at
+// the same moment. Weights are duplicated per engine (60 MB for b18c384nbt); activation memory is
+// the same in total.
 struct kmx_handle {
-  std::unique_ptr<Engine> engine;   // rows [0, h)  (all rows when not split)
-  std::unique_ptr<Engine> engine2;  // rows [h, n)  or null
+  std::vector<std::unique_ptr<Engine>> engines;  // [0] serves unsplit batches and the first part of split ones
   int precision;
   int maxBatch;
-  int splitMin;  // batches of at least this many rows are split
+  int splitMin;          // batches of at least this many rows are split
+  int splitMinAtCreate;  // the value the handle was created with (KMX_SPLIT_MIN or the default)
+  int staggerOp = 0;     // the other parts start after this many launches of part 0 (0: all at entry)
+  // fork / join of the streams around a split device-entry call: the other engines' streams wait for `fork` (recorded
+  // on engines[0]'s stream, i.e. after everything the caller enqueued there), engines[0]'s stream waits for each `join`
+  // (recorded after that part's last launch). kmx_handle_stream() is thereby an ordering point for the inputs and
+  // outputs of ALL parts.
+  hipEvent_t fork = nullptr;
+  std::vector<hipEvent_t> join;
   uint64_t batches = 0;
-  bool splits(int n) const { return engine2 && n >= splitMin; }
+  Engine& e0() const { return *engines[0]; }
+  int ways() const { return (int)engines.size(); }
+  bool splits(int n) const { return engines.size() > 1 && n >= splitMin; }
+  // rows [begin, begin + count) of part i of an n-row batch: parts differ by at most one row
+  void part(int n, int i, int* begin, int* count) const {
+    const int k = ways(), base = n / k, extra = n % k;
+    *begin = i * base + (i < extra ? i : extra);
+    *count = base + (i < extra ? 1 : 0);
+  }
+  void syncAll() {
+    for(auto& e : engines) e->sync();
+  }
+  ~kmx_handle() {
+    if(fork) (void)hipEventDestroy(fork);
+    for(hipEvent_t e : join)
+      if(e) (void)hipEventDestroy(e);
+  }
 };
 
 namespace {
@@ -182,12 +206,23 @@ int kmx_handle_create(kmx_context* ctx, const kmx_model* model, int max_batch_si
     const int dtype = dtypeForPrecision(ctx->precisionMode);
     h->precision = dtype == DT_F16 ? KMX_PREC_FP16 : KMX_PREC_BF16;
     h->maxBatch = max_batch_size;
-    int splitMin = 224;  // two halves of >= 112 boards: the 8-wave work-groups of both halves together fill >= 87 % of the CUs
+    int splitMin = 224;  // parts of >= 56 boards: the 8-wave work-groups of all parts together fill >= 87 % of the CUs
     if(const char* e = getenv("KMX_SPLIT_MIN")) splitMin = atoi(e);  // 0 disables splitting
-    h->splitMin = splitMin;
-    h->engine.reset(new Engine(*model->desc, ctx->nnXLen, ctx->nnYLen, max_batch_size, dtype, dev));
-    if(splitMin > 1 && max_batch_size >= splitMin)
-      h->engine2.reset(new Engine(*model->desc, ctx->nnXLen, ctx->nnYLen, max_batch_size / 2, dtype, dev));
+    int ways = 2;
+    if(const char* e = getenv("KMX_SPLIT_WAYS")) ways = std::max(1, std::min(8, atoi(e)));
+    h->splitMin = h->splitMinAtCreate = splitMin;
+    if(const char* e = getenv("KMX_SPLIT_STAGGER")) h->staggerOp = atoi(e);
+    h->engines.emplace_back(new Engine(*model->desc, ctx->nnXLen, ctx->nnYLen, max_batch_size, dtype, dev));
+    if(splitMin > 1 && ways > 1 && max_batch_size >= splitMin && max_batch_size >= ways) {
+      const int partMax = (max_batch_size + ways - 1) / ways;
+      hipCheck(hipEventCreateWithFlags(&h->fork, hipEventDisableTiming), "hipEventCreate");
+      for(int i = 1; i < ways; i++) {
+        h->engines.emplace_back(new Engine(*model->desc, ctx->nnXLen, ctx->nnYLen, partMax, dtype, dev));
+        hipEvent_t ev = nullptr;
+        hipCheck(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+        h->join.push_back(ev);
+      }
+    }
     *out = h.release();
   });
 }
@@ -218,28 +253,35 @@ static int evalHostEntry(kmx_handle* handle, int n_rows, const float* const* row
         if(symmetry[i] < 0 || symmetry[i] > 7) throw Error(KMX_ERR_INVALID_ARG, "kmx_eval: symmetry must be in 0..7");
     handle->batches++;
     if(!handle->splits(n_rows)) {
-      handle->engine->setConcurrency(1);
-      handle->engine->evalHostBegin(n_rows, row_spatial, row_packed, row_global, row_meta, symmetry, policy_optimism, out_ownership);
-      handle->engine->evalHostFinish(n_rows, out_policy, out_value, out_score, out_ownership);
+      handle->e0().setConcurrency(1);
+      handle->e0().evalHostBegin(n_rows, row_spatial, row_packed, row_global, row_meta, symmetry, policy_optimism, out_ownership);
+      handle->e0().evalHostFinish(n_rows, out_policy, out_value, out_score, out_ownership);
       return;
     }
-    const int h = n_rows - n_rows / 2, r = n_rows / 2;  // engine2 holds max_batch/2 rows
-    handle->engine->setConcurrency(2);
-    handle->engine2->setConcurrency(2);
+    const int K = handle->ways();
     try {
-      handle->engine->evalHostBegin(h, row_spatial, row_packed, row_global, row_meta, symmetry, policy_optimism, out_ownership);
-      handle->engine2->evalHostBegin(r, row_spatial ? row_spatial + h : nullptr, row_packed ? row_packed + h : nullptr, row_global + h,
-                                     row_meta ? row_meta + h : nullptr, symmetry ? symmetry + h : nullptr,
-                                     policy_optimism ? policy_optimism + h : nullptr, out_ownership ? out_ownership + h : nullptr);
-      handle->engine->evalHostFinish(h, out_policy, out_value, out_score, out_ownership);
-      handle->engine2->evalHostFinish(r, out_policy + h, out_value + (size_t)h * 3, out_score + (size_t)h * 6,
-                                      out_ownership ? out_ownership + h : nullptr);
+      for(int i = 0; i < K; i++) {
+        int b, c;
+        handle->part(n_rows, i, &b, &c);
+        Engine& e = *handle->engines[i];
+        e.setConcurrency(K);
+        e.evalHostBegin(c, row_spatial ? row_spatial + b : nullptr, row_packed ? row_packed + b : nullptr, row_global + b,
+                        row_meta ? row_meta + b : nullptr, symmetry ? symmetry + b : nullptr,
+                        policy_optimism ? policy_optimism + b : nullptr, out_ownership ? out_ownership + b : nullptr);
+      }
+      for(int i = 0; i < K; i++) {
+        int b, c;
+        handle->part(n_rows, i, &b, &c);
+        handle->engines[i]->evalHostFinish(c, out_policy + b, out_value + (size_t)b * 3, out_score + (size_t)b * 6,
+                                           out_ownership ? out_ownership + b : nullptr);
+      }
     }
     catch(...) {
-      // one half failed while the other may still be in flight: the call is synchronous, so nothing of it may be running
+      // one part failed while others may still be in flight: the call is synchronous, so nothing of it may be running
       // when the error is reported
-      try { handle->engine->sync(); } catch(...) {}
-      try { handle->engine2->sync(); } catch(...) {}
+      for(auto& e : handle->engines) {
+        try { e->sync(); } catch(...) {}
+      }
       throw;
     }
   });
@@ -296,65 +338,97 @@ int kmx_eval_device_meta(kmx_handle* handle, int n_rows, const float* d_spatial,
     if(n_rows < 1 || n_rows > handle->maxBatch) throw Error(KMX_ERR_INVALID_ARG, "batch size out of range for this handle");
     handle->batches++;
     if(!handle->splits(n_rows)) {
-      handle->engine->setConcurrency(1);
-      handle->engine->evalDevice(n_rows, d_spatial, d_global, d_meta, symmetry, policy_optimism, d_policy, d_value, d_score,
-                                 d_ownership, sync != 0);
+      handle->e0().setConcurrency(1);
+      handle->e0().evalDevice(n_rows, d_spatial, d_global, d_meta, symmetry, policy_optimism, d_policy, d_value, d_score, d_ownership,
+                              sync != 0);
       return;
     }
-    const int h = n_rows - n_rows / 2, r = n_rows / 2;
-    const size_t S = (size_t)handle->engine->nnXLen() * handle->engine->nnYLen();
-    const size_t spRow = S * handle->engine->numInputChannels(), glRow = handle->engine->numInputGlobalChannels();
-    handle->engine->setConcurrency(2);
-    handle->engine2->setConcurrency(2);
-    const size_t mtRow = handle->engine->numInputMetaChannels();
-    handle->engine->evalDevice(h, d_spatial, d_global, d_meta, symmetry, policy_optimism, d_policy, d_value, d_score, d_ownership, false);
-    handle->engine2->evalDevice(r, d_spatial + h * spRow, d_global + h * glRow, d_meta ? d_meta + h * mtRow : nullptr,
-                                symmetry ? symmetry + h : nullptr,
-                                policy_optimism ? policy_optimism + h : nullptr, d_policy + h * (S + 1), d_value + (size_t)h * 3,
-                                d_score + (size_t)h * 6, d_ownership ? d_ownership + h * S : nullptr, false);
-    if(sync != 0) {
-      handle->engine->sync();
-      handle->engine2->sync();
+    Engine& e0 = handle->e0();
+    const size_t S = (size_t)e0.nnXLen() * e0.nnYLen();
+    const size_t spRow = S * e0.numInputChannels(), glRow = e0.numInputGlobalChannels(), mtRow = e0.numInputMetaChannels();
+    const int K = handle->ways();
+    // Fork: the other engines' streams start after the point of engines[0]'s stream where the fork event is recorded -
+    // at entry (so that inputs the caller enqueued on kmx_handle_stream() are complete for every part), or, with a
+    // stagger, some launches into part 0, which keeps the parts out of phase even when calls are queued back to back.
+    // Join: engines[0]'s stream then waits for every other part's last launch, so the handle stream orders all outputs.
+    try {
+      for(int i = 0; i < K; i++) {
+        int b, c;
+        handle->part(n_rows, i, &b, &c);
+        Engine& e = *handle->engines[i];
+        e.setConcurrency(K);
+        if(i == 0) e.setForkPoint(handle->staggerOp, handle->fork);
+        else hipCheck(hipStreamWaitEvent(e.stream(), handle->fork, 0), "hipStreamWaitEvent");
+        e.evalDevice(c, d_spatial + b * spRow, d_global + b * glRow, d_meta ? d_meta + b * mtRow : nullptr,
+                     symmetry ? symmetry + b : nullptr, policy_optimism ? policy_optimism + b : nullptr, d_policy + b * (S + 1),
+                     d_value + (size_t)b * 3, d_score + (size_t)b * 6, d_ownership ? d_ownership + b * S : nullptr, false);
+        if(i == 0) e.setForkPoint(0, nullptr);
+        else hipCheck(hipEventRecord(handle->join[i - 1], e.stream()), "hipEventRecord");
+      }
+      for(int i = 1; i < K; i++) hipCheck(hipStreamWaitEvent(e0.stream(), handle->join[i - 1], 0), "hipStreamWaitEvent");
+      if(sync != 0) e0.sync();  // covers the other parts through the joins
+    }
+    catch(...) {
+      // one part failed to launch while others may be in flight: drain everything before the error is reported
+      e0.setForkPoint(0, nullptr);
+      for(auto& e : handle->engines) {
+        try { e->sync(); } catch(...) {}
+      }
+      throw;
     }
   });
 }
-void* kmx_handle_stream(kmx_handle* handle) { return handle ? (void*)handle->engine->stream() : nullptr; }
+void* kmx_handle_stream(kmx_handle* handle) { return handle ? (void*)handle->e0().stream() : nullptr; }
 int kmx_handle_sync(kmx_handle* handle) {
   return guarded([&] {
     if(!handle) throw Error(KMX_ERR_INVALID_ARG, "kmx_handle_sync: null handle");
-    handle->engine->sync();
-    if(handle->engine2) handle->engine2->sync();
+    handle->syncAll();
   });
 }
 int kmx_handle_stats(const kmx_handle* handle, uint64_t* rows, uint64_t* batches) {
   if(!handle) return setError(KMX_ERR_INVALID_ARG, "kmx_handle_stats: null handle");
-  if(rows) *rows = handle->engine->rowsProcessed() + (handle->engine2 ? handle->engine2->rowsProcessed() : 0);
+  if(rows) {
+    *rows = 0;
+    for(const auto& e : handle->engines) *rows += e->rowsProcessed();
+  }
   if(batches) *batches = handle->batches;
   return KMX_OK;
 }
 
 int kmx_handle_set_split_min(kmx_handle* handle, int min_rows) {
   return guarded([&] {
-    if(!handle || min_rows < 0) throw Error(KMX_ERR_INVALID_ARG, "kmx_handle_set_split_min: bad argument");
-    handle->engine->sync();
-    if(handle->engine2) handle->engine2->sync();
-    handle->splitMin = min_rows == 0 ? 0x7fffffff : (min_rows < 2 ? 2 : min_rows);
+    if(!handle) throw Error(KMX_ERR_INVALID_ARG, "kmx_handle_set_split_min: null handle");
+    handle->syncAll();
+    // negative: back to the value the handle was created with
+    handle->splitMin = min_rows < 0 ? handle->splitMinAtCreate : min_rows == 0 ? 0x7fffffff : (min_rows < 2 ? 2 : min_rows);
   });
 }
 
 int kmx_handle_set_profiling(kmx_handle* handle, int enabled) {
   return guarded([&] {
     if(!handle) throw Error(KMX_ERR_INVALID_ARG, "kmx_handle_set_profiling: null handle");
-    handle->engine->setProfiling(enabled != 0);
-    if(handle->engine2) handle->engine2->setProfiling(enabled != 0);
+    for(auto& e : handle->engines) e->setProfiling(enabled != 0);
   });
+}
+int kmx_handle_set_graphs(kmx_handle* handle, int enabled) {
+  return guarded([&] {
+    if(!handle) throw Error(KMX_ERR_INVALID_ARG, "kmx_handle_set_graphs: null handle");
+    handle->syncAll();
+    for(auto& e : handle->engines) e->setGraphs(enabled != 0);
+  });
+}
+int kmx_handle_graph_stats(const kmx_handle* handle, uint64_t* graph_launches) {
+  if(!handle || !graph_launches) return setError(KMX_ERR_INVALID_ARG, "kmx_handle_graph_stats: null argument");
+  *graph_launches = 0;
+  for(const auto& e : handle->engines) *graph_launches += e->graphLaunches();
+  return KMX_OK;
 }
 int kmx_handle_get_profile(kmx_handle* handle, kmx_profile_entry* entries, int max_entries, int* n_entries) {
   return guarded([&] {
     if(!handle || !n_entries || (max_entries > 0 && !entries)) throw Error(KMX_ERR_INVALID_ARG, "kmx_handle_get_profile: null argument");
-    std::vector<Engine::ProfileEntry> prof = handle->engine->getProfile();
-    if(handle->engine2)
-      for(const Engine::ProfileEntry& e2 : handle->engine2->getProfile()) {  // same classes: add the second stream's launches
+    std::vector<Engine::ProfileEntry> prof = handle->e0().getProfile();
+    for(size_t k = 1; k < handle->engines.size(); k++)
+      for(const Engine::ProfileEntry& e2 : handle->engines[k]->getProfile()) {  // same classes: add the other streams' launches
         bool found = false;
         for(Engine::ProfileEntry& e : prof)
           if(e.name == e2.name) {

@@ -153,7 +153,7 @@ class Reader {
     std::string t = token(what);
     char* e;
     float v = strtof(t.c_str(), &e);
-    if(e == t.c_str()) bad(std::string(what) + ": expected a number but found '" + t + "'");
+    if(e == t.c_str() || *e != 0) bad(std::string(what) + ": expected a number but found '" + t + "'");
     return v;
   }
   // desc.cpp:40-90
@@ -344,7 +344,7 @@ BlockDesc parseBlock(Reader& r, int version, int trunkC, const std::string& owne
       }
       else {
         b.ropeTheta = r.real("rope theta");
-        if(!(b.ropeTheta > 0.0f)) bad(b.name + ": rope theta must be positive");
+        if(!(b.ropeTheta > 0.0f) || !std::isfinite(b.ropeTheta)) bad(b.name + ": rope theta must be positive and finite");  // desc.cpp:1248
       }
     }
     return b;
@@ -469,7 +469,7 @@ std::unique_ptr<ModelDesc> ModelDesc::loadFromFile(const std::string& path, cons
     if(m.version >= 15) {
       m.trunkNormKind = r.integer("trunkNormKind");
       r.expectZeros(5, "trunk option");
-      if(m.trunkNormKind < 0 || m.trunkNormKind > 3) bad(trunkName + ": unknown trunkNormKind");
+      if(m.trunkNormKind != 0 && m.trunkNormKind != 1) bad(trunkName + ": unknown trunkNormKind");  // STANDARD / RMSNORM only, desc.cpp:1698
     }
     if(m.numBlocks < 1) bad(trunkName + ": trunk num blocks must be positive");
     if(m.trunkC <= 0 || m.midC <= 0 || m.regularC <= 0 || m.gpoolC <= 0) bad(trunkName + ": all numbers of channels must be positive");

@@ -23,6 +23,9 @@ typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorInvalidDevice = 101 };
 typedef void* hipStream_t;
 typedef void* hipEvent_t;
+typedef void* hipGraph_t;
+typedef void* hipGraphExec_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1, hipStreamCaptureModeRelaxed = 2 };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
@@ -43,6 +46,16 @@ inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
 inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : 2; }
 inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+// launches execute immediately here, so there is nothing to capture: refusing makes the engine launch directly
+inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return 801; }
+inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = nullptr; return 801; }
+inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t) { return 801; }
+inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return 801; }
+inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : 2; }

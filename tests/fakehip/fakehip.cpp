@@ -118,6 +118,13 @@ hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+// the dry run logs launches as they are issued: capture is refused, the engine then launches directly
+hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorNotSupported; }
+hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = nullptr; return hipErrorNotSupported; }
+hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, hipGraphNode_t*, char*, size_t) { return hipErrorNotSupported; }
+hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
+hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
 
 // ---- fat binary registration: only the host stub -> kernel name map is kept ----
 void** __hipRegisterFatBinary(const void*) { static void* dummy[4]; return dummy; }

@@ -1,0 +1,223 @@
+"""-m gpu: the paths only bench.py used to exercise (the driver's bench died with a GPU memory fault
+while every other GPU test was green).
+
+* the driver's exact command, from a fresh process, must exit 0 and print one parsable JSON line that carries `roofline`
+  and `cpu_baseline` and is self-consistent;
+* many back-to-back ASYNCHRONOUS device-entry calls (kmx_eval_device, sync=0) on a 256-row handle — the two-engine
+  path, then the single-engine path with per-launch hipEvents (kmx_handle_set_split_min(0) + kmx_handle_set_profiling)
+  — must leave exactly the bits of one synchronous call;
+* the handle stream is an ordering point for both halves of a split batch: inputs copied on it before the call and
+  outputs copied on it after the call, with no other synchronisation, are the right ones.
+"""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO, make_rows
+from katago_amd import capi, modelgen, nninterface as nn
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_bench(args, timeout=600):
+    env = dict(os.environ)
+    env.pop("KMX_SPLIT_MIN", None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, cwd=REPO, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    assert r.returncode == 0, "bench.py %s -> rc %d\n%s\n%s" % (" ".join(args), r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def _check_line(d, steps, warmup):
+    assert d["metric"] == "nn_evals_per_s" and d["unit"] == "evals/s" and d["n_gpus"] == 1
+    assert d["steps"] == steps and d["warmup"] == warmup and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["value"] > 1000 and abs(d["value"] - 256 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0.05 < r["frac"] < 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) / r["achieved"] < 0.01
+
+
+def test_driver_command_exits_zero_with_roofline_and_cpu_baseline():
+    """`python3 bench.py --gpus 1 --steps 20 --warmup 5`, exactly as the driver runs it (BENCH_rNN.json)."""
+    d = _run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5"])
+    _check_line(d, 20, 5)
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+
+
+@pytest.mark.parametrize("rep", range(3))
+def test_driver_command_repeated_fresh_processes(rep):
+    """The round-1 fault was not deterministic: a few more fresh processes, without the CPU leg."""
+    _check_line(_run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"]), 20, 5)
+
+
+def test_default_command_runs():
+    d = _run_bench(["--no-cpu-baseline"])
+    _check_line(d, d["steps"], d["warmup"])
+
+
+@pytest.fixture(scope="module")
+def big_handle(tmp_path_factory):
+    nn.globalInitialize()
+    p = os.path.join(str(tmp_path_factory.mktemp("async")), "b18.bin")
+    modelgen.write_model(p, "b18c384nbt", seed=77)
+    ctx = nn.createComputeContext([0], 19, 19, precision="bf16")
+    h = nn.createComputeHandle(ctx, nn.loadModelFile(p), 256)
+    yield h
+    h.close()
+
+
+def _device_buffers(n):
+    import torch
+
+    return (torch.zeros((n, 362), device="cuda"), torch.zeros((n, 3), device="cuda"), torch.zeros((n, 6), device="cuda"),
+            torch.zeros((n, 361), device="cuda"))
+
+
+@pytest.mark.parametrize("mode", ["split", "single", "single_profiled"])
+def test_many_async_device_calls_equal_one_synchronous_call(big_handle, mode):
+    """40 queued sync=0 calls (what bench.py's timed region and its hipEvent pass do), alternating between two input
+    sets so that a call reading the wrong call's row parameters or buffers would show; then bit-exact comparison with
+    the synchronous results of both sets."""
+    import torch
+
+    h, lib = big_handle, big_handle._lib
+    rng = np.random.default_rng(5)
+    sets = []
+    for k in range(2):
+        sp, gl = make_rows(rng, 256, 19, [(19, 19), (13, 13), (9, 9), (19, 10)] * 64 if k else None)
+        sym = rng.integers(0, 8, 256).astype(np.int32)
+        opt = rng.random(256).astype(np.float32)
+        want = nn.getOutput(h, sp, gl, sym, opt)  # host entry, synchronous
+        sets.append((torch.from_numpy(sp).cuda(), torch.from_numpy(gl).cuda(), sym, opt, want, _device_buffers(256)))
+    torch.cuda.synchronize()
+    capi.check(lib.kmx_handle_set_split_min(h._p, -1 if mode == "split" else 0), lib)
+    if mode == "single_profiled":
+        capi.check(lib.kmx_handle_set_profiling(h._p, 1), lib)
+    try:
+        for i in range(40):
+            d_sp, d_gl, sym, opt, _, (d_pol, d_val, d_sc, d_own) = sets[i & 1]
+            nn.getOutputDevice(h, d_sp.data_ptr(), d_gl.data_ptr(), sym, opt, d_pol.data_ptr(), d_val.data_ptr(), d_sc.data_ptr(),
+                               d_own.data_ptr(), sync=False)
+        h.sync()
+        if mode == "single_profiled":
+            ent = (capi.ProfileEntry * 32)()
+            cnt = ctypes.c_int()
+            capi.check(lib.kmx_handle_get_profile(h._p, ent, 32, ctypes.byref(cnt)), lib)
+            prof = {ent[i].name.decode(): ent[i].launches for i in range(cnt.value)}
+            assert prof["conv3x3"] == 40 * 73 and prof["input_stage"] == 40, prof
+    finally:
+        capi.check(lib.kmx_handle_set_profiling(h._p, 0), lib)
+        capi.check(lib.kmx_handle_set_split_min(h._p, -1), lib)
+    for _, _, _, _, want, (d_pol, d_val, d_sc, d_own) in sets:
+        assert np.array_equal(d_pol.cpu().numpy(), want["policy"]) and np.array_equal(d_val.cpu().numpy(), want["value"])
+        assert np.array_equal(d_sc.cpu().numpy(), want["score"]) and np.array_equal(d_own.cpu().numpy(), want["ownership"])
+
+
+def test_first_launch_of_a_fresh_process_is_the_device_entry():
+    """bench.py's situation: no host-entry call has warmed anything up before the first asynchronous split call."""
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+from conftest import make_rows
+from katago_amd import modelgen, nninterface as nn
+nn.globalInitialize()
+modelgen.write_model("/tmp/kmx_fresh_b18.bin", "b18c384nbt", seed=3)
+h = nn.createComputeHandle(nn.createComputeContext([0], 19, 19, precision="bf16"), nn.loadModelFile("/tmp/kmx_fresh_b18.bin"), 256)
+sp, gl = make_rows(np.random.default_rng(0), 256)
+sym = (np.arange(256) %% 8).astype(np.int32)
+d_sp, d_gl = torch.from_numpy(sp).cuda(), torch.from_numpy(gl).cuda()
+outs = [torch.zeros((256, k), device="cuda") for k in (362, 3, 6, 361)]
+torch.cuda.synchronize()
+for _ in range(25):
+    nn.getOutputDevice(h, d_sp.data_ptr(), d_gl.data_ptr(), sym, None, *[o.data_ptr() for o in outs], sync=False)
+h.sync()
+got = [o.cpu().numpy() for o in outs]
+want = nn.getOutput(h, sp, gl, sym)
+assert all(np.array_equal(g, want[k]) for g, k in zip(got, ("policy", "value", "score", "ownership")))
+print("FRESH_OK")
+""" % (REPO, REPO)
+    for _ in range(2):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "FRESH_OK" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
+def test_handle_stream_orders_inputs_and_outputs_of_a_split_batch(big_handle):
+    """in the split path the second engine's stream used to be unordered against the stream
+    kmx_handle_stream() returns. Inputs are copied ON the handle stream right before an asynchronous call and outputs
+    are copied out ON the handle stream right after it; only that stream is synchronised."""
+    import torch
+
+    h, lib = big_handle, big_handle._lib
+    rng = np.random.default_rng(11)
+    sp, gl = make_rows(rng, 256)
+    sym = rng.integers(0, 8, 256).astype(np.int32)
+    want = nn.getOutput(h, sp, gl, sym)
+    stream = torch.cuda.ExternalStream(lib.kmx_handle_stream(h._p))
+    pin_sp, pin_gl = torch.from_numpy(sp).pin_memory(), torch.from_numpy(gl).pin_memory()
+    d_sp, d_gl = torch.zeros(sp.shape, device="cuda"), torch.zeros(gl.shape, device="cuda")
+    d_pol, d_val, d_sc, d_own = _device_buffers(256)
+    host = [torch.zeros(t.shape).pin_memory() for t in (d_pol, d_val, d_sc, d_own)]
+    torch.cuda.synchronize()
+    for _ in range(3):
+        d_sp.zero_(), d_gl.zero_()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            d_sp.copy_(pin_sp, non_blocking=True)
+            d_gl.copy_(pin_gl, non_blocking=True)
+            nn.getOutputDevice(h, d_sp.data_ptr(), d_gl.data_ptr(), sym, None, d_pol.data_ptr(), d_val.data_ptr(), d_sc.data_ptr(),
+                               d_own.data_ptr(), sync=False)
+            for dst, src in zip(host, (d_pol, d_val, d_sc, d_own)):
+                dst.copy_(src, non_blocking=True)
+        stream.synchronize()
+        for got, k in zip(host, ("policy", "value", "score", "ownership")):
+            assert np.array_equal(got.numpy(), want[k]), k
+
+
+@pytest.mark.parametrize("n", [1, 8, 64, 200, 256])
+def test_graph_replay_is_bit_identical_to_direct_launches(big_handle, n):
+    """hipGraph replay of the launch schedule (kmx_handle_set_graphs): the second pass with the same row count and buffers
+    captures, later ones replay. Same kernels, same arguments, same order => the same bits as direct launches, for the
+    host entry (engine-owned staging buffers) and the device entry, split (256) and unsplit."""
+    import torch
+
+    h, lib = big_handle, big_handle._lib
+    rng = np.random.default_rng(100 + n)
+    sp, gl = make_rows(rng, n, 19, [(19, 19), (9, 9), (13, 13), (19, 19)] * (n // 4 + 1))
+    sym = rng.integers(0, 8, n).astype(np.int32)
+    opt = rng.random(n).astype(np.float32)
+    capi.check(lib.kmx_handle_set_graphs(h._p, 0), lib)
+    want = nn.getOutput(h, sp, gl, sym, opt)
+    capi.check(lib.kmx_handle_set_graphs(h._p, 1), lib)
+    before = ctypes.c_uint64()
+    capi.check(lib.kmx_handle_graph_stats(h._p, ctypes.byref(before)), lib)
+    try:
+        for rep in range(4):  # direct, capture + replay, replay, replay
+            got = nn.getOutput(h, sp, gl, sym, opt)
+            for k in want:
+                assert np.array_equal(got[k], want[k]), (rep, k)
+        d_sp, d_gl = torch.from_numpy(sp).cuda(), torch.from_numpy(gl).cuda()
+        outs = _device_buffers(n)
+        torch.cuda.synchronize()
+        for rep in range(4):
+            for o in outs:
+                o.zero_()
+            torch.cuda.synchronize()
+            nn.getOutputDevice(h, d_sp.data_ptr(), d_gl.data_ptr(), sym, opt, *[o.data_ptr() for o in outs], sync=(rep % 2 == 0))
+            h.sync()
+            for o, k in zip(outs, ("policy", "value", "score", "ownership")):
+                assert np.array_equal(o.cpu().numpy(), want[k]), (rep, k)
+        after = ctypes.c_uint64()
+        capi.check(lib.kmx_handle_graph_stats(h._p, ctypes.byref(after)), lib)
+        parts = 2 if n >= 224 else 1
+        assert after.value - before.value >= 2 * 3 * parts - 2, (before.value, after.value)  # replays really happened
+    finally:
+        capi.check(lib.kmx_handle_set_graphs(h._p, 1), lib)
