@@ -35,7 +35,8 @@ extern "C" {
  * 3: + kmx_test_rmsnorm / kmx_test_attention / kmx_test_swiglu (experimental unit hooks). Additive over 2.
  * 4: + kmx_handle_set_graphs / kmx_handle_graph_stats (hipGraph replay of the launch schedule); kmx_handle_set_split_min
  *    accepts a negative value (restore the creation value); the handle stream orders both halves of a split batch.
- *    Additive over 3. */
+ *    + kmx_test_pointwise_pair (unit hook of the fused 1x1 -> 1x1 seam kernel); + kmx_batcher_* (persistent leaf
+ *    batcher). Additive over 3. */
 #define KMX_ABI_VERSION 4
 
 typedef enum kmx_status {
@@ -189,6 +190,31 @@ int kmx_pack_row(const float* row_spatial_nhwc, int nn_x_len, int nn_y_len, int 
 void* kmx_handle_stream(kmx_handle* handle);
 int kmx_handle_sync(kmx_handle* handle);
 
+/* ---- persistent leaf batcher (north_star: "a persistent device-side leaf batcher over a thin C-ABI") ----
+ * Replaces the server half of NNEvaluator — serve() popping up to maxBatch rows off a queue and calling getOutput
+ * synchronously (nneval.cpp:562-752, core/threadsafequeue.h:173-189) — for callers that submit rows themselves:
+ *   kmx_batcher_submit  thread-safe, called by the search thread that owns the leaf: reserves a row of the batch that is
+ *                       filling and bit-packs the fp32 NHWC feature planes (all V7 planes are 0/1; any other value fails the
+ *                       batch with KMX_ERR_INVALID_ARG) straight into that batch's pinned staging, outside the lock.
+ *                       Blocks only while every staging set is busy. Returns a ticket.
+ *   kmx_batcher_wait    blocks until the ticket's batch is back from the device and copies the row's outputs (layout as
+ *                       kmx_eval: policy nn_x*nn_y+1, value 3, score 6, ownership nn_x*nn_y or NULL). Each ticket is
+ *                       waited for exactly once.
+ * Batching is greedy like the reference's (a batch is sealed as soon as the device has room for it and at least one row
+ * is waiting; it never waits for more), but up to max_in_flight batches (default 2 when <= 0) are between H2D and D2H at
+ * once on their own engines and streams, so copies and kernels of consecutive batches overlap and rows arriving while
+ * the device is busy accumulate into the next batch. rows/batches as nneval.cpp:712-713. A row's outputs are
+ * bit-identical to the same row through kmx_eval. */
+typedef struct kmx_batcher kmx_batcher;
+int kmx_batcher_create(kmx_context* ctx, const kmx_model* model, int max_batch_size, int max_in_flight, int gpu_idx,
+                       kmx_batcher** out);
+void kmx_batcher_free(kmx_batcher* batcher); /* fails rows not yet launched, completes those on the device */
+int kmx_batcher_submit(kmx_batcher* batcher, const float* row_spatial, const float* row_global, const float* row_meta,
+                       int symmetry, float policy_optimism, int want_ownership, uint64_t* ticket);
+int kmx_batcher_wait(kmx_batcher* batcher, uint64_t ticket, float* out_policy, float* out_value, float* out_score,
+                     float* out_ownership);
+int kmx_batcher_stats(kmx_batcher* batcher, uint64_t* rows, uint64_t* batches);
+
 /* NNEvaluator counters (nneval.cpp:330-347, incremented :712-713): rows = evaluated
  * positions, batches = kmx_eval calls. */
 int kmx_handle_stats(const kmx_handle* handle, uint64_t* rows, uint64_t* batches);
@@ -213,10 +239,12 @@ typedef struct kmx_profile_entry {
  * restores the threshold the handle was created with. */
 int kmx_handle_set_split_min(kmx_handle* handle, int min_rows);
 int kmx_handle_set_profiling(kmx_handle* handle, int enabled); /* resets the accumulated profile */
-/* hipGraph replay (default on; environment KMX_GRAPHS=0 at creation turns it off): the ~130 kernel launches of a pass are
+/* hipGraph replay (default off; environment KMX_GRAPHS=1 at creation turns it on): the ~130 kernel launches of a pass are
  * captured the second time a (row count, buffer pointers) combination occurs and replayed with one hipGraphLaunch from
  * then on - what NNEvaluator's warm-up evaluations (setIsWarmup, nneval.cpp:487-560) prepare. Same kernels, arguments
- * and order as direct launches: bit-identical results. graph_launches counts replayed passes (all engines of a handle). */
+ * and order as direct launches: bit-identical results. graph_launches counts replayed passes (all engines of a handle).
+ * Measured on MI355X (b18c384nbt, batch 1 ... 256): the same rate as direct launches to 1 % - a pass is bound by the
+ * kernels, not by the CPU's launch calls - hence opt-in. */
 int kmx_handle_set_graphs(kmx_handle* handle, int enabled);
 int kmx_handle_graph_stats(const kmx_handle* handle, uint64_t* graph_launches);
 int kmx_handle_get_profile(kmx_handle* handle, kmx_profile_entry* entries, int max_entries, int* n_entries);
@@ -280,6 +308,14 @@ int kmx_test_resblock(const kmx_resblock_desc* desc, int batch, int nn_x_len, in
 int kmx_test_gpoolblock(const kmx_gpoolblock_desc* desc, int batch, int nn_x_len, int nn_y_len,
                         int precision_mode, const float* in_nhwc, const float* mask_nhw, float* out_nhwc);
 
+/* Unit hook for the fused seam of two 1x1 convolutions between nested-bottleneck blocks (NestedBottleneckResidualBlock::apply,
+ * eigenbackend.cpp:1308-1314, at a block boundary): trunk = resid + W1 x; t = act1(bn1(trunk)) mask; mid = W2 t;
+ * mid_act = act2(bn2(mid)) mask. fused = 1: the one-launch kernel (KMX_ERR_UNSUPPORTED when no kernel exists for the
+ * channel counts), fused = 0: the two convolution launches it replaces. Weights are [out][in]. */
+int kmx_test_pointwise_pair(int batch, int nn_x_len, int nn_y_len, int precision_mode, int c1, int c2, int c3,
+                            const float* in_nhwc, const float* resid_nhwc, const float* w1_oi, const float* scale1,
+                            const float* bias1, int act1, const float* w2_oi, const float* scale2, const float* bias2, int act2,
+                            const float* mask_nhw, int fused, float* out_trunk_raw, float* out_mid_raw, float* out_mid_act);
 /* EXPERIMENTAL unit hooks for the layers of model-v17 transformer trunks that are not convolutions (the reference has no
  * test hook for them; its definitions are TransformerRMSNormLayer / RMSNormLayer, eigenbackend.cpp:867-1034, the attention
  * of TransformerAttentionBlock::apply, :1376-1600, and the SwiGLU of TransformerFFNBlock::apply, :1674-1689). fp32 NHWC

@@ -18,6 +18,7 @@
 #include "neuralnet/modelversion.h"
 #include "neuralnet/desc.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -171,6 +172,13 @@ ComputeContext* NeuralNet::createComputeContext(
     else if(p == "fp32") precisionMode = KMX_PREC_FP32;
     else if(p == "auto") precisionMode = KMX_PREC_AUTO;
     else throw StringError("katamxPrecision must be one of fp16, bf16, fp32, auto");
+  }
+  else if(const char* e = getenv("KATAMX_PRECISION")) {
+    // for the reference commands that build their NNEvaluator without a user config (runsearchtestsv8, runtests ...)
+    string p = e;
+    if(p == "fp16") precisionMode = KMX_PREC_FP16;
+    else if(p == "bf16") precisionMode = KMX_PREC_BF16;
+    else if(p != "auto" && p != "") throw StringError("KATAMX_PRECISION must be one of fp16, bf16, auto");
   }
   context->precisionMode = precisionMode;
 #ifndef KMX_USE_ORACLE

@@ -16,8 +16,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libkatamx.so")
 
-SOURCES = ["conv_mfma.hip", "conv_bench.hip", "misc_kernels.hip", "transformer_kernels.hip", "engine.cpp", "model_desc.cpp", "kmx_api.cpp"]
-HEADERS = ["kernels.h", "device_common.h", "conv_kernel.h", "engine.h", "model_desc.h", os.path.join("..", "..", "include", "katamx.h")]
+SOURCES = ["conv_mfma.hip", "pointwise.hip", "conv_bench.hip", "misc_kernels.hip", "transformer_kernels.hip", "engine.cpp", "model_desc.cpp", "kmx_api.cpp", "batcher.cpp"]
+HEADERS = ["kernels.h", "device_common.h", "conv_kernel.h", "pointwise_kernel.h", "engine.h", "model_desc.h", os.path.join("..", "..", "include", "katamx.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-x", "hip"]
 

@@ -107,6 +107,11 @@ SIGNATURES = {
                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "kmx_eval_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, _IP, _FP,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    "kmx_batcher_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "kmx_batcher_free": (None, [ctypes.c_void_p]),
+    "kmx_batcher_submit": (ctypes.c_int, [ctypes.c_void_p, _FP, _FP, _FP, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]),
+    "kmx_batcher_wait": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, _FP, _FP, _FP, _FP]),
+    "kmx_batcher_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "kmx_handle_stream": (ctypes.c_void_p, [ctypes.c_void_p]),
     "kmx_handle_sync": (ctypes.c_int, [ctypes.c_void_p]),
     "kmx_handle_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
@@ -118,6 +123,8 @@ SIGNATURES = {
     "kmx_bench_conv": (ctypes.c_int, [ctypes.c_int] * 10 + [ctypes.POINTER(ctypes.c_double)]),
     "kmx_debug_conv_cfg": (ctypes.c_int, [ctypes.c_int] * 3 + [_IP, _IP]),
     "kmx_bench_mfma": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_double)] * 3),
+    "kmx_test_pointwise_pair": (ctypes.c_int, [ctypes.c_int] * 7 + [_FP, _FP, _FP, _FP, _FP, ctypes.c_int, _FP, _FP, _FP, ctypes.c_int, _FP,
+                                               ctypes.c_int, _FP, _FP, _FP]),
     "kmx_test_conv": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP]),
     "kmx_test_bnact": (ctypes.c_int, [ctypes.POINTER(BnActDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP, _FP]),
     "kmx_test_resblock": (ctypes.c_int, [ctypes.POINTER(ResBlockDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP, _FP]),

@@ -1,0 +1,367 @@
+// batcher.cpp — the persistent leaf batcher behind the C ABI (include/katamx.h, kmx_batcher_*).
+//
+// Replaces, for callers that adopt it, the server half of the reference's NNEvaluator (cpp/neuralnet/nneval.cpp:562-752:
+// serve() popping up to maxBatch NNResultBuf* from a ThreadsafeQueue, cpp/core/threadsafequeue.h:173-189, and calling
+// NeuralNet::getOutput synchronously) and the row copies of the backend's getOutput:
+//   * kmx_batcher_submit is called by the SEARCH thread that owns the leaf. It reserves a row in the batch that is filling and
+//     bit-packs the row's feature planes straight into that batch's PINNED staging (1012 instead of 31768 bytes per 19x19 row;
+//     the reference's binaryInputNCHWPacked layout) — in parallel with the other submitters, outside the lock.
+//   * a dispatcher thread seals the filling batch as soon as the device has room (at most `max_in_flight` batches between H2D
+//     and D2H) and enqueues H2D -> schedule -> D2H asynchronously on that slot's own engine and stream: greedy, like
+//     waitPopUpToN — it never waits for more rows once one is waiting and the device can take it — but with several batches
+//     in flight, so H2D of batch k+1, the kernels of batch k and D2H of batch k-1 overlap, and rows that arrive while the
+//     device is busy accumulate into the next batch instead of queueing behind a synchronous call.
+//   * a completion thread waits for each batch's event and wakes exactly the threads whose rows were in it.
+//   * kmx_batcher_wait copies the row's results out of pinned memory.
+// Rows/batches counters have the meaning of nneval.cpp:712-713. Rows never interact, so a row's outputs are bit-identical to
+// the same row through kmx_eval, whatever batch it lands in (tests/test_gpu_batcher.py).
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "../../include/katamx.h"
+#include "engine.h"
+#include "model_desc.h"
+
+namespace kmx {
+
+// One row of fp32 NHWC binary feature planes -> bit planes [C][ceil(S/8)], MSB first (packBits of
+// dataio/trainingwrite.cpp:314-337, plane by plane). Returns false if a value is neither 0 nor 1.
+bool packRowNHWC(const float* row, int S, int C, unsigned char* out) {
+  const int PB = (S + 7) / 8;
+  memset(out, 0, (size_t)C * PB);
+  bool binary = true;
+  for(int p = 0; p < S; p++) {
+    const float* cell = row + (size_t)p * C;
+    unsigned m = 0, bad = 0;
+    for(int c = 0; c < C; c++) {  // branch-free: which channels are set in this cell
+      uint32_t u;
+      memcpy(&u, cell + c, 4);
+      m |= (unsigned)(u != 0u) << c;
+      bad |= (unsigned)(u != 0u && u != 0x3f800000u);
+    }
+    binary = binary && bad == 0;
+    const int byte = p >> 3;
+    const unsigned char bit = (unsigned char)(1u << (7 - (p & 7)));
+    while(m) {
+      const int c = __builtin_ctz(m);
+      m &= m - 1;
+      out[(size_t)c * PB + byte] |= bit;
+    }
+  }
+  return binary;
+}
+
+class Batcher {
+ public:
+  Batcher(const ModelDesc& model, int nnXLen, int nnYLen, int maxBatch, int dtype, int device, int maxInFlight, int numSlots)
+    : maxBatch_(maxBatch), maxInFlight_(maxInFlight) {
+    S_ = nnXLen * nnYLen;
+    for(int i = 0; i < numSlots; i++) slots_.emplace_back();
+    for(Slot& s : slots_) {
+      s.eng.reset(new Engine(model, nnXLen, nnYLen, maxBatch, dtype, device));
+      s.sym.resize(maxBatch);
+      s.opt.resize(maxBatch);
+    }
+    cin_ = slots_[0].eng->numInputChannels();
+    gin_ = slots_[0].eng->numInputGlobalChannels();
+    min_ = slots_[0].eng->numInputMetaChannels();
+    if(cin_ > 32) throw Error(KMX_ERR_UNSUPPORTED, "batcher: more than 32 spatial input planes");
+    dispatcher_ = std::thread([this] { dispatchLoop(); });
+    completer_ = std::thread([this] { completeLoop(); });
+  }
+  ~Batcher() {
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      closing_ = true;
+    }
+    cvWork_.notify_all();
+    cvComplete_.notify_all();
+    cvFree_.notify_all();
+    for(Slot& s : slots_) s.cvDone.notify_all();
+    if(dispatcher_.joinable()) dispatcher_.join();
+    if(completer_.joinable()) completer_.join();
+  }
+
+  uint64_t submit(const float* rowSpatial, const float* rowGlobal, const float* rowMeta, int symmetry, float optimism, bool wantOwnership) {
+    if(!rowSpatial || !rowGlobal) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_submit: null row");
+    if(symmetry < 0 || symmetry > 7) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_submit: symmetry must be in 0..7");
+    if((min_ > 0) != (rowMeta != nullptr))
+      throw Error(KMX_ERR_INVALID_ARG, min_ > 0 ? "this net has an sgf-metadata encoder: rows need the metadata input"
+                                                : "this net has no sgf-metadata encoder: the metadata input must be NULL");
+    int si, r;
+    uint32_t gen;
+    {
+      std::unique_lock<std::mutex> l(mu_);
+      for(;;) {
+        if(closing_) throw Error(KMX_ERR_INTERNAL, "kmx_batcher_submit: the batcher is shutting down");
+        if(filling_ < 0) {
+          int f = -1;
+          for(size_t i = 0; i < slots_.size(); i++)
+            if(slots_[i].state == FREE) { f = (int)i; break; }
+          if(f < 0) {  // every staging set is filling, in flight or waiting to be collected
+            cvFree_.wait(l);
+            continue;
+          }
+          Slot& s = slots_[f];
+          s.state = FILLING;
+          s.count = 0;
+          s.copied.store(0, std::memory_order_relaxed);
+          s.collected = 0;
+          s.anyOwner = false;
+          s.error = KMX_OK;
+          s.gen++;
+          filling_ = f;
+        }
+        Slot& s = slots_[filling_];
+        si = filling_;
+        r = s.count++;
+        gen = s.gen;
+        s.sym[r] = symmetry;
+        s.opt[r] = optimism;
+        s.anyOwner = s.anyOwner || wantOwnership;
+        if(s.count == maxBatch_) {  // full: no further reservations, the next row opens a new batch
+          s.state = SEALED;
+          sealed_.push_back(filling_);
+          filling_ = -1;
+        }
+        break;
+      }
+    }
+    cvWork_.notify_one();
+    // stage the row outside the lock: the dispatcher launches only once every reserved row has been copied
+    Slot& s = slots_[si];
+    const bool binary = packRowNHWC(rowSpatial, S_, cin_, s.eng->stagedPackedRow(r));
+    memcpy(s.eng->stagedGlobalRow(r), rowGlobal, (size_t)gin_ * sizeof(float));
+    if(min_ > 0) memcpy(s.eng->stagedMetaRow(r), rowMeta, (size_t)min_ * sizeof(float));
+    if(!binary) s.nonBinary.store(true, std::memory_order_relaxed);
+    s.copied.fetch_add(1, std::memory_order_release);
+    return ((uint64_t)gen << 32) | ((uint64_t)si << 16) | (uint64_t)r;
+  }
+
+  void wait(uint64_t ticket, float* outPolicy, float* outValue, float* outScore, float* outOwnership) {
+    const uint32_t gen = (uint32_t)(ticket >> 32);
+    const int si = (int)((ticket >> 16) & 0xffff), r = (int)(ticket & 0xffff);
+    if(si < 0 || si >= (int)slots_.size() || !outPolicy || !outValue || !outScore) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_wait: bad ticket or null output");
+    Slot& s = slots_[si];
+    int err;
+    {
+      std::unique_lock<std::mutex> l(mu_);
+      if(s.gen != gen || r >= s.count || s.state == FREE) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_wait: stale ticket (already collected?)");
+      while(s.state != DONE) s.cvDone.wait(l);  // on shutdown the dispatcher fails the batches it will not launch
+      err = s.error;
+      if(err == KMX_OK && outOwnership && !s.anyOwner) {
+        err = KMX_ERR_INVALID_ARG;  // still counts as collected below
+        s.errorMsg = "kmx_batcher_wait: ownership requested for a batch in which no row was submitted with want_ownership";
+      }
+    }
+    if(err == KMX_OK) {
+      memcpy(outPolicy, s.eng->stagedPolicy(r), (size_t)(S_ + 1) * sizeof(float));
+      memcpy(outValue, s.eng->stagedValue(r), 3 * sizeof(float));
+      memcpy(outScore, s.eng->stagedScore(r), 6 * sizeof(float));
+      if(outOwnership) memcpy(outOwnership, s.eng->stagedOwnership(r), (size_t)S_ * sizeof(float));
+    }
+    std::string msg;
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      if(err != KMX_OK) msg = s.errorMsg;
+      if(++s.collected == s.count) {
+        s.state = FREE;
+        cvFree_.notify_all();
+      }
+    }
+    if(err != KMX_OK) throw Error(err, msg);
+  }
+
+  void stats(uint64_t* rows, uint64_t* batches) {
+    std::lock_guard<std::mutex> l(mu_);
+    if(rows) *rows = rows_;
+    if(batches) *batches = batches_;
+  }
+  int numInputMetaChannels() const { return min_; }
+
+ private:
+  enum State { FREE, FILLING, SEALED, RUNNING, DONE };
+  struct Slot {
+    std::unique_ptr<Engine> eng;
+    State state = FREE;
+    int count = 0;                 // rows reserved
+    std::atomic<int> copied{0};    // rows staged
+    std::atomic<bool> nonBinary{false};
+    int collected = 0;             // rows whose results were taken
+    uint32_t gen = 0;
+    bool anyOwner = false;
+    std::vector<int> sym;
+    std::vector<float> opt;
+    int error = KMX_OK;
+    std::string errorMsg;
+    std::condition_variable cvDone;
+  };
+
+  void dispatchLoop() {
+    std::unique_lock<std::mutex> l(mu_);
+    for(;;) {
+      cvWork_.wait(l, [&] {
+        return closing_ || (running_ < maxInFlight_ && (!sealed_.empty() || (filling_ >= 0 && slots_[filling_].count > 0)));
+      });
+      if(closing_) {
+        // rows that were never launched: fail their waiters
+        auto fail = [&](int i) {
+          Slot& s = slots_[i];
+          s.error = KMX_ERR_INTERNAL;
+          s.errorMsg = "the batcher shut down before this row was evaluated";
+          s.state = DONE;
+          s.cvDone.notify_all();
+        };
+        for(int i : sealed_) fail(i);
+        sealed_.clear();
+        if(filling_ >= 0) {
+          fail(filling_);
+          filling_ = -1;
+        }
+        return;
+      }
+      int si;
+      if(!sealed_.empty()) {
+        si = sealed_.front();
+        sealed_.pop_front();
+      }
+      else {
+        si = filling_;  // greedy: take what is there (threadsafequeue.h:173-189), the next row opens a new batch
+        slots_[si].state = SEALED;
+        filling_ = -1;
+      }
+      Slot& s = slots_[si];
+      running_++;
+      const int n = s.count;
+      const bool anyOwner = s.anyOwner;
+      l.unlock();
+      while(s.copied.load(std::memory_order_acquire) < n) std::this_thread::yield();  // a row copy takes a few microseconds
+      int err = KMX_OK;
+      std::string msg;
+      try {
+        if(s.nonBinary.exchange(false)) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_submit: spatial features must be 0 or 1 (bit-packed staging); use kmx_eval for other inputs");
+        s.eng->launchStagedPacked(n, s.sym.data(), s.opt.data(), anyOwner);
+      }
+      catch(const Error& e) { err = e.code; msg = e.what(); }
+      catch(const std::exception& e) { err = KMX_ERR_INTERNAL; msg = e.what(); }
+      l.lock();
+      s.error = err;
+      s.errorMsg = msg;
+      s.state = RUNNING;
+      inflight_.push_back(si);
+      cvComplete_.notify_one();
+    }
+  }
+
+  void completeLoop() {
+    std::unique_lock<std::mutex> l(mu_);
+    for(;;) {
+      // a batch the dispatcher has counted (running_) but not yet handed over is still coming
+      cvComplete_.wait(l, [&] { return !inflight_.empty() || (closing_ && running_ == 0); });
+      if(inflight_.empty()) return;
+      const int si = inflight_.front();
+      inflight_.pop_front();
+      Slot& s = slots_[si];
+      l.unlock();
+      int err = KMX_OK;
+      std::string msg;
+      if(s.error == KMX_OK) {
+        try { s.eng->sync(); }
+        catch(const Error& e) { err = e.code; msg = e.what(); }
+        catch(const std::exception& e) { err = KMX_ERR_INTERNAL; msg = e.what(); }
+      }
+      l.lock();
+      if(err != KMX_OK) {
+        s.error = err;
+        s.errorMsg = msg;
+      }
+      if(s.error == KMX_OK) {
+        rows_ += (uint64_t)s.count;
+        batches_ += 1;
+      }
+      s.state = DONE;
+      running_--;
+      s.cvDone.notify_all();
+      cvWork_.notify_one();
+    }
+  }
+
+  int maxBatch_, maxInFlight_, S_ = 0, cin_ = 0, gin_ = 0, min_ = 0;
+  std::deque<Slot> slots_;  // a Slot holds a condition variable: never moved
+  std::mutex mu_;
+  std::condition_variable cvWork_, cvComplete_, cvFree_;
+  std::deque<int> sealed_, inflight_;
+  int filling_ = -1, running_ = 0;
+  bool closing_ = false;
+  uint64_t rows_ = 0, batches_ = 0;
+  std::thread dispatcher_, completer_;
+};
+
+}  // namespace kmx
+
+using namespace kmx;
+
+struct kmx_batcher {
+  std::unique_ptr<Batcher> b;
+};
+
+// shared with kmx_api.cpp
+namespace kmx {
+int apiGuarded(const std::function<void()>& f);
+int apiDtypeFor(const kmx_context* ctx, const kmx_model* model);
+const ModelDesc& apiModelDesc(const kmx_model* model);
+void apiContextDims(const kmx_context* ctx, int* x, int* y);
+int apiSetError(int code, const std::string& msg);
+}  // namespace kmx
+
+extern "C" {
+
+int kmx_batcher_create(kmx_context* ctx, const kmx_model* model, int max_batch_size, int max_in_flight, int gpu_idx, kmx_batcher** out) {
+  return apiGuarded([&] {
+    if(!ctx || !model || !out) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_create: null argument");
+    *out = nullptr;
+    if(max_batch_size < 1 || max_batch_size > 65535) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_create: max_batch_size must be in 1..65535");
+    if(max_in_flight < 1) max_in_flight = 2;
+    if(max_in_flight > 8) max_in_flight = 8;
+    int ndev = 0;
+    if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw Error(KMX_ERR_DEVICE, "no usable HIP device (katamx has no CPU fallback)");
+    const int dev = gpu_idx < 0 ? 0 : gpu_idx;
+    if(dev >= ndev) throw Error(KMX_ERR_DEVICE, "kmx_batcher_create: device index out of range");
+    int x, y;
+    apiContextDims(ctx, &x, &y);
+    std::unique_ptr<kmx_batcher> h(new kmx_batcher());
+    // staging sets: the ones on the device, one filling, one being collected by its waiters
+    h->b.reset(new Batcher(apiModelDesc(model), x, y, max_batch_size, apiDtypeFor(ctx, model), dev, max_in_flight, max_in_flight + 2));
+    *out = h.release();
+  });
+}
+void kmx_batcher_free(kmx_batcher* b) { delete b; }
+
+int kmx_batcher_submit(kmx_batcher* b, const float* row_spatial, const float* row_global, const float* row_meta, int symmetry,
+                       float policy_optimism, int want_ownership, uint64_t* ticket) {
+  return apiGuarded([&] {
+    if(!b || !ticket) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_submit: null argument");
+    *ticket = b->b->submit(row_spatial, row_global, row_meta, symmetry, policy_optimism, want_ownership != 0);
+  });
+}
+int kmx_batcher_wait(kmx_batcher* b, uint64_t ticket, float* out_policy, float* out_value, float* out_score, float* out_ownership) {
+  return apiGuarded([&] {
+    if(!b) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_wait: null batcher");
+    b->b->wait(ticket, out_policy, out_value, out_score, out_ownership);
+  });
+}
+int kmx_batcher_stats(kmx_batcher* b, uint64_t* rows, uint64_t* batches) {
+  if(!b) return apiSetError(KMX_ERR_INVALID_ARG, "kmx_batcher_stats: null batcher");
+  b->b->stats(rows, batches);
+  return KMX_OK;
+}
+
+}  // extern "C"

@@ -159,6 +159,8 @@ void Engine::construct(const ModelDesc& model) {
   hipCheck(hipSetDevice(device_), "hipSetDevice");
   hipCheck(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
   if(const char* e = getenv("KMX_GRAPHS")) useGraphs_ = atoi(e) != 0;
+  if(const char* e = getenv("KMX_FUSE_SEAMS")) fuseSeams_ = atoi(e) != 0;
+  if(const char* e = getenv("KMX_FUSE_MIN_ROWS")) fuseMinRows_ = std::max(1, atoi(e));
   cin_ = model.numInputChannels;
   gin_ = model.numInputGlobalChannels;
   min_ = model.metaEncoderVersion > 0 ? model.numInputMetaChannels : 0;
@@ -236,9 +238,9 @@ const FusedConv* Engine::newConv(const std::vector<ConvSegment>& segs, std::vect
   return convs_.back().get();
 }
 
-void Engine::addConv(const FusedConv* fc, const void* in, int inStride, const float* ncBias, int ncBiasStride,
-                     const void* resid, int residStride, void* rawOut, int rawStride, int rawBegin, int rawEnd,
-                     void* actOut, int actStride, int actBegin, int actEnd, int actKind) {
+ConvArgs Engine::makeConvArgs(const FusedConv* fc, const void* in, int inStride, const float* ncBias, int ncBiasStride,
+                              const void* resid, int residStride, void* rawOut, int rawStride, int rawBegin, int rawEnd,
+                              void* actOut, int actStride, int actBegin, int actEnd, int actKind, double* bytesPerRow) {
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.in = in;
@@ -266,16 +268,70 @@ void Engine::addConv(const FusedConv* fc, const void* in, int inStride, const fl
   a.actKind = actKind;
   a.mask = mask_.as<float>();
   if(inStride < fc->nChunks * KCHUNK) throw Error(KMX_ERR_INTERNAL, "addConv: input stride smaller than the padded channel count");
-  const int dtype = dtype_, ks = fc->ks, coutPad = fc->coutPad;
   // algorithmic traffic: read the input once, the residual once, write each output once (16-bit elements)
   double bytes = 2.0 * S_ * (double)fc->cin;
   if(resid) bytes += 2.0 * S_ * (double)(a.rawEnd - a.rawBegin);
   if(rawOut) bytes += 2.0 * S_ * (double)(a.rawEnd - a.rawBegin);
   if(actOut) bytes += 2.0 * S_ * (double)(a.actEnd - a.actBegin);
-  addOp(ks == 1 ? "conv1x1" : ks == 3 ? "conv3x3" : "conv5x5", 2.0 * fc->macPerCell * S_, bytes, [=](int n, hipStream_t st) {
-    ConvArgs b = a;
-    b.N = n;
-    hipCheck(launchConv(dtype, ks, chooseConvCfg(ks, coutPad, n * cfgScale_), b, st), "convolution launch");
+  if(bytesPerRow) *bytesPerRow = bytes;
+  return a;
+}
+
+void Engine::launchConvOp(const ConvArgs& a, int ks, int n, hipStream_t st) {
+  ConvArgs b = a;
+  b.N = n;
+  hipCheck(launchConv(dtype_, ks, chooseConvCfg(ks, a.coutPad, n * cfgScale_), b, st), "convolution launch");
+}
+
+void Engine::addConv(const FusedConv* fc, const void* in, int inStride, const float* ncBias, int ncBiasStride,
+                     const void* resid, int residStride, void* rawOut, int rawStride, int rawBegin, int rawEnd,
+                     void* actOut, int actStride, int actBegin, int actEnd, int actKind) {
+  double bytes = 0;
+  const ConvArgs a = makeConvArgs(fc, in, inStride, ncBias, ncBiasStride, resid, residStride, rawOut, rawStride, rawBegin, rawEnd, actOut,
+                                  actStride, actBegin, actEnd, actKind, &bytes);
+  const int ks = fc->ks;
+  addOp(ks == 1 ? "conv1x1" : ks == 3 ? "conv3x3" : "conv5x5", 2.0 * fc->macPerCell * S_, bytes,
+        [this, a, ks](int n, hipStream_t st) { launchConvOp(a, ks, n, st); });
+}
+
+// The seam between two nested-bottleneck blocks (pointwise_kernel.h): block i's closing 1x1 convolution into the residual
+// stream `s`, block i+1's preBN + activation, block i+1's opening 1x1 convolution into `mid` with the first inner block's
+// preBN. Batches of at least fuseMinRows_ boards run it as ONE launch in which the activated trunk image never leaves the
+// CU; smaller ones as the two convolution launches it replaces (same arithmetic, bit-identical, tests/test_gpu_pointwise.py).
+void Engine::addSeam(const ConvDesc& post, const void* in, int inStride, const Stream& s, const BnDesc& nextBN, const ConvDesc& pre,
+                     const Stream& mid, const BnDesc& innerBN) {
+  const FusedConv* c1 = newConv({{&post, &nextBN}});
+  const FusedConv* c2 = newConv({{&pre, &innerBN}});
+  double b1 = 0, b2 = 0;
+  const ConvArgs a1 = makeConvArgs(c1, in, inStride, nullptr, 0, s.raw, s.stride, s.raw, s.stride, 0, c1->coutPad, s.act, s.stride, 0,
+                                   c1->coutPad, nextBN.act, &b1);
+  const ConvArgs a2 = makeConvArgs(c2, s.act, s.stride, nullptr, 0, nullptr, 0, mid.raw, mid.stride, 0, c2->coutPad, mid.act, mid.stride, 0,
+                                   c2->coutPad, innerBN.act, &b2);
+  PwPairArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.in = in; pa.inC = inStride;
+  pa.w1 = c1->w.get();
+  pa.resid = s.raw; pa.rawOut = s.raw; pa.trunkC = s.stride;
+  pa.actOut = nullptr;  // only block i+1's opening convolution reads the activated trunk, and that happens in LDS
+  pa.scale1 = c1->scale.as<float>(); pa.bias1 = c1->bias.as<float>(); pa.actKind1 = nextBN.act;
+  pa.w2 = c2->w.get();
+  pa.rawOut2 = mid.raw; pa.actOut2 = mid.act; pa.midC = mid.stride;
+  pa.scale2 = c2->scale.as<float>(); pa.bias2 = c2->bias.as<float>(); pa.actKind2 = innerBN.act;
+  pa.mask = mask_.as<float>();
+  pa.zeroPage = zeroPage_.get();
+  const int C1 = post.inC, C2 = post.outC, C3 = pre.outC, S = S_;
+  // traffic of the fused form: in + residual + trunk raw + mid raw + mid act
+  const double fusedBytes = 2.0 * S_ * ((double)C1 + 2.0 * C2 + 2.0 * C3);
+  addOp("conv1x1_pair", 2.0 * (c1->macPerCell + c2->macPerCell) * S_, fusedBytes, [this, a1, a2, pa, C1, C2, C3, S](int n, hipStream_t st) {
+    if(n >= fuseMinRows_) {
+      PwPairArgs x = pa;
+      x.cells = (long long)n * S;
+      hipCheck(launchPointwisePair(dtype_, C1, C2, C3, x, st), "pointwise pair launch");
+    }
+    else {
+      launchConvOp(a1, 1, n, st);
+      launchConvOp(a2, 1, n, st);
+    }
   });
 }
 
@@ -354,6 +410,7 @@ static void ropeTables(const BlockDesc& b, int X, int Y, std::vector<float>& cos
 }
 
 void Engine::buildStack(const std::vector<BlockDesc>& blocks, const Stream& s, const BnDesc* bnAfter, int depth) {
+  bool openedBySeam = false;  // the previous block's seam launch already ran this block's opening convolution
   for(size_t i = 0; i < blocks.size(); i++) {
     const BlockDesc& b = blocks[i];
     const BnDesc* nextBN = i + 1 < blocks.size() ? (blocks[i + 1].isTransformer() ? nullptr : &blocks[i + 1].preBN) : bnAfter;
@@ -462,14 +519,29 @@ void Engine::buildStack(const std::vector<BlockDesc>& blocks, const Stream& s, c
       mid.act = acts_[3 + 2 * (depth + 1)]->get();
       mid.stride = roundUp(M, 32);
       const BnDesc* firstInnerBN = b.inner[0].isTransformer() ? nullptr : &b.inner[0].preBN;
-      const FusedConv* pre = newConv({{&b.regularConv, firstInnerBN}});
-      if(firstInnerBN != nullptr)
-        addConv(pre, s.act, s.stride, nullptr, 0, nullptr, 0, mid.raw, mid.stride, 0, pre->coutPad, mid.act, mid.stride, 0,
-                pre->coutPad, firstInnerBN->act);
-      else
-        addConv(pre, s.act, s.stride, nullptr, 0, nullptr, 0, mid.raw, mid.stride, 0, pre->coutPad, nullptr, 0, 0, 0, KMX_ACT_IDENTITY);
+      if(!openedBySeam) {
+        const FusedConv* pre = newConv({{&b.regularConv, firstInnerBN}});
+        if(firstInnerBN != nullptr)
+          addConv(pre, s.act, s.stride, nullptr, 0, nullptr, 0, mid.raw, mid.stride, 0, pre->coutPad, mid.act, mid.stride, 0,
+                  pre->coutPad, firstInnerBN->act);
+        else
+          addConv(pre, s.act, s.stride, nullptr, 0, nullptr, 0, mid.raw, mid.stride, 0, pre->coutPad, nullptr, 0, 0, 0, KMX_ACT_IDENTITY);
+      }
+      openedBySeam = false;
       buildStack(b.inner, mid, &b.midBN, depth + 1);
-      addResidualConv(b.finalConv, mid.act, mid.stride, s, nextBN);
+      // the closing convolution, fused with the next block's opening one when that is a nested block of a supported shape
+      const BlockDesc* nx = i + 1 < blocks.size() ? &blocks[i + 1] : nullptr;
+      const bool seam = fuseSeams_ && nx != nullptr && nx->kind == BlockKind::Nested && nextBN != nullptr && !nx->inner.empty() &&
+                        !nx->inner[0].isTransformer() && b.finalConv.ky == 1 && b.finalConv.kx == 1 && nx->regularConv.ky == 1 &&
+                        nx->regularConv.kx == 1 && nx->regularConv.inC == b.finalConv.outC &&
+                        pointwisePairSupported(b.finalConv.inC, b.finalConv.outC, nx->regularConv.outC);
+      if(seam) {
+        Stream nmid = mid;  // the next block's mid stream lives in the same buffers (same nesting depth)
+        nmid.stride = roundUp(nx->regularConv.outC, 32);
+        addSeam(b.finalConv, mid.act, mid.stride, s, *nextBN, nx->regularConv, nmid, nx->inner[0].preBN);
+        openedBySeam = true;
+      }
+      else addResidualConv(b.finalConv, mid.act, mid.stride, s, nextBN);
     }
   }
 }
@@ -869,6 +941,26 @@ void Engine::evalHostBegin(int n, const float* const* rowSpatial, const unsigned
     hipCheck(hipMemcpyAsync(hOwnership_, dOwnership_.get(), (size_t)n * S_ * sizeof(float), hipMemcpyDeviceToHost, stream_), "D2H ownership");
 }
 
+void Engine::launchStagedPacked(int n, const int* symmetry, const float* policyOptimism, bool anyOwner) {
+  if(n < 1 || n > maxBatch_) throw Error(KMX_ERR_INVALID_ARG, "batch size out of range for this handle");
+  hipCheck(hipSetDevice(device_), "hipSetDevice");
+  const size_t rowBytes = (size_t)packedRowBytes();
+  hipCheck(hipMemcpyAsync(dPackedIn_.get(), hPacked_, n * rowBytes, hipMemcpyHostToDevice, stream_), "H2D packed planes");
+  hipCheck(hipMemcpyAsync(dGlobalIn_.get(), hGlobal_, (size_t)n * gin_ * sizeof(float), hipMemcpyHostToDevice, stream_), "H2D global");
+  if(min_ > 0) hipCheck(hipMemcpyAsync(dMetaIn_.get(), hMeta_, (size_t)n * min_ * sizeof(float), hipMemcpyHostToDevice, stream_), "H2D meta");
+  hostAnyOwner_ = anyOwner;
+  stageRowParams(n, symmetry, policyOptimism);
+  runSchedule(n, nullptr, dPackedIn_.as<unsigned char>(), dGlobalIn_.as<float>(), min_ > 0 ? dMetaIn_.as<float>() : nullptr,
+              dPolicy_.as<float>(), dValue_.as<float>(), dScore_.as<float>(), anyOwner ? dOwnership_.as<float>() : nullptr);
+  hipCheck(hipMemcpyAsync(hPolicy_, dPolicy_.get(), (size_t)n * (S_ + 1) * sizeof(float), hipMemcpyDeviceToHost, stream_), "D2H policy");
+  hipCheck(hipMemcpyAsync(hValue_, dValue_.get(), (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_), "D2H value");
+  hipCheck(hipMemcpyAsync(hScore_, dScore_.get(), (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost, stream_), "D2H score");
+  if(anyOwner)
+    hipCheck(hipMemcpyAsync(hOwnership_, dOwnership_.get(), (size_t)n * S_ * sizeof(float), hipMemcpyDeviceToHost, stream_), "D2H ownership");
+  rows_ += (uint64_t)n;
+  batches_ += 1;
+}
+
 void Engine::evalHostFinish(int n, float* const* outPolicy, float* outValue, float* outScore, float* const* outOwnership) {
   sync();
   for(int i = 0; i < n; i++) {
@@ -1052,6 +1144,61 @@ void testGPoolBlock(int dtype, const kmx_gpoolblock_desc* d, int batch, int X, i
   hipCheck(launchGPoolApply(dtype, ga, h.st), "gpool launch");
   h.conv(f2, r.get(), rStride, raw.get(), stride, raw.get(), stride, 0, roundUp(C, 8), nullptr, 0, 0, 0, KMX_ACT_IDENTITY);
   h.toHost(raw, stride, C, out);
+}
+
+// The seam of two 1x1 convolutions (pointwise_kernel.h) on its own: fused = 1 runs the one-launch kernel, fused = 0 the two
+// convolution launches it replaces; both from the same re-tiled weights.
+void testPointwisePair(int dtype, int batch, int X, int Y, int c1, int c2, int c3, const float* in, const float* resid, const float* w1,
+                       const float* scale1, const float* bias1, int act1, const float* w2, const float* scale2, const float* bias2,
+                       int act2, const float* mask, bool fused, float* outTrunkRaw, float* outMidRaw, float* outMidAct) {
+  if(!in || !resid || !w1 || !w2 || !scale1 || !bias1 || !scale2 || !bias2 || !outTrunkRaw || !outMidRaw || !outMidAct)
+    throw Error(KMX_ERR_INVALID_ARG, "test pointwise pair: null argument");
+  if(fused && !pointwisePairSupported(c1, c2, c3)) throw Error(KMX_ERR_UNSUPPORTED, "test pointwise pair: no fused kernel for these channel counts");
+  HookCtx h(dtype, batch, X, Y, mask);
+  auto conv1x1 = [](const char* name, int ic, int oc, const float* w) {  // [oc][ic] -> file order [1][1][ic][oc]
+    ConvDesc c;
+    c.name = name; c.ky = c.kx = 1; c.inC = ic; c.outC = oc;
+    c.w.resize((size_t)ic * oc);
+    for(int o = 0; o < oc; o++)
+      for(int i = 0; i < ic; i++) c.w[(size_t)i * oc + o] = w[(size_t)o * ic + i];
+    return c;
+  };
+  auto bn = [](int c, const float* sc, const float* bi, int act) {
+    BnDesc b;
+    b.name = "testbn"; b.c = c; b.act = act;
+    b.scale.assign(sc, sc + c);
+    b.bias.assign(bi, bi + c);
+    return b;
+  };
+  const ConvDesc cd1 = conv1x1("post", c1, c2, w1), cd2 = conv1x1("pre", c2, c3, w2);
+  const BnDesc bn1 = bn(c2, scale1, bias1, act1), bn2 = bn(c3, scale2, bias2, act2);
+  FusedConv f1 = buildFusedConv(dtype, {{&cd1, &bn1}}, nullptr), f2 = buildFusedConv(dtype, {{&cd2, &bn2}}, nullptr);
+  int inStride, trunkStride;
+  DevBuf x = h.toDevice(in, c1, &inStride);
+  DevBuf trunkRaw = h.toDevice(resid, c2, &trunkStride);
+  const int midStride = roundUp(c3, 32);
+  const size_t cells = (size_t)batch * h.S;
+  DevBuf trunkAct(cells * trunkStride * 2), midRaw(cells * midStride * 2), midAct(cells * midStride * 2);
+  if(fused) {
+    PwPairArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.in = x.get(); pa.inC = inStride; pa.w1 = f1.w.get();
+    pa.resid = trunkRaw.get(); pa.rawOut = trunkRaw.get(); pa.trunkC = trunkStride; pa.actOut = nullptr;
+    pa.scale1 = f1.scale.as<float>(); pa.bias1 = f1.bias.as<float>(); pa.actKind1 = act1;
+    pa.w2 = f2.w.get(); pa.rawOut2 = midRaw.get(); pa.actOut2 = midAct.get(); pa.midC = midStride;
+    pa.scale2 = f2.scale.as<float>(); pa.bias2 = f2.bias.as<float>(); pa.actKind2 = act2;
+    pa.mask = h.mask.as<float>(); pa.cells = (long long)cells; pa.zeroPage = h.zero.get();
+    hipCheck(launchPointwisePair(dtype, c1, c2, c3, pa, h.st), "pointwise pair launch");
+  }
+  else {
+    h.conv(f1, x.get(), inStride, trunkRaw.get(), trunkStride, trunkRaw.get(), trunkStride, 0, f1.coutPad, trunkAct.get(), trunkStride, 0,
+           f1.coutPad, act1);
+    h.conv(f2, trunkAct.get(), trunkStride, nullptr, 0, midRaw.get(), midStride, 0, f2.coutPad, midAct.get(), midStride, 0, f2.coutPad, act2);
+  }
+  hipCheck(hipStreamSynchronize(h.st), "sync");
+  h.toHost(trunkRaw, trunkStride, c2, outTrunkRaw);
+  h.toHost(midRaw, midStride, c3, outMidRaw);
+  h.toHost(midAct, midStride, c3, outMidAct);
 }
 
 // ---- unit hooks for the transformer kernels (experimental; tests/test_gpu_transformer.py) ----

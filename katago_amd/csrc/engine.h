@@ -99,6 +99,17 @@ class Engine {
                   const float* policyOptimism, float* dPolicy, float* dValue, float* dScore, float* dOwnership, bool sync);
   int numInputMetaChannels() const { return min_; }
   void sync();
+  // Staged entry (the batcher, batcher.cpp): rows are written by their submitters straight into this engine's pinned staging
+  // - bit-packed planes, globals, metadata - then ONE call enqueues H2D, the pass and D2H without waiting; after sync() the
+  // results sit in pinned memory. The engine must be idle when rows are staged (the batcher's slot state machine sees to it).
+  unsigned char* stagedPackedRow(int i) { return hPacked_ + (size_t)i * packedRowBytes(); }
+  float* stagedGlobalRow(int i) { return hGlobal_ + (size_t)i * gin_; }
+  float* stagedMetaRow(int i) { return hMeta_ + (size_t)i * min_; }
+  void launchStagedPacked(int n, const int* symmetry, const float* policyOptimism, bool anyOwner);
+  const float* stagedPolicy(int i) const { return hPolicy_ + (size_t)i * (S_ + 1); }
+  const float* stagedValue(int i) const { return hValue_ + (size_t)i * 3; }
+  const float* stagedScore(int i) const { return hScore_ + (size_t)i * 6; }
+  const float* stagedOwnership(int i) const { return hOwnership_ + (size_t)i * S_; }
 
   void setProfiling(bool enabled);
   struct ProfileEntry { std::string name; uint64_t launches = 0; double ms = 0, flops = 0, bytes = 0; };
@@ -144,6 +155,12 @@ class Engine {
   void addConv(const FusedConv* fc, const void* in, int inStride, const float* ncBias, int ncBiasStride,
                const void* resid, int residStride, void* rawOut, int rawStride, int rawBegin, int rawEnd, void* actOut,
                int actStride, int actBegin, int actEnd, int actKind);
+  ConvArgs makeConvArgs(const FusedConv* fc, const void* in, int inStride, const float* ncBias, int ncBiasStride, const void* resid,
+                        int residStride, void* rawOut, int rawStride, int rawBegin, int rawEnd, void* actOut, int actStride,
+                        int actBegin, int actEnd, int actKind, double* bytesPerRow);
+  void launchConvOp(const ConvArgs& a, int ks, int n, hipStream_t st);
+  void addSeam(const ConvDesc& post, const void* in, int inStride, const Stream& s, const BnDesc& nextBN, const ConvDesc& pre,
+               const Stream& mid, const BnDesc& innerBN);
   const FusedConv* newConv(const std::vector<ConvSegment>& segs, std::vector<int>* offs = nullptr);
   void addResidualConv(const ConvDesc& conv, const void* in, int inStride, const Stream& s, const BnDesc* nextBN);
   void addRmsNorm(const void* in, int inStride, void* out, int outStride, int C, float eps, const std::vector<float>& w,
@@ -181,6 +198,8 @@ class Engine {
   int stagingSlot_ = 0;
   bool hostAnyOwner_ = false;
   int cfgScale_ = 1;
+  bool fuseSeams_ = true;   // KMX_FUSE_SEAMS=0: always the two convolution launches
+  int fuseMinRows_ = 24;    // KMX_FUSE_MIN_ROWS: smallest batch that takes the fused seam kernel
   int forkOps_ = 0;
   hipEvent_t forkEv_ = nullptr;
 
@@ -202,7 +221,7 @@ class Engine {
     uint64_t lastUse = 0;
   };
   std::map<GraphKey, GraphEntry> graphCache_;
-  bool useGraphs_ = true;
+  bool useGraphs_ = false;  // opt-in (KMX_GRAPHS=1 / kmx_handle_set_graphs): measured on MI355X, replay is not faster than direct launches
   uint64_t graphLaunches_ = 0, graphClock_ = 0;
   void launchOps(int n);   // the ops of one pass, directly on stream_
   void dropGraphs() noexcept;
@@ -236,6 +255,9 @@ void testResBlock(int dtype, const kmx_resblock_desc* d, int batch, int X, int Y
 void testGPoolBlock(int dtype, const kmx_gpoolblock_desc* d, int batch, int X, int Y, const float* in, const float* mask,
                     float* out);
 
+void testPointwisePair(int dtype, int batch, int X, int Y, int c1, int c2, int c3, const float* in, const float* resid, const float* w1,
+                       const float* scale1, const float* bias1, int act1, const float* w2, const float* scale2, const float* bias2,
+                       int act2, const float* mask, bool fused, float* outTrunkRaw, float* outMidRaw, float* outMidAct);
 // Unit hooks for the transformer kernels (experimental): fp32 NHWC in/out like the hooks above.
 void testRmsNorm(int dtype, int batch, int X, int Y, int C, float eps, const float* w, const float* beta, int actKind, bool perBoard,
                  const float* in, const float* mask, float* out);

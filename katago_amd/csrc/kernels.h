@@ -57,6 +57,34 @@ hipError_t launchConv(int dtype, int ks, int cfg, const ConvArgs& a, hipStream_t
 int chooseConvCfg(int ks, int coutPad, int batch);
 bool convCfgInstantiated(int ks, int cfg);  // is there a kernel for this (kernel size, shape)?
 
+// The seam between two nested-bottleneck blocks as ONE launch (pointwise_kernel.h): block i's closing 1x1 convolution
+// (+ residual), block i+1's preBN + activation, block i+1's opening 1x1 convolution and the first inner block's
+// preBN + activation. The activated trunk image only exists in LDS. Cells are the flat N*S index.
+struct PwPairArgs {
+  const void* in;        // T [cells][inC]: activated mid image of block i
+  int inC;
+  const void* w1;        // T [C1/32][C2][32], rows slot-swizzled (the FusedConv layout)
+  const void* resid;     // T [cells][trunkC]: trunk raw (may alias rawOut)
+  void* rawOut;          // T [cells][trunkC]
+  int trunkC;            // channel stride of the trunk tensors (>= C2)
+  void* actOut;          // T [cells][trunkC] or null: the activated trunk image, only written when something else reads it
+  const float* scale1;   // [C2] merged BN of block i+1's preBN
+  const float* bias1;
+  int actKind1;
+  const void* w2;        // T [C2/32][C3][32]
+  void* rawOut2;         // T [cells][midC]
+  void* actOut2;         // T [cells][midC]
+  int midC;              // channel stride of the mid tensors (>= C3)
+  const float* scale2;   // [C3]
+  const float* bias2;
+  int actKind2;
+  const float* mask;     // [cells]
+  long long cells;       // N * S
+  const void* zeroPage;  // >= 64 readable zero bytes
+};
+hipError_t launchPointwisePair(int dtype, int c1, int c2, int c3, const PwPairArgs& a, hipStream_t stream);
+bool pointwisePairSupported(int c1, int c2, int c3);  // is there a kernel for these channel counts?
+
 // Input staging: fp32 NHWC rows (not symmetrised) -> T[N][S][32] symmetrised + mask + maskSum +
 // ncBias[n][C] = W_global^T * global[n]   (copyInputsWithSymmetry nninputs.cpp:529-597, Model::apply
 // eigenbackend.cpp:2181-2182, initialMatMul eigenbackend.cpp:1928-1930)

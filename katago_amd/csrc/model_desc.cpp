@@ -596,13 +596,6 @@ std::unique_ptr<ModelDesc> ModelDesc::loadFromFile(const std::string& path, cons
   conv(m.p1Conv); conv(m.g1Conv); conv(m.p2Conv); conv(m.v1Conv); conv(m.vOwnershipConv);
   m.macPerPosition = mac;
   m.numParameters = params;
-  if(m.hasTransformerBlocks || m.trunkNormKind != 0) {
-    // The device kernels for these layers (transformer_kernels.hip) have been written against the oracle but have not
-    // run on hardware yet: until they have, such a net is refused unless the caller opts in explicitly.
-    const char* e = getenv("KMX_EXPERIMENTAL_TRANSFORMER");
-    if(e == nullptr || std::string(e) != "1")
-      throw ModelError(KMX_ERR_UNSUPPORTED, m.name + ": transformer blocks / RMSNorm trunk tips are not supported by the katamx backend yet (convolutional nets only)");
-  }
   return mp;
 }
 

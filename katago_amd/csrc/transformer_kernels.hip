@@ -6,10 +6,10 @@
 //                      attention with grouped-query heads (eigenbackend.cpp:1466-1560)
 //   swiGluKernel       SiLU(linear1) * gate (eigenbackend.cpp:1674-1689)
 //
-// STATUS: written against the CPU restatement of these layers (the test oracle, pinned on the reference PyTorch model),
-// compiled for gfx950, NOT yet run on hardware. model_desc.cpp refuses nets that need these kernels unless
-// KMX_EXPERIMENTAL_TRANSFORMER=1. First version: correctness-oriented VALU code, one thread per query, K/V of one
-// (board, head) staged in LDS; attention is < 2 % of the FLOPs of the nets in question, an MFMA version comes after parity.
+// Verified on the MI355X (round 2): unit kernels against numpy restatements, whole nets against the reference PyTorch
+// goldens and the oracle, and the reference's two trained transformer nets through its `testgpuerror` acceptance test
+// (tests/test_gpu_transformer.py). Two attention kernels: attentionMfmaKernel (default, matrix cores) and attentionKernel
+// (KMX_ATTENTION_VALU=1; one thread per query, the cross-check of the other).
 #include "device_common.h"
 
 #include <atomic>

@@ -292,6 +292,23 @@ def _prec(useFP16):
     return capi.PREC_AUTO if useFP16 else capi.PREC_FP32
 
 
+def testEvaluatePointwisePair(batchSize, nnXLen, nnYLen, useFP16, x, resid, w1, s1, b1, act1, w2, s2, b2, act2, mask, fused):
+    """kmx_test_pointwise_pair: the seam of two 1x1 convolutions between nested-bottleneck blocks, as the one-launch kernel
+    (fused=True) or as the two convolution launches it replaces. Arrays: x [cells][c1], resid [cells][c2], w [out][in],
+    mask [cells] or None. Returns (trunk_raw [cells][c2], mid_raw [cells][c3], mid_act [cells][c3])."""
+    lib = capi.load_library()
+    cells = batchSize * nnXLen * nnYLen
+    c = [np.ascontiguousarray(v, dtype=np.float32) for v in (x, resid, w1, s1, b1, w2, s2, b2)]
+    c1, c2, c3 = c[0].shape[1], c[1].shape[1], c[5].shape[0]
+    assert c[0].shape[0] == cells and c[2].shape == (c2, c1) and c[5].shape == (c3, c2)
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.float32)
+    out = [np.empty((cells, c2), np.float32), np.empty((cells, c3), np.float32), np.empty((cells, c3), np.float32)]
+    capi.check(lib.kmx_test_pointwise_pair(batchSize, nnXLen, nnYLen, _prec(useFP16), c1, c2, c3, _fp(c[0]), _fp(c[1]), _fp(c[2]), _fp(c[3]),
+                                           _fp(c[4]), act1, _fp(c[5]), _fp(c[6]), _fp(c[7]), act2, None if m is None else _fp(m),
+                                           1 if fused else 0, _fp(out[0]), _fp(out[1]), _fp(out[2])), lib)
+    return out
+
+
 def testEvaluateConv(w_oihw, batchSize, nnXLen, nnYLen, useFP16, inputNHWC):
     lib = capi.load_library()
     d, keep = _conv_desc(w_oihw)

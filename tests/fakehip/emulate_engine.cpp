@@ -17,6 +17,9 @@ namespace kmx {
 #ifndef KMX_EMU_REAL_CONV
 int chooseConvCfg(int, int, int) { return 11; }
 bool convCfgInstantiated(int, int) { return true; }
+// no fused seam kernel in this build: the engine then schedules the two convolution launches
+bool pointwisePairSupported(int, int, int) { return false; }
+hipError_t launchPointwisePair(int, int, int, int, const PwPairArgs&, hipStream_t) { return 801; }
 #endif
 double benchConv(int, int, int, int, int, int, int, int, int, int) { return 0.0; }
 double benchMfma(int, int, int, int, int, double*, double*) { return 0.0; }

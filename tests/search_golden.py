@@ -1,0 +1,47 @@
+"""Parser and comparison for the output of the reference's `runsearchtestsv8` (cpp/tests/testsearchv8.cpp; setup
+cpp/tests/testsearchcommon.cpp:193-248): a sequence of search reports, each with the root line and one line per child
+(`LOC : T ..c W ..c S ..c (...) LCB ..c P ..% WF .. PSV .. N  <visits> -- <pv>`). A search amplifies last-digit
+differences of the net, so visit counts are compared statistically, against the spread the reference itself shows
+between its own fp32 and fp16 goldens (cpp/tests/results/runSearchTestsV8Bin.txt vs runSearchTestsV8FP16.txt)."""
+import re
+
+_ROOT = re.compile(r"^: T\s+(-?[\d.]+)c W\s+(-?[\d.]+)c S\s+(-?[\d.]+)c \(.*?\) N\s+(\d+)\s+--\s*(.*)$")
+_CHILD = re.compile(r"^([A-T]\d+|pass)\s*: T\s+(-?[\d.]+)c W\s+(-?[\d.]+)c .*? P\s+([\d.]+)% .*? N\s+(\d+)\s+--")
+
+
+def parse(text):
+    """-> list of searches: dict(root_T, root_N, pv, children=[(loc, T, prior%, N), ...]) in file order."""
+    out, cur = [], None
+    for line in text.replace("\r", "\n").splitlines():
+        m = _ROOT.match(line)
+        if m:
+            cur = dict(root_T=float(m.group(1)), root_N=int(m.group(4)), pv=m.group(5).split(), children=[])
+            out.append(cur)
+            continue
+        m = _CHILD.match(line)
+        if m and cur is not None:
+            cur["children"].append((m.group(1), float(m.group(2)), float(m.group(4)), int(m.group(5))))
+    return [s for s in out if s["children"]]
+
+
+def compare(a, b):
+    """Statistics of search list `a` against `b` (same positions, same seeds): fraction with the same best move, the
+    largest / mean absolute difference of the best move's visit share, the largest root-utility difference (in c, i.e.
+    hundredths), the mean total-variation distance of the child visit distributions."""
+    n = min(len(a), len(b))
+    same, share, util, tv = 0, [], [], []
+    for x, y in zip(a[:n], b[:n]):
+        if x["root_N"] != y["root_N"] or x["root_N"] <= 1:
+            continue
+        bx, by = x["children"][0], y["children"][0]
+        same += bx[0] == by[0]
+        vy = {c[0]: c[3] for c in y["children"]}
+        vx = {c[0]: c[3] for c in x["children"]}
+        tot = max(sum(vx.values()), 1), max(sum(vy.values()), 1)
+        share.append(abs(vx.get(by[0], 0) / tot[0] - by[3] / tot[1]))
+        util.append(abs(x["root_T"] - y["root_T"]))
+        keys = set(vx) | set(vy)
+        tv.append(0.5 * sum(abs(vx.get(k, 0) / tot[0] - vy.get(k, 0) / tot[1]) for k in keys))
+    m = len(share)
+    return dict(searches=m, same_best=same / max(m, 1), best_share_max=max(share), best_share_mean=sum(share) / m,
+                root_util_max=max(util), root_util_mean=sum(util) / m, tv_mean=sum(tv) / m, tv_max=max(tv))

@@ -20,7 +20,7 @@ from conftest import REPO
 FAKE = os.path.join(REPO, "tests", "fakehip")
 CSRC = os.path.join(REPO, "katago_amd", "csrc")
 SOURCES = [os.path.join(FAKE, "emulate_engine.cpp")] + [os.path.join(CSRC, f) for f in
-                                                          ("misc_kernels.hip", "transformer_kernels.hip", "engine.cpp", "model_desc.cpp", "kmx_api.cpp")]
+                                                          ("misc_kernels.hip", "transformer_kernels.hip", "engine.cpp", "model_desc.cpp", "kmx_api.cpp", "batcher.cpp")]
 
 
 @pytest.fixture(scope="module")
@@ -62,6 +62,16 @@ CONV_REWRITES = [
 ]
 
 
+# pointwise_kernel.h (the fused seam of two 1x1 convolutions) gets the same treatment
+PW_REWRITES = [
+    (r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\(N\) : "memory"\);', ";", 1),
+    (r'asm volatile\("s_waitcnt lgkmcnt\(0\)" ::: "memory"\);', ";", 1),
+    (r'extern __shared__ __attribute__\(\(aligned\(256\)\)\) char smemPw\[\];', "char* const smemPw = (char*)emu::dynLds();", 1),
+    (r'__builtin_amdgcn_global_load_lds\(', "emu::globalLoadLds(", 1),
+    (r'__attribute__\(\(amdgpu_waves_per_eu\(2, 2\)\)\)', "", 1),
+]
+
+
 @pytest.fixture(scope="module")
 def emu_full_lib(tmp_path_factory):
     import re
@@ -74,10 +84,16 @@ def emu_full_lib(tmp_path_factory):
         assert k == count, "conv_kernel.h changed: %r matched %d times, expected %d" % (pat, k, count)
     open(os.path.join(d, "conv_kernel.h"), "w").write(src)
     shutil.copy(os.path.join(CSRC, "conv_mfma.hip"), os.path.join(d, "conv_mfma.hip"))
+    src = open(os.path.join(CSRC, "pointwise_kernel.h")).read()
+    for pat, rep, count in PW_REWRITES:
+        src, k = re.subn(pat, rep, src)
+        assert k == count, "pointwise_kernel.h changed: %r matched %d times, expected %d" % (pat, k, count)
+    open(os.path.join(d, "pointwise_kernel.h"), "w").write(src)
+    shutil.copy(os.path.join(CSRC, "pointwise.hip"), os.path.join(d, "pointwise.hip"))
     cxx = ["/opt/rocm/lib/llvm/bin/clang++", "-x", "c++", "-std=c++20", "-O2", "-fPIC", "-pthread", "-I" + os.path.join(FAKE, "emul"), "-I" + FAKE,
            "-I" + CSRC, "-DKMX_EMU_REAL_CONV"]
     procs, objs = [], []
-    for src_file in [os.path.join(d, "conv_mfma.hip")] + SOURCES:
+    for src_file in [os.path.join(d, "conv_mfma.hip"), os.path.join(d, "pointwise.hip")] + SOURCES:
         obj = os.path.join(d, os.path.splitext(os.path.basename(src_file))[0] + ".o")
         objs.append(obj)
         procs.append((src_file, subprocess.Popen(cxx + ["-c", src_file, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -234,8 +250,38 @@ def test_reference_transformer_nets_emulated(emu_lib):
     check(res, 0.05, 0.15)
 
 
-def test_emulated_library_refuses_transformer_nets_without_opt_in(emu_lib):
-    env = dict(os.environ)
-    env.pop("KMX_EXPERIMENTAL_TRANSFORMER", None)
-    p = subprocess.run([sys.executable, os.path.join(FAKE, "run_emulated_nets.py"), emu_lib, "bf16:torch_tfa"], capture_output=True, text=True, env=env)
-    assert p.returncode != 0 and "not supported" in (p.stdout + p.stderr)
+def test_pointwise_seam_kernel_emulated(emu_full_lib):
+    """pointwise_kernel.h itself on the CPU (MFMA and LDS-DMA emulated): one full 128-cell tile plus a tail tile (2 boards of
+    9x9 = 162 cells), masked cells, against the numpy restatement and bit for bit against the two emulated convolution launches."""
+    code = r"""
+import sys, json
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+from katago_amd import capi
+capi._lib = capi.load_library(path=sys.argv[1])
+from katago_amd import nninterface as nn
+import pointwise_ref as ref
+rng = np.random.default_rng(3)
+batch, L = 2, 9
+mask = np.ones((batch, L, L), np.float32); mask[1, :, 6:] = 0
+x, resid, w1, s1, b1, w2, s2, b2, m = ref.make_case(rng, batch * L * L, 192, 384, 192, mask.reshape(-1))
+out = {}
+for dtype in ("bf16", "fp16"):
+    fused = nn.testEvaluatePointwisePair(batch, L, L, dtype, x, resid, w1, s1, b1, 2, w2, s2, b2, 1, m, True)
+    plain = nn.testEvaluatePointwisePair(batch, L, L, dtype, x, resid, w1, s1, b1, 2, w2, s2, b2, 1, m, False)
+    want = ref.seam(x, resid, w1, s1, b1, 2, w2, s2, b2, 1, m, dtype)
+    out[dtype] = {"same": [bool(np.array_equal(f, p)) for f, p in zip(fused, plain)],
+                  "err": [float(np.abs(f - w).max()) for f, w in zip(fused, want)],
+                  "scale": [float(np.abs(w).max()) for w in want],
+                  "off_board_zero": bool((fused[2][m != 1.0] == 0).all())}
+print("RESULT " + json.dumps(out))
+""" % (REPO, os.path.join(REPO, "tests"))
+    p = subprocess.run([sys.executable, "-c", code, emu_full_lib], capture_output=True, text=True, timeout=1800)
+    assert p.returncode == 0 and "RESULT " in p.stdout, (p.stdout + p.stderr)[-3000:]
+    res = json.loads(p.stdout.split("RESULT ")[1])
+    print(res)
+    for dtype, r in res.items():
+        assert all(r["same"]) and r["off_board_zero"], (dtype, r)
+        ulp = 2.0 ** -7 if dtype == "bf16" else 2.0 ** -10
+        for e, s, k in zip(r["err"], r["scale"], (1, 4, 4)):
+            assert e <= 2 * ulp * max(s, 1.0) * k, (dtype, r)

@@ -1,9 +1,6 @@
-"""-m gpu, EXPERIMENTAL: model-v17 transformer trunks on the HIP backend (transformer_kernels.hip + the 1x1 convolution
-kernel) against the reference PyTorch goldens and the oracle. The device kernels of these layers have not run on
-hardware yet; the loader refuses such nets unless KMX_EXPERIMENTAL_TRANSFORMER=1, and these tests only run with it:
-
-    KMX_EXPERIMENTAL_TRANSFORMER=1 python -m pytest tests/test_gpu_transformer.py -m gpu -x -q
-"""
+"""-m gpu: model-v17 transformer trunks on the HIP backend (transformer_kernels.hip + the 1x1 convolution kernel)
+against numpy restatements of the unit kernels, the reference PyTorch goldens, the oracle, and the reference's own
+`testgpuerror` acceptance test on its two trained transformer nets (row f4)."""
 import os
 
 import numpy as np
@@ -14,8 +11,7 @@ from katago_amd import nninterface as nn
 from oracle import oracle
 from test_gpu_model import outputs_close
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("KMX_EXPERIMENTAL_TRANSFORMER") != "1", reason="experimental: set KMX_EXPERIMENTAL_TRANSFORMER=1")]
+pytestmark = pytest.mark.gpu
 GOLD = os.path.join(REPO, "tests", "golden")
 REF_MODELS = os.path.join(REPO, "oracle", "_ref", "models")
 
@@ -259,14 +255,26 @@ def test_oracle_transformer_agrees_with_reference_opencl_backend(tmp_path, net):
 
 @pytest.mark.parametrize("net", TF_NETS)
 def test_reference_gpuerror_acceptance_transformer_on_hip(tmp_path, net):
-    """`testgpuerror` on the katamx backend for the transformer nets, bf16, against the reduced-precision limits."""
+    """`testgpuerror` on the katamx backend for the reference's two trained transformer nets at the backend's own choice
+    of precision (KMX_PREC_AUTO = fp16 for nets with transformer blocks or RMSNorm tips), against the reduced-precision
+    limits of cpp/tests/testnnevalcanary.cpp:806-807. Measured: 0.24x / 0.06x of the limit. bf16, which a user may still
+    force, sits at 4.1x / 1.1x on these nets (8-bit mantissa through per-cell normalisations) - recorded, not asserted."""
     if not os.path.exists(os.path.join(REF_MODELS, net)):
         pytest.skip("reference test nets not packaged")
     args = _reference_file(tmp_path, net)
-    r = subprocess.run([ref_binary("katago_hip")] + args + ["-override-config", "katamxPrecision=bf16"], capture_output=True, text=True,
-                       timeout=900, cwd=str(tmp_path))
-    out = r.stdout + r.stderr
-    assert "Loaded reference values for" in out, out[-3000:]
-    margins = {k: float(v) for k, v in re.findall(_MARGIN, out)}
-    print(net, margins)
-    assert len(margins) == 4 and margins["current cfg"] < 1.0 and margins["batched current cfg"] < 1.0, (margins, out[-1500:])
+    results = {}
+    for prec in ("auto", "bf16"):
+        r = subprocess.run([ref_binary("katago_hip")] + args + ["-override-config", "katamxPrecision=" + prec], capture_output=True,
+                           text=True, timeout=900, cwd=str(tmp_path))
+        out = r.stdout + r.stderr
+        assert "Loaded reference values for" in out, out[-3000:]
+        results[prec] = {k: float(v) for k, v in re.findall(_MARGIN, out)}
+        print(net, prec, results[prec])
+        keep = os.path.join(REPO, "gpurun_out")
+        if os.path.isdir(keep):
+            os.makedirs(os.path.join(keep, "transformer"), exist_ok=True)
+            with open(os.path.join(keep, "transformer", "gpuerror_%s_%s.log" % (net.split("-")[0].split(".")[0], prec)), "w") as f:
+                f.write("\n".join(l for l in out.splitlines() if "error vs reference" in l) + "\n")
+    m = results["auto"]
+    assert len(m) == 4 and m["current cfg"] < 0.5 and m["batched current cfg"] < 0.5, results
+    assert results["bf16"]["current cfg"] > m["current cfg"]  # AUTO picked the more accurate format
