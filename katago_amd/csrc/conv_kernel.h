@@ -370,21 +370,28 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
       int cell = wm * (32 * MT) + pt * 32 + myPos;
       cell = cellOf(cell < S ? cell : S - 1);
       const T* const rrow = (const T*)a.resid + ((size_t)n * S + cell) * a.residC - a.rawBegin;
-      V4 rr[WN][4];
+      // 16-byte loads: lanes c and c + 32 of a tile column fetch the two 8-channel runs of each 16 channels and exchange
+      // halves afterwards (device_common.h unpair) - half the load instructions of 8-byte pieces for the same bytes
+      u32x4 rq[WN][2];
 #pragma unroll
       for(int ct = 0; ct < WN; ct++)
 #pragma unroll
-        for(int g = 0; g < 4; g++) {
-          const int c = cout0 + wn * (32 * WN) + ct * 32 + 8 * g + 4 * khalf;
+        for(int j = 0; j < 2; j++) {
+          const int c = cout0 + wn * (32 * WN) + ct * 32 + 16 * j + 8 * khalf;
           const T* src = (c >= a.rawBegin && c < a.rawEnd) ? rrow + c : (const T*)zero;
-          rr[ct][g] = *(const V4*)src;
+          rq[ct][j] = *(const u32x4*)src;
         }
 #pragma unroll
-      for(int ct = 0; ct < WN; ct++)
+      for(int ct = 0; ct < WN; ct++) {
+        u32x2 rp[4];
+        unpair(rq[ct], rp);
 #pragma unroll
-        for(int g = 0; g < 4; g++)
+        for(int g = 0; g < 4; g++) {
+          const V4 rr = __builtin_bit_cast(V4, rp[g]);
 #pragma unroll
-          for(int i = 0; i < 4; i++) acc[ct][pt][4 * g + i] = TR::toFloat(rr[ct][g][i]);
+          for(int i = 0; i < 4; i++) acc[ct][pt][4 * g + i] = TR::toFloat(rr[i]);
+        }
+      }
     }
   }
   else {
@@ -519,12 +526,25 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   asm volatile("" ::: "memory");
   if(!waveActive) return;
   float* const stage = (float*)smem + wave * STAGE_FLOATS;
+  // Per-lane parameters of its 8 channels: three pairs of 16-byte loads (the arrays are padded to coutPad, so no lane needs a
+  // guard; lanes outside [actBegin, actEnd) never use theirs). The per-board bias only exists for the stem convolution.
+  const bool hasNb = a.ncBias != nullptr;  // uniform
   float sc[8], bi[8], nb[8];
+  {
+    const f32x4 s0 = *(const f32x4*)(a.scale + c8), s1 = *(const f32x4*)(a.scale + c8 + 4);
+    const f32x4 b0 = *(const f32x4*)(a.bias + c8), b1 = *(const f32x4*)(a.bias + c8 + 4);
+    f32x4 n0 = {0.0f, 0.0f, 0.0f, 0.0f}, n1 = n0;
+    if(hasNb) {
+      const float* nbRow = a.ncBias + (size_t)n * a.ncBiasStride + c8;
+      n0 = *(const f32x4*)nbRow;
+      n1 = *(const f32x4*)(nbRow + 4);
+    }
 #pragma unroll
-  for(int i = 0; i < 8; i++) {
-    sc[i] = inAct ? a.scale[c8 + i] : 0.0f;
-    bi[i] = inAct ? a.bias[c8 + i] : 0.0f;
-    nb[i] = a.ncBias != nullptr ? a.ncBias[(size_t)n * a.ncBiasStride + c8 + i] : 0.0f;
+    for(int i = 0; i < 4; i++) {
+      sc[i] = s0[i]; sc[4 + i] = s1[i];
+      bi[i] = b0[i]; bi[4 + i] = b1[i];
+      nb[i] = n0[i]; nb[4 + i] = n1[i];
+    }
   }
   {
     // Consume the parameter loads HERE, while no store is in flight: otherwise the compiler re-waits for them with
@@ -534,6 +554,24 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
     for(int i = 0; i < 8; i++) touch += sc[i] + bi[i] + nb[i];
     asm volatile("" ::"v"(touch));
   }
+  // Index arithmetic of the row walk without compare chains or an integer division (both cost tens of vector instructions
+  // per row): posOf as a nibble table over the lane quad, cellOf's division by X-16 as a multiply by a 16-bit reciprocal
+  // (exact for the < 384 columns of a board).
+  const unsigned restInv = restW > 0 ? (65536u + (unsigned)restW - 1u) / (unsigned)restW : 0u;  // uniform
+  auto posOfFast = [](int l) -> int { return (int)((((0x73261540u >> ((unsigned)(l >> 2) * 4u)) & 7u) << 2) | ((unsigned)l & 3u)); };
+  auto cellOfFast = [&](int m) -> int {
+    if(X < 16) return m;  // uniform
+    const int k = m - mainCols;
+    const int yy = (int)(((unsigned)k * restInv) >> 16);
+    const int rest = yy * X + 16 + (k - yy * restW);
+    const int mainCell = (m >> 4) * X + (m & 15);
+    return m < mainCols ? mainCell : rest;
+  };
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const int actKindRt = (ABL & ABL_EPI_NOACT) ? KMX_ACT_IDENTITY : a.actKind;  // uniform for the launch
+  // this board's rows of the two outputs at this lane's channels; a cell then adds a 32-bit offset
+  T* const rawLane = (T*)a.rawOut + (size_t)n * S * a.rawC + (c8 - a.rawBegin);
+  T* const actLane = (T*)a.actOut + (size_t)n * S * a.actC + (c8 - a.actBegin);
 #pragma unroll
   for(int pt = 0; pt < MT; pt++) {
     const int cellBase = wm * (32 * MT) + pt * 32;
@@ -554,50 +592,58 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
     for(int it = 0; it < NIT; it++) {
       const int cl = it * CPI + pc;
       if(!laneOn || cl >= 32) continue;
-      const int col = cellBase + posOf(cl);  // staged row cl came from lane cl
+      const int col = cellBase + posOfFast(cl);  // staged row cl came from lane cl
       if(col >= S) continue;
-      const int cell = cellOf(col);
-      const size_t gcell = (size_t)n * S + cell;
+      const int cell = cellOfFast(col);
       const f32x4 lo = *(const f32x4*)(stage + cl * ROWF + pk * 8);
       const f32x4 hi = *(const f32x4*)(stage + cl * ROWF + pk * 8 + 4);
+      // off-board cells of the activated image are ZERO whatever the arithmetic gave (the raw residual stream is never
+      // masked off the board, and an overflowed fp16 value there must not reach the halo of the next 3x3 convolution as
+      // inf * 0 = NaN): the result bits are ANDed with an all-ones / all-zeros word - no select, no branch per element
+      const unsigned onBits = maskBoard[cell] == 1.0f ? 0xffffffffu : 0u;
       float v[8];
 #pragma unroll
       for(int i = 0; i < 4; i++) {
-        v[i] = lo[i] + nb[i];
-        v[4 + i] = hi[i] + nb[4 + i];
+        v[i] = lo[i];
+        v[4 + i] = hi[i];
+      }
+      if(hasNb) {
+#pragma unroll
+        for(int i = 0; i < 8; i++) v[i] += nb[i];
       }
       if(inRaw) {
         V8 o;
 #pragma unroll
         for(int i = 0; i < 8; i++) o[i] = TR::fromFloat(v[i]);
         if(ABL & ABL_EPI_NOSTORE) asm volatile("" ::"v"(o));
-        else *(V8*)((T*)a.rawOut + gcell * a.rawC + (c8 - a.rawBegin)) = o;
+        else *(V8*)(rawLane + cell * a.rawC) = o;
       }
       if(inAct) {
-        // a select, not a multiply: the raw residual stream is never masked off the board, and an overflowed fp16 value
-        // there (inf) times a zero mask would put a NaN into the halo of the next 3x3 convolution
-        const bool on = maskBoard[cell] == 1.0f;
-        V8 o;
+        float r[8];
+#pragma unroll
+        for(int i = 0; i < 8; i++) r[i] = v[i] * sc[i] + bi[i];
         // the activation kind is uniform for the launch: branch ONCE per row, not per element
-        const int kind = (ABL & ABL_EPI_NOACT) ? KMX_ACT_IDENTITY : a.actKind;
-        if(kind == KMX_ACT_MISH) {
+        if(actKindRt == KMX_ACT_MISH) {
 #pragma unroll
-          for(int i = 0; i < 8; i++) o[i] = TR::fromFloat(on ? actMish(v[i] * sc[i] + bi[i]) : 0.0f);
+          for(int i = 0; i < 8; i++) r[i] = actMish(r[i]);
         }
-        else if(kind == KMX_ACT_RELU) {
+        else if(actKindRt == KMX_ACT_RELU) {
 #pragma unroll
-          for(int i = 0; i < 8; i++) o[i] = TR::fromFloat(on ? fmaxf(v[i] * sc[i] + bi[i], 0.0f) : 0.0f);
+          for(int i = 0; i < 8; i++) r[i] = fmaxf(r[i], 0.0f);
         }
-        else if(kind == KMX_ACT_SILU) {
+        else if(actKindRt == KMX_ACT_SILU) {
 #pragma unroll
-          for(int i = 0; i < 8; i++) o[i] = TR::fromFloat(on ? actSilu(v[i] * sc[i] + bi[i]) : 0.0f);
+          for(int i = 0; i < 8; i++) r[i] = actSilu(r[i]);
         }
-        else {
+        V8 o;
 #pragma unroll
-          for(int i = 0; i < 8; i++) o[i] = TR::fromFloat(on ? v[i] * sc[i] + bi[i] : 0.0f);
-        }
+        for(int i = 0; i < 8; i++) o[i] = TR::fromFloat(r[i]);
+        u32x4 ob = __builtin_bit_cast(u32x4, o);
+#pragma unroll
+        for(int i = 0; i < 4; i++) ob[i] &= onBits;
+        o = __builtin_bit_cast(V8, ob);
         if(ABL & ABL_EPI_NOSTORE) asm volatile("" ::"v"(o));
-        else *(V8*)((T*)a.actOut + gcell * a.actC + (c8 - a.actBegin)) = o;
+        else *(V8*)(actLane + cell * a.actC) = o;
       }
     }
   }

@@ -40,12 +40,59 @@ struct TraitsBF16 {
   static __device__ __forceinline__ T fromFloat(float x) { return (T)x; }
 };
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte global accesses for values that live in the accumulator layout of a 32x32 MFMA tile.
+// Lane (column c, half h = lane >> 5) of a tile holds rows 8g + 4h + i (g, i = 0..3): for one g that is 4 consecutive 16-bit
+// channels = 8 bytes, and straight loads/stores of it are 8-byte accesses scattered 16 bytes apart - half the bytes per
+// memory instruction of what the vector memory path moves best (MI355X_MICROARCH.md: an epilogue of dwordx2 stores is
+// store-ISSUE-bound, dwordx4 halves it). Lanes c and c + 32 hold the two halves of every 16-byte run, so one
+// v_permlane32_swap per dword regroups them: after pairUp() lane h = 0 holds channels [0,8) and [16,24) of the tile's 32,
+// lane h = 1 holds [8,16) and [24,32), each as one 16-byte piece. unpair() is the same exchange backwards (loads).
+// Every lane of the wave must execute these (lane exchange): call them outside divergent control flow.
+__device__ __forceinline__ void swapUpperLower(unsigned& x, unsigned& y) {  // lanes 32-63 of x <-> lanes 0-31 of y
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+  x = r[0];
+  y = r[1];
+}
+// p[g] = the lane's 4 channels of group g (two dwords). Returns q[j] = 16 bytes: channels 16 j + 8 h + [0,8).
+__device__ __forceinline__ void pairUp(const u32x2 (&p)[4], u32x4 (&q)[2]) {
+#pragma unroll
+  for(int j = 0; j < 2; j++) {
+    unsigned x0 = p[2 * j][0], x1 = p[2 * j][1], y0 = p[2 * j + 1][0], y1 = p[2 * j + 1][1];
+    swapUpperLower(x0, y0);
+    swapUpperLower(x1, y1);
+    q[j][0] = x0; q[j][1] = x1; q[j][2] = y0; q[j][3] = y1;
+  }
+}
+__device__ __forceinline__ void unpair(const u32x4 (&q)[2], u32x2 (&p)[4]) {
+#pragma unroll
+  for(int j = 0; j < 2; j++) {
+    unsigned x0 = q[j][0], x1 = q[j][1], y0 = q[j][2], y1 = q[j][3];
+    swapUpperLower(x0, y0);
+    swapUpperLower(x1, y1);
+    p[2 * j][0] = x0; p[2 * j][1] = x1; p[2 * j + 1][0] = y0; p[2 * j + 1][1] = y1;
+  }
+}
+
 // Activations in fp32. Mish follows the reference's form x*tanh(softplus(x)) with softplus linearised
 // above 20 (eigenbackend.cpp:754): tanh(log1p(e)) = (e^2+2e)/(e^2+2e+2), e = exp(min(x,20)); for x > 20
 // the tanh argument exceeds 20 and tanh saturates to exactly 1 in fp32, as does this rational form.
+// min(x, c) as the single v_min_f32 it is on the hardware: fminf() makes the compiler canonicalise x first (a v_max_f32 x, x
+// per element, for signalling NaNs), and the epilogues evaluate this once per output value
+__device__ __forceinline__ float minPlain(float x, float c) {
+#if defined(__AMDGCN__)
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(c));
+  return r;
+#else
+  return fminf(x, c);
+#endif
+}
 __device__ __forceinline__ float actMish(float x) {
   // e = exp(min(x,20)) through the hardware base-2 exponential; n = e^2 + 2e; mish = x * n / (n + 2)
-  const float e = __builtin_amdgcn_exp2f(fminf(x, 20.0f) * 1.4426950408889634f);
+  const float e = __builtin_amdgcn_exp2f(minPlain(x, 20.0f) * 1.4426950408889634f);
   const float n = e * (e + 2.0f);
   return x * n * __builtin_amdgcn_rcpf(n + 2.0f);  // v_rcp_f32 (1 ulp): outputs are rounded to 16 bits anyway
 }

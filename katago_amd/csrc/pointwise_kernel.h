@@ -16,8 +16,8 @@
 //           K = C1 in chunks of 32; the whole X tile [TM][C1] is fetched into LDS up front (LDS-DMA, swizzled on the source
 //           side exactly like the convolution kernel's board image), W1 slabs [C2][32] ride a ring of 3, fetched two steps
 //           ahead. Accumulators start from the residual stream.
-//   epilogue 1: raw trunk values -> HBM (8-byte pieces straight from the accumulator layout: the four pieces of a 64-byte
-//           line are stored back to back by the same lanes), activated values -> LDS in the image layout of GEMM 2.
+//   epilogue 1: raw trunk values -> HBM (16-byte pieces: the lane pair (c, c + 32) of a tile column regroups its 8-byte
+//           accumulator runs with v_permlane32_swap, device_common.h pairUp), activated values -> LDS in the image layout of GEMM 2.
 //   GEMM 2: D2[C3][TM], waves 4 (cells) x 2 (channels): 32 cells x 32*WN2 channels per wave; K = C2, W2 slabs on the ring.
 //   epilogue 2: mid raw and activated -> HBM.
 // Same MFMA (v_mfma_f32_32x32x16), same operand roles (weights = A, cells = B), same K order (chunk, k-half) and the
@@ -165,18 +165,25 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
   for(int pt = 0; pt < MT1; pt++) {
     const int cl = wm1 * (32 * MT1) + pt * 32 + myPos;
     const bool live = cell0 + cl < a.cells;
-    const T* const rrow = live ? (const T*)a.resid + (size_t)(cell0 + cl) * a.trunkC + wn1 * (32 * WN1) + 4 * khalf : (const T*)zero;
-    V4 rr[WN1][4];
+    // 16-byte pieces: the lane pair (c, c + 32) of a tile column loads channels [16 j + 8 h, +8) and exchanges halves
+    // afterwards (device_common.h unpair)
+    const T* const rrow = live ? (const T*)a.resid + (size_t)(cell0 + cl) * a.trunkC + wn1 * (32 * WN1) + 8 * khalf : (const T*)zero;
+    u32x4 rq[WN1][2];
 #pragma unroll
     for(int ct = 0; ct < WN1; ct++)
 #pragma unroll
-      for(int g = 0; g < 4; g++) rr[ct][g] = *(const V4*)(live ? rrow + ct * 32 + 8 * g : rrow);
+      for(int j = 0; j < 2; j++) rq[ct][j] = *(const u32x4*)(live ? rrow + ct * 32 + 16 * j : rrow);
 #pragma unroll
-    for(int ct = 0; ct < WN1; ct++)
+    for(int ct = 0; ct < WN1; ct++) {
+      u32x2 rp[4];
+      unpair(rq[ct], rp);
 #pragma unroll
-      for(int g = 0; g < 4; g++)
+      for(int g = 0; g < 4; g++) {
+        const V4 rr = __builtin_bit_cast(V4, rp[g]);
 #pragma unroll
-        for(int i = 0; i < 4; i++) acc1[ct][pt][4 * g + i] = TR::toFloat(rr[ct][g][i]);
+        for(int i = 0; i < 4; i++) acc1[ct][pt][4 * g + i] = TR::toFloat(rr[i]);
+      }
+    }
   }
 
   const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -230,13 +237,15 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
   for(int pt = 0; pt < MT1; pt++) {
     const int cl = wm1 * (32 * MT1) + pt * 32 + myPos;
     const bool live = cell0 + cl < a.cells;
-    const bool on = maskS[cl] == 1.0f;
+    // off-board cells of the activated image are zero whatever the arithmetic gave: result bits ANDed with all-ones / zeros
+    const unsigned onBits = maskS[cl] == 1.0f ? 0xffffffffu : 0u;
     T* const rawRow = (T*)a.rawOut + (size_t)(cell0 + cl) * a.trunkC;
     T* const actRow = a.actOut != nullptr ? (T*)a.actOut + (size_t)(cell0 + cl) * a.trunkC : nullptr;
     const unsigned rowXor = ((unsigned)cl >> 2) & 3;
 #pragma unroll
     for(int ct = 0; ct < WN1; ct++) {
       const int chunk = wn1 * WN1 + ct;  // 32-channel chunk of the trunk this tile covers
+      u32x2 rp[4], op[4];
 #pragma unroll
       for(int g = 0; g < 4; g++) {
         const int c = chunk * 32 + 8 * g + 4 * khalf;
@@ -247,14 +256,26 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
         for(int i = 0; i < 4; i++) {
           const float v = acc1[ct][pt][4 * g + i];
           r[i] = TR::fromFloat(v);
-          o[i] = TR::fromFloat(on ? actK<KIND>(v * sc[i] + bi[i]) : 0.0f);
+          o[i] = TR::fromFloat(actK<KIND>(v * sc[i] + bi[i]));
         }
+        rp[g] = __builtin_bit_cast(u32x2, r);
+        op[g] = __builtin_bit_cast(u32x2, o);
+        op[g][0] &= onBits;
+        op[g][1] &= onBits;
+      }
+      // regroup into 16-byte runs (lane pair c, c + 32): this lane now holds channels chunk*32 + 16 j + 8 h + [0,8)
+      u32x4 rq[2], oq[2];
+      pairUp(rp, rq);
+      pairUp(op, oq);
+#pragma unroll
+      for(int j = 0; j < 2; j++) {
+        const int c = chunk * 32 + 16 * j + 8 * khalf;
         if(live) {
-          *(V4*)(rawRow + c) = r;
-          if(actRow != nullptr) *(V4*)(actRow + c) = o;
+          *(u32x4*)(rawRow + c) = rq[j];
+          if(actRow != nullptr) *(u32x4*)(actRow + c) = oq[j];
         }
-        // image layout: chunk `chunk`, row cl, logical slot g at physical g ^ rowXor, this lane's 8 bytes at khalf*8
-        *(V4*)(smem + chunk * G::CHUNK_BYTES + cl * ROWB + ((g ^ rowXor) << 4) + khalf * 8) = o;
+        // image layout: chunk `chunk`, row cl, logical 16-byte slot 2 j + h at physical slot ^ rowXor
+        *(u32x4*)(smem + chunk * G::CHUNK_BYTES + cl * ROWB + (((2 * j + khalf) ^ rowXor) << 4)) = oq[j];
       }
     }
   }
@@ -309,12 +330,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
   for(int pt = 0; pt < MT2; pt++) {
     const int cl = wm2 * (32 * MT2) + pt * 32 + myPos;
-    if(cell0 + cl >= a.cells) continue;
-    const bool on = maskS[cl] == 1.0f;
+    const bool live = cell0 + cl < a.cells;  // the same for both lanes of a pair; no lane leaves before the exchange below
+    const unsigned onBits = maskS[cl] == 1.0f ? 0xffffffffu : 0u;
     T* const rawRow = (T*)a.rawOut2 + (size_t)(cell0 + cl) * a.midC;
     T* const actRow = (T*)a.actOut2 + (size_t)(cell0 + cl) * a.midC;
 #pragma unroll
-    for(int ct = 0; ct < WN2; ct++)
+    for(int ct = 0; ct < WN2; ct++) {
+      u32x2 rp[4], op[4];
 #pragma unroll
       for(int g = 0; g < 4; g++) {
         const int c = wn2 * (32 * WN2) + ct * 32 + 8 * g + 4 * khalf;
@@ -325,11 +347,25 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
         for(int i = 0; i < 4; i++) {
           const float v = acc2[ct][pt][4 * g + i];
           r[i] = TR::fromFloat(v);
-          o[i] = TR::fromFloat(on ? actK<KIND>(v * sc[i] + bi[i]) : 0.0f);
+          o[i] = TR::fromFloat(actK<KIND>(v * sc[i] + bi[i]));
         }
-        *(V4*)(rawRow + c) = r;
-        *(V4*)(actRow + c) = o;
+        rp[g] = __builtin_bit_cast(u32x2, r);
+        op[g] = __builtin_bit_cast(u32x2, o);
+        op[g][0] &= onBits;
+        op[g][1] &= onBits;
       }
+      u32x4 rq[2], oq[2];
+      pairUp(rp, rq);
+      pairUp(op, oq);
+      if(live) {
+#pragma unroll
+        for(int j = 0; j < 2; j++) {
+          const int c = wn2 * (32 * WN2) + ct * 32 + 16 * j + 8 * khalf;
+          *(u32x4*)(rawRow + c) = rq[j];
+          *(u32x4*)(actRow + c) = oq[j];
+        }
+      }
+    }
   }
   });
 }

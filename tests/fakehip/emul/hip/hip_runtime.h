@@ -177,6 +177,36 @@ inline void globalLoadLds(G gsrc, L ldsBase, int size, int, int) {
   memcpy((char*)(uintptr_t)ldsBase + (tIdx.x & 63) * size, (const void*)(uintptr_t)gsrc, (size_t)size);
 }
 }  // namespace emu
+// v_permlane32_swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second; returns {new first, new second}
+namespace emu {
+struct Pair32 {
+  unsigned v[2];
+  unsigned operator[](int i) const { return v[i]; }
+  template <class V> operator V() const { V r; r[0] = v[0]; r[1] = v[1]; return r; }
+};
+inline Pair32 permlane32Swap(unsigned a, unsigned b) {
+  Wave& w = cur->waves[tIdx.x >> 6];
+  const unsigned lane = tIdx.x & 63;
+  unsigned ua, ub;
+  memcpy(&w.opA[lane][0], &a, 4);
+  memcpy(&w.opB[lane][0], &b, 4);
+  w.bar->arrive_and_wait();
+  Pair32 r;
+  if(lane < 32) {
+    r.v[0] = a;
+    memcpy(&ua, &w.opA[lane + 32][0], 4);
+    r.v[1] = ua;  // new second, lower half = old first, upper half
+  }
+  else {
+    memcpy(&ub, &w.opB[lane - 32][0], 4);
+    r.v[0] = ub;  // new first, upper half = old second, lower half
+    r.v[1] = b;
+  }
+  w.bar->arrive_and_wait();
+  return r;
+}
+}  // namespace emu
+#define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) emu::permlane32Swap(a, b)
 inline float __shfl_xor(float v, int laneMask) {
   emu::Wave& w = emu::cur->waves[emu::tIdx.x >> 6];
   const unsigned lane = emu::tIdx.x & 63;
