@@ -60,6 +60,7 @@ constexpr int MAXLEN = 19;
 enum { ABL_NO_EPILOGUE = 1, ABL_NO_COMPUTE = 2, ABL_NO_DMA = 4, ABL_NO_LDS_READ = 8, ABL_NO_VMWAIT = 16, ABL_NO_W_DMA = 32, ABL_NO_A_DMA = 64,
        ABL_EPI_NOACT = 512, ABL_EPI_NOSTORE = 1024,
        ABL_TIMING = 2048 /* s_memtime stamps between the segments of a step, summed per wave into ConvArgs::dbg */,
+       ABL_PRIO = 8192 /* EXPERIMENT: waves 4-7 (the younger wave of each SIMD, which loses the issue arbitration) run the main loop at s_setprio 1 */,
        ABL_BP2 = 4096 /* EXPERIMENT, not an ablation: work-group barrier on even taps only (Geom::BP = 2). Carried in this
                          parameter so that the product kernels (ABL = 0) keep their symbols and their code. */ };
 
@@ -102,13 +103,17 @@ struct Geom {
   static constexpr int NSW = D + BP;
   static_assert(BP == 1 || (BP == 2 && WNW == 2 && KS * KS > 1 && (KS * KS) % 2 == 1 && D >= 3),
                 "the even-tap barrier variant exists for the 8-wave 3x3 / 5x5 shapes with a ring of at least 3 requests");
-  static constexpr int SLACK_BYTES = NWAVES * 1024;
+  static constexpr int SLACK_BYTES = 1024;  // destination of padding / past-the-end DMA instructions (never read; shared by all waves)
   static constexpr int NPM = (384 + NTHREADS - 1) / NTHREADS;          // 4-byte DMA instructions per wave for the mask
   static constexpr int MASK_BYTES = NPM * NTHREADS * 4;
+  // per-channel parameters of the tile for the epilogue: scale | bias | per-board bias, each padded to whole 64-lane instructions
+  static constexpr int NTP = (NTILE + 63) / 64 * 64;
+  static constexpr int NPP = (3 * NTP / 64 + NWAVES - 1) / NWAVES;     // 4-byte DMA instructions per wave for them
+  static constexpr int PARAM_BYTES = NPP * NWAVES * 256;
   static constexpr int PIPE_BYTES = NSA * ACT_BYTES + NSW * W_BYTES + SLACK_BYTES;
-  static constexpr int STAGE_BYTES = NWAVES * 32 * (32 * WN + 4) * 4;  // epilogue transpose, reuses the pipeline LDS
-  static constexpr int MASK_OFFSET = PIPE_BYTES > STAGE_BYTES ? PIPE_BYTES : STAGE_BYTES;
-  static constexpr int LDS_BYTES = MASK_OFFSET + MASK_BYTES;
+  static constexpr int MASK_OFFSET = PIPE_BYTES;
+  static constexpr int PARAM_OFFSET = MASK_OFFSET + MASK_BYTES;
+  static constexpr int LDS_BYTES = PARAM_OFFSET + PARAM_BYTES;
   // DMA instructions younger than the data of the current step when it is waited for
   // top of step s: everything up to slab s+1 has landed (requested in step s+1-D, followed there by its image piece)
   static constexpr int VMCNT = SPREAD ? PPS + (D - 2) * (NPW + PPS) : (D - 2) * (NPW + NPA);
@@ -124,9 +129,15 @@ template <int N>
 __device__ __forceinline__ void waitVm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-__device__ __forceinline__ void dma16(const void* gsrc, char* ldsWaveBase) {
+// LDS destinations are 32-bit LDS addresses (wave-uniform; lane l lands at +16 l), not generic pointers: a generic -> LDS
+// pointer cast carries a null check, and hipcc (ROCm 7.2) mis-selects that compare when the pointer is a select of uniform values
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned ldsWaveBase) {
   __builtin_amdgcn_global_load_lds(
-    (const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)ldsWaveBase, 16, 0, 0);
+    (const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)(size_t)ldsWaveBase, 16, 0, 0);
+}
+__device__ __forceinline__ void dma4(const void* gsrc, unsigned ldsWaveBase) {
+  __builtin_amdgcn_global_load_lds(
+    (const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)(size_t)ldsWaveBase, 4, 0, 0);
 }
 
 template <class TR, int KS, int WN, int WNW, int D, int ABL>
@@ -141,9 +152,10 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
 
   const unsigned long long tKernel0 = (ABL & ABL_TIMING) ? __builtin_readcyclecounter() : 0;  // work-group start
   extern __shared__ __attribute__((aligned(256))) char smem[];
-  char* const bufA = smem;
-  char* const bufW = smem + G::NSA * G::ACT_BYTES;
-  char* const slack = bufW + G::NSW * G::W_BYTES;
+  const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;  // 32-bit LDS byte address of the allocation
+  const unsigned bufA = ldsBase;
+  const unsigned bufW = bufA + G::NSA * G::ACT_BYTES;
+  const unsigned slack = bufW + G::NSW * G::W_BYTES;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -179,7 +191,7 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
 
   const char* const inBoard = (const char*)a.in + (size_t)n * S * inC * sizeof(T);
   const char* const zero = (const char*)a.zeroPage;
-  char* const mySlack = slack + wave * 1024;
+  const unsigned mySlack = slack;
 
   // ---- per-lane DMA source POINTERS of the board image (halo and out-of-image lanes point into the zero page) ----
   // LDS piece p = row p/4, PHYSICAL slot p%4; it holds logical slot (p%4) ^ ((row>>2)&3) of that row. The pointers
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
     if(ABL & (ABL_NO_DMA | ABL_NO_W_DMA)) return;
     const bool live = step < nSteps;
     const char* slab = wBase + (size_t)(live ? step : 0) * wSlabStride;
-    char* dst = bufW + (step % G::NSW) * G::W_BYTES;
+    const unsigned dst = bufW + (step % G::NSW) * G::W_BYTES;
 #pragma unroll
     for(int j = 0; j < NPW; j++) {
       const int pbase = (j * G::NLW + (lw % G::NLW)) * 64;
@@ -243,7 +255,6 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   };
 
   // ---- per-lane LDS read addressing (32-bit LDS byte addresses; kept to 3-4 vector ALU operations per fragment) ----
-  const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const unsigned khalf = lane >> 5;  // which 8 of the 16 k-values of an MFMA this lane feeds
   // weights: row r = wn*32*WN + ct*32 + (lane&31); (r>>2)&3 does not depend on ct or wn (both multiples of 32 rows)
   const unsigned wXor = (lane >> 2) & 3;
@@ -321,8 +332,20 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   for(int j = 0; j < G::NPM; j++) {
     const int cellIdx = (j * NWAVES + wave) * 64 + lane;
     const float* msrc = cellIdx < S ? a.mask + (size_t)n * S + cellIdx : (const float*)zero;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)msrc,
-                                     (__attribute__((address_space(3))) void*)(smem + G::MASK_OFFSET + (j * NWAVES + wave) * 256), 4, 0, 0);
+    dma4(msrc, ldsBase + G::MASK_OFFSET + (j * NWAVES + wave) * 256);
+  }
+  // ... and the per-channel parameters of this tile for the epilogue (merged BN scale, bias, per-board bias)
+#pragma unroll
+  for(int j = 0; j < G::NPP; j++) {
+    const int idx = (j * NWAVES + wave) * 64 + lane;
+    const int arr = idx / G::NTP, c = idx % G::NTP;
+    const float* psrc = (const float*)zero;
+    if(c < G::NTILE) {
+      if(arr == 0) psrc = a.scale + cout0 + c;
+      else if(arr == 1) psrc = a.bias + cout0 + c;
+      else if(arr == 2 && a.ncBias != nullptr) psrc = a.ncBias + (size_t)n * a.ncBiasStride + cout0 + c;
+    }
+    dma4(psrc, ldsBase + G::PARAM_OFFSET + (j * NWAVES + wave) * 256);
   }
   // ---- prologue, part 2: fill the pipeline with the same per-step instruction pattern the loop uses ----
   if(ROLES) {
@@ -469,6 +492,7 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
     seg[which] += now - tPrev;
     tPrev = now;
   };
+  if((ABL & ABL_PRIO) && wave >= 4) __builtin_amdgcn_s_setprio(1);
   if(ABL & ABL_TIMING) tPrev = __builtin_readcyclecounter();
   const unsigned long long tLoop0 = tPrev;
   int step = 0;
@@ -507,149 +531,110 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
       stamp(3);
     }
   }
+  if(ABL & ABL_PRIO) __builtin_amdgcn_s_setprio(0);
   if(!(ABL & ABL_NO_DMA)) waitVm<0>();  // retire the trailing dummies before the LDS is reused / the wave exits
   const unsigned long long tLoop1 = (ABL & ABL_TIMING) ? __builtin_readcyclecounter() : 0;
 
   // ---- epilogue ----
-  const float* const maskBoard = (const float*)(smem + G::MASK_OFFSET);
-  constexpr int ROWF = 32 * WN + 4;         // floats per staged row (+16 B: rows 16 B apart mod 128 -> conflict-free b128 writes)
-  constexpr int STAGE_FLOATS = 32 * ROWF;   // one 32-cell x (32*WN)-channel tile per wave
-  constexpr int PPC = 4 * WN;               // 8-channel pieces per cell
-  constexpr int CPI = 64 / PPC;             // cells covered by one wave-wide access
-  constexpr int NIT = (32 + CPI - 1) / CPI;
-  const int pk = lane % PPC, pc = lane / PPC;
-  const bool laneOn = pc < CPI;
-  const int c8 = cout0 + wn * (32 * WN) + pk * 8;  // first of this lane's 8 output channels (fixed for all cells)
-  const bool inRaw = c8 >= a.rawBegin && c8 < a.rawEnd;
-  const bool inAct = c8 >= a.actBegin && c8 < a.actEnd;
-  __builtin_amdgcn_s_barrier();             // every wave is done reading the operand images
-  asm volatile("" ::: "memory");
+  // Straight from the accumulator layout, no LDS round trip and no work-group barrier (nothing below writes LDS, so a wave
+  // that leaves the loop early starts here while its SIMD partner still multiplies): lane (column, h) of a tile holds 4
+  // consecutive channels per group g of ONE cell, so the cell index, its mask and its output rows are computed once per
+  // tile; the per-channel parameters come from LDS (two broadcast reads per group); lane pairs (c, c + 32) regroup their
+  // 8-byte runs into 16-byte pieces (device_common.h pairUp) and store them. The vector ALU is what bounds this phase
+  // (~4 cycles per wave instruction, 144 outputs per lane): the row-walk it replaces spent a third of its instructions on
+  // index arithmetic and staging.
+  // (explicit LDS addresses, as for the fragment reads)
+  auto ldsF4 = [&](unsigned addr) { return *(const __attribute__((address_space(3))) f32x4*)addr; };
+  auto ldsF1 = [&](unsigned addr) { return *(const __attribute__((address_space(3))) float*)addr; };
+  const unsigned maskAddr = ldsBase + G::MASK_OFFSET;
+  const unsigned scAddr = ldsBase + G::PARAM_OFFSET, biAddr = scAddr + G::NTP * 4, nbAddr = biAddr + G::NTP * 4;
   if(!waveActive) return;
-  float* const stage = (float*)smem + wave * STAGE_FLOATS;
-  // Per-lane parameters of its 8 channels: three pairs of 16-byte loads (the arrays are padded to coutPad, so no lane needs a
-  // guard; lanes outside [actBegin, actEnd) never use theirs). The per-board bias only exists for the stem convolution.
-  const bool hasNb = a.ncBias != nullptr;  // uniform
-  float sc[8], bi[8], nb[8];
-  {
-    const f32x4 s0 = *(const f32x4*)(a.scale + c8), s1 = *(const f32x4*)(a.scale + c8 + 4);
-    const f32x4 b0 = *(const f32x4*)(a.bias + c8), b1 = *(const f32x4*)(a.bias + c8 + 4);
-    f32x4 n0 = {0.0f, 0.0f, 0.0f, 0.0f}, n1 = n0;
-    if(hasNb) {
-      const float* nbRow = a.ncBias + (size_t)n * a.ncBiasStride + c8;
-      n0 = *(const f32x4*)nbRow;
-      n1 = *(const f32x4*)(nbRow + 4);
-    }
-#pragma unroll
-    for(int i = 0; i < 4; i++) {
-      sc[i] = s0[i]; sc[4 + i] = s1[i];
-      bi[i] = b0[i]; bi[4 + i] = b1[i];
-      nb[i] = n0[i]; nb[4 + i] = n1[i];
-    }
-  }
-  {
-    // Consume the parameter loads HERE, while no store is in flight: otherwise the compiler re-waits for them with
-    // vmcnt(0) inside every row iteration below, and each of those waits then also drains the previous row's stores.
-    float touch = 0.0f;
-#pragma unroll
-    for(int i = 0; i < 8; i++) touch += sc[i] + bi[i] + nb[i];
-    asm volatile("" ::"v"(touch));
-  }
-  // Index arithmetic of the row walk without compare chains or an integer division (both cost tens of vector instructions
-  // per row): posOf as a nibble table over the lane quad, cellOf's division by X-16 as a multiply by a 16-bit reciprocal
-  // (exact for the < 384 columns of a board).
-  const unsigned restInv = restW > 0 ? (65536u + (unsigned)restW - 1u) / (unsigned)restW : 0u;  // uniform
-  auto posOfFast = [](int l) -> int { return (int)((((0x73261540u >> ((unsigned)(l >> 2) * 4u)) & 7u) << 2) | ((unsigned)l & 3u)); };
-  auto cellOfFast = [&](int m) -> int {
-    if(X < 16) return m;  // uniform
-    const int k = m - mainCols;
-    const int yy = (int)(((unsigned)k * restInv) >> 16);
-    const int rest = yy * X + 16 + (k - yy * restW);
-    const int mainCell = (m >> 4) * X + (m & 15);
-    return m < mainCols ? mainCell : rest;
-  };
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const bool hasNb = a.ncBias != nullptr;                 // uniform; only the stem convolution has a per-board bias
+  const bool anyRaw = a.rawEnd > a.rawBegin, anyAct = a.actEnd > a.actBegin;  // uniform
   const int actKindRt = (ABL & ABL_EPI_NOACT) ? KMX_ACT_IDENTITY : a.actKind;  // uniform for the launch
-  // this board's rows of the two outputs at this lane's channels; a cell then adds a 32-bit offset
-  T* const rawLane = (T*)a.rawOut + (size_t)n * S * a.rawC + (c8 - a.rawBegin);
-  T* const actLane = (T*)a.actOut + (size_t)n * S * a.actC + (c8 - a.actBegin);
+  T* const rawBoard = (T*)a.rawOut + (size_t)n * S * a.rawC - a.rawBegin;
+  T* const actBoard = (T*)a.actOut + (size_t)n * S * a.actC - a.actBegin;
+  float keep = 0.0f;  // ABL_NO_EPILOGUE: keeps the accumulators observable
+  withActKind(actKindRt, [&](auto kindTag) {
+  constexpr int KIND = decltype(kindTag)::value;
 #pragma unroll
   for(int pt = 0; pt < MT; pt++) {
     const int cellBase = wm * (32 * MT) + pt * 32;
     if(cellBase >= S) break;  // wave-uniform
-    // (a) accumulators -> LDS, [cell][channel] fp32
+    if(ABL & ABL_NO_EPILOGUE) {
 #pragma unroll
-    for(int ct = 0; ct < WN; ct++)
+      for(int ct = 0; ct < WN; ct++)
+#pragma unroll
+        for(int r = 0; r < 16; r++) keep += acc[ct][pt][r];
+      continue;
+    }
+    const int col = cellBase + myPos;
+    const bool live = col < S;                 // the same for both lanes of a pair
+    const int cell = cellOf(live ? col : S - 1);
+    // off-board cells of the activated image are ZERO whatever the arithmetic gave (the raw residual stream is never masked
+    // off the board, and an overflowed fp16 value there must not reach the halo of the next 3x3 convolution as inf * 0 =
+    // NaN): the result bits are ANDed with an all-ones / all-zeros word - no select, no branch per element
+    const unsigned onBits = ldsF1(maskAddr + cell * 4) == 1.0f ? 0xffffffffu : 0u;
+    T* const rawRow = rawBoard + (size_t)cell * a.rawC;
+    T* const actRow = actBoard + (size_t)cell * a.actC;
+#pragma unroll
+    for(int ct = 0; ct < WN; ct++) {
+      const int chTile = wn * (32 * WN) + ct * 32;  // first channel of this 32-channel tile inside the work-group's channels
+      // the parameters are re-read from LDS for every tile (broadcast reads, cheap): kept across the cell tiles they would
+      // occupy 96 registers next to the accumulators and spill. The empty asm hides the address from common-subexpression
+      // elimination.
+      unsigned pOff = (unsigned)(chTile + 4 * khalf) * 4u;
+      asm volatile("" : "+v"(pOff));
+      u32x2 rp[4], op[4];
 #pragma unroll
       for(int g = 0; g < 4; g++) {
+        const f32x4 sc = ldsF4(scAddr + pOff + 32 * g);
+        const f32x4 bi = ldsF4(biAddr + pOff + 32 * g);
         f32x4 v;
 #pragma unroll
         for(int i = 0; i < 4; i++) v[i] = acc[ct][pt][4 * g + i];
-        *(f32x4*)(stage + (lane & 31) * ROWF + ct * 32 + 8 * g + 4 * khalf) = v;
-      }
-    if(ABL & ABL_NO_EPILOGUE) continue;
-    // (b) row-wise walk: lane -> (cell pc of this group, 8 channels pk)
+        if(hasNb) v += ldsF4(nbAddr + pOff + 32 * g);
+        V4 r, o;
 #pragma unroll
-    for(int it = 0; it < NIT; it++) {
-      const int cl = it * CPI + pc;
-      if(!laneOn || cl >= 32) continue;
-      const int col = cellBase + posOfFast(cl);  // staged row cl came from lane cl
-      if(col >= S) continue;
-      const int cell = cellOfFast(col);
-      const f32x4 lo = *(const f32x4*)(stage + cl * ROWF + pk * 8);
-      const f32x4 hi = *(const f32x4*)(stage + cl * ROWF + pk * 8 + 4);
-      // off-board cells of the activated image are ZERO whatever the arithmetic gave (the raw residual stream is never
-      // masked off the board, and an overflowed fp16 value there must not reach the halo of the next 3x3 convolution as
-      // inf * 0 = NaN): the result bits are ANDed with an all-ones / all-zeros word - no select, no branch per element
-      const unsigned onBits = maskBoard[cell] == 1.0f ? 0xffffffffu : 0u;
-      float v[8];
-#pragma unroll
-      for(int i = 0; i < 4; i++) {
-        v[i] = lo[i];
-        v[4 + i] = hi[i];
-      }
-      if(hasNb) {
-#pragma unroll
-        for(int i = 0; i < 8; i++) v[i] += nb[i];
-      }
-      if(inRaw) {
-        V8 o;
-#pragma unroll
-        for(int i = 0; i < 8; i++) o[i] = TR::fromFloat(v[i]);
-        if(ABL & ABL_EPI_NOSTORE) asm volatile("" ::"v"(o));
-        else *(V8*)(rawLane + cell * a.rawC) = o;
-      }
-      if(inAct) {
-        float r[8];
-#pragma unroll
-        for(int i = 0; i < 8; i++) r[i] = v[i] * sc[i] + bi[i];
-        // the activation kind is uniform for the launch: branch ONCE per row, not per element
-        if(actKindRt == KMX_ACT_MISH) {
-#pragma unroll
-          for(int i = 0; i < 8; i++) r[i] = actMish(r[i]);
+        for(int i = 0; i < 4; i++) {
+          r[i] = TR::fromFloat(v[i]);
+          o[i] = TR::fromFloat(actK<KIND>(v[i] * sc[i] + bi[i]));
         }
-        else if(actKindRt == KMX_ACT_RELU) {
+        rp[g] = __builtin_bit_cast(u32x2, r);
+        op[g] = __builtin_bit_cast(u32x2, o);
+        op[g][0] &= onBits;
+        op[g][1] &= onBits;
+      }
+      // this lane's two 16-byte pieces of the tile: channels chTile + 16 j + 8 h + [0, 8)
+      if(anyRaw) {
+        u32x4 rq[2];
+        pairUp(rp, rq);
 #pragma unroll
-          for(int i = 0; i < 8; i++) r[i] = fmaxf(r[i], 0.0f);
+        for(int j = 0; j < 2; j++) {
+          const int c = cout0 + chTile + 16 * j + 8 * khalf;
+          if(live && c >= a.rawBegin && c < a.rawEnd) {
+            if(ABL & ABL_EPI_NOSTORE) asm volatile("" ::"v"(rq[j]));
+            else *(u32x4*)(rawRow + c) = rq[j];
+          }
         }
-        else if(actKindRt == KMX_ACT_SILU) {
+      }
+      if(anyAct) {
+        u32x4 oq[2];
+        pairUp(op, oq);
 #pragma unroll
-          for(int i = 0; i < 8; i++) r[i] = actSilu(r[i]);
+        for(int j = 0; j < 2; j++) {
+          const int c = cout0 + chTile + 16 * j + 8 * khalf;
+          if(live && c >= a.actBegin && c < a.actEnd) {
+            if(ABL & ABL_EPI_NOSTORE) asm volatile("" ::"v"(oq[j]));
+            else *(u32x4*)(actRow + c) = oq[j];
+          }
         }
-        V8 o;
-#pragma unroll
-        for(int i = 0; i < 8; i++) o[i] = TR::fromFloat(r[i]);
-        u32x4 ob = __builtin_bit_cast(u32x4, o);
-#pragma unroll
-        for(int i = 0; i < 4; i++) ob[i] &= onBits;
-        o = __builtin_bit_cast(V8, ob);
-        if(ABL & ABL_EPI_NOSTORE) asm volatile("" ::"v"(o));
-        else *(V8*)(actLane + cell * a.actC) = o;
       }
     }
   }
+  });
   if(ABL & ABL_NO_EPILOGUE) {
-    // keep the staged values observable so the compiler cannot drop the accumulators
-    if(stage[lane] == 12345.678f) ((float*)a.actOut)[lane] = stage[lane + 1];
+    if(keep == 12345.678f) ((float*)a.actOut)[lane] = keep;
   }
   if((ABL & ABL_TIMING) && a.dbg != nullptr && lane == 0 && blockIdx.x == 0 && (int)blockIdx.y == a.N / 2) {
     // one record of 8 counters per wave of the middle board's first work-group
@@ -669,7 +654,6 @@ hipError_t launchOne(const ConvArgs& a, hipStream_t stream) {
   constexpr int ldsBytes = G::LDS_BYTES;
   static_assert(ldsBytes <= 160 * 1024, "LDS budget exceeded");
   static_assert(!G::SPREAD || G::LS + (G::ROLES ? 1 : D) <= G::NT, "image pieces must land within their chunk");
-  static_assert(G::STAGE_BYTES <= G::MASK_OFFSET, "epilogue staging overlaps the mask tile");
   auto kern = convMfmaKernel<TR, KS, WN, WNW, D, ABL>;
   // The opt-in to more than 64 KiB of dynamic LDS is a property of the function ON ONE DEVICE, and one process may hold
   // handles on several GPUs (the reference runs one server thread per GPU in a single process): one flag per

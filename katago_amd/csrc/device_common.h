@@ -106,6 +106,24 @@ __device__ __forceinline__ float actApply(float x, int kind) {
   return x;
 }
 
+// The activation kind is uniform for a launch: kernels branch ONCE (withActKind) into a body instantiated for the kind, instead of
+// once per element or per row - and only that body's code is fetched.
+template <int KIND>
+__device__ __forceinline__ float actK(float x) {
+  return KIND == KMX_ACT_MISH ? actMish(x) : KIND == KMX_ACT_RELU ? fmaxf(x, 0.0f) : KIND == KMX_ACT_SILU ? actSilu(x) : x;
+}
+template <int K>
+struct ActKindTag {
+  static constexpr int value = K;
+};
+template <class F>
+__device__ __forceinline__ void withActKind(int kind, F&& f) {
+  if(kind == KMX_ACT_MISH) f(ActKindTag<KMX_ACT_MISH>());
+  else if(kind == KMX_ACT_RELU) f(ActKindTag<KMX_ACT_RELU>());
+  else if(kind == KMX_ACT_SILU) f(ActKindTag<KMX_ACT_SILU>());
+  else f(ActKindTag<KMX_ACT_IDENTITY>());
+}
+
 // Index map of copyWithSymmetry (nninputs.cpp:529-577) for one channel-last image: the cell (h,w) of the
 // source lands on cell index symDst(...) of the destination. reverse=false for inputs, true for outputs.
 __device__ __forceinline__ int symDst(int h, int w, int hSize, int wSize, int symmetry, bool reverse) {

@@ -27,7 +27,6 @@
 #define KMX_POINTWISE_KERNEL_H_
 
 #include <atomic>
-#include <type_traits>
 
 #include "device_common.h"
 
@@ -83,19 +82,6 @@ __device__ __forceinline__ void dma16(const void* gsrc, char* ldsWaveBase) {
   __builtin_amdgcn_global_load_lds(
     (const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)ldsWaveBase, 16, 0, 0);
 }
-template <int KIND>
-__device__ __forceinline__ float actK(float x) {
-  return KIND == KMX_ACT_MISH ? actMish(x) : KIND == KMX_ACT_RELU ? fmaxf(x, 0.0f) : KIND == KMX_ACT_SILU ? actSilu(x) : x;
-}
-// the activation kind is uniform for a launch: branch once per epilogue, not per element
-template <class F>
-__device__ __forceinline__ void withActKind(int kind, F&& f) {
-  if(kind == KMX_ACT_MISH) f(std::integral_constant<int, KMX_ACT_MISH>());
-  else if(kind == KMX_ACT_RELU) f(std::integral_constant<int, KMX_ACT_RELU>());
-  else if(kind == KMX_ACT_SILU) f(std::integral_constant<int, KMX_ACT_SILU>());
-  else f(std::integral_constant<int, KMX_ACT_IDENTITY>());
-}
-
 template <class TR, int K1, int WN1, int WN2, int TM>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void pointwisePairKernel(const PwPairArgs a) {
   typedef typename TR::T T;

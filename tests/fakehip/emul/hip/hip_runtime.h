@@ -138,6 +138,7 @@ void launchImpl(dim3 grid, dim3 block, const std::function<void()>& body);
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_s_barrier() __syncthreads()
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }

@@ -45,20 +45,17 @@ def emu_lib(tmp_path_factory):
 # ---- the "real convolution" build: conv_mfma.hip / conv_kernel.h themselves, emulated -----------------------------------
 # The kernel source is used as it is except for the statements that only exist on the GPU, which are rewritten at test time
 # (the product file is not touched): s_waitcnt / register-class asm statements are dropped, the dynamic LDS declaration
-# becomes the emulator's buffer, global_load_lds becomes an immediate per-lane copy, and a wave-level sync is injected at the
-# two places of the epilogue where a wave reads back what its other lanes wrote to LDS (lockstep on the hardware, not
-# between OS threads). v_mfma_f32_32x32x16 runs as a wave-collective in the hardware's register layout. What this cannot
+# becomes the emulator's buffer, global_load_lds becomes an immediate per-lane copy. v_mfma_f32_32x32x16 and
+# v_permlane32_swap run as wave-collectives in the hardware's register layout. What this cannot
 # show is anything about asynchronous completion (the s_waitcnt / ring-depth logic): the copies are immediate here.
 CONV_REWRITES = [
     (r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\(N\) : "memory"\);', ";", 1),
     (r'asm volatile\("" : "\+s"\(sTap\)\);', ";", 1),
-    (r'asm volatile\("" ::"v"\(touch\)\);', ";", 1),
-    (r'asm volatile\("" ::"v"\(o\)\);', ";", 2),
+    (r'asm volatile\("" ::"v"\((rq|oq)\[j\]\)\);', ";", 2),
+    (r'asm volatile\("" : "\+v"\(pOff\)\);', ";", 1),
     (r'extern __shared__ __attribute__\(\(aligned\(256\)\)\) char smem\[\];', "char* const smem = (char*)emu::dynLds();", 1),
     (r'__builtin_amdgcn_global_load_lds\(', "emu::globalLoadLds(", 2),
     (r'__attribute__\(\(amdgpu_waves_per_eu\(2, 2\)\)\)', "", 1),
-    (r'(\n    // \(a\) accumulators -> LDS, \[cell\]\[channel\] fp32)', r"\n    emu::waveSync();\1", 1),
-    (r'(\n    // \(b\) row-wise walk: lane -> \(cell pc of this group, 8 channels pk\))', r"\n    emu::waveSync();\1", 1),
 ]
 
 

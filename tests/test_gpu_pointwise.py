@@ -78,7 +78,14 @@ def test_whole_net_with_and_without_fused_seams_is_bit_identical(tmp_path, dtype
         a = nn.getOutput(h0, sp[:n], gl[:n], sym[:n])
         b = nn.getOutput(h1, sp[:n], gl[:n], sym[:n])
         for k in a:
-            assert np.array_equal(a[k], b[k]), (n, k, float(np.abs(a[k] - b[k]).max()))
+            if not np.array_equal(a[k], b[k]):
+                d = np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).reshape(n, -1)
+                rows = np.where(~(d == 0).all(axis=1))[0]
+                # which of the two is the odd one out? evaluate both again
+                a2 = nn.getOutput(h0, sp[:n], gl[:n], sym[:n])
+                b2 = nn.getOutput(h1, sp[:n], gl[:n], sym[:n])
+                raise AssertionError((n, k, float(np.nanmax(d)), "rows", rows[:20].tolist(), "unfused repeatable", bool(np.array_equal(a[k], a2[k])),
+                                      "fused repeatable", bool(np.array_equal(b[k], b2[k])), "second pass equal", bool(np.array_equal(a2[k], b2[k]))))
     lib = h1._lib
 
     def profile(h):
