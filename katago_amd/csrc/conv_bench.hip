@@ -33,6 +33,7 @@ hipError_t launchVariant(int ks, int cfg, int variant, const ConvArgs& a, hipStr
   V(3, 2, 3, 4, 2048) /* ring depth 4 with cycle stamps: the unexplained 2x slowdown */ V(3, 2, 3, 3, 4096) V(3, 2, 3, 4, 4096) V(3, 2, 2, 3, 4096) V(3, 2, 3, 3, 6144) V(3, 2, 3, 4, 6144)  // ABL_BP2 (+ ABL_TIMING): barrier on even taps
   V(1, 1, 3, 2, 0) V(1, 2, 3, 2, 0) V(1, 2, 3, 3, 0)
   V(3, 2, 3, 3, 8192) V(3, 2, 3, 3, 8192 + 2048)  // ABL_PRIO
+  V(3, 2, 3, 3, 16384) V(3, 2, 3, 3, 16384 + 2048) V(3, 2, 3, 3, 16384 + 1)  // ABL_TWOLOADERS
   V(1, 1, 3, 2, 1) V(1, 1, 3, 2, 2) V(1, 1, 3, 2, 4) V(1, 1, 3, 2, 5)
   V(1, 2, 3, 2, 1) V(1, 2, 3, 2, 2) V(1, 2, 3, 2, 4) V(1, 2, 3, 2, 5)
 #undef V
@@ -68,7 +69,7 @@ double benchConv(int ks, int cfg, int variant, int cin, int cout, int batch, int
   FusedConv fc = buildFusedConv(dtype, {{&c, &bn}}, nullptr);
   std::vector<uint16_t> hin(cells * inStride);
   for(uint16_t& v : hin) v = dtype == DT_F16 ? floatToHalfBits(rnd()) : floatToBf16Bits(rnd());
-  DevBuf in(hin.size() * 2, false), resid(cells * outStride * 2), raw(cells * outStride * 2), act(cells * outStride * 2), zero(ZERO_PAGE_BYTES);
+  DevBuf in(hin.size() * 2, false), resid(cells * outStride * 2), raw(cells * outStride * 2), act(cells * outStride * 2), zero(ZERO_PAGE_ALLOC);
   in.upload(hin.data(), hin.size() * 2);
   std::vector<float> ones(cells, 1.0f);
   DevBuf mask(cells * sizeof(float), false);
@@ -104,7 +105,7 @@ double benchConv(int ks, int cfg, int variant, int cin, int cout, int batch, int
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   const int r2 = variant - 2000, r3 = variant - 3000;  // variant = D*1000 + ABL with D in {2,3} for the timing variants
-  if((r2 >= 2048 && r2 < 2304) || (r3 >= 2048 && r3 < 2304) || variant == 3000 + 6144 || variant == 4000 + 6144 || variant == 4000 + 2048 || variant == 3000 + 8192 + 2048) {  // ABL_TIMING: cycle sums of the last launch, one line per wave
+  if((r2 >= 2048 && r2 < 2304) || (r3 >= 2048 && r3 < 2304) || variant == 3000 + 6144 || variant == 4000 + 6144 || variant == 4000 + 2048 || variant == 3000 + 8192 + 2048 || variant == 3000 + 16384 + 2048) {  // ABL_TIMING: cycle sums of the last launch, one line per wave
     unsigned long long h[64];
     hipCheck(hipMemcpy(h, dbg.get(), sizeof(h), hipMemcpyDeviceToHost), "copy timing");
     const int nw = (cfg / 10) * 4;

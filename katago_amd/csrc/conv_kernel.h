@@ -60,6 +60,7 @@ constexpr int MAXLEN = 19;
 enum { ABL_NO_EPILOGUE = 1, ABL_NO_COMPUTE = 2, ABL_NO_DMA = 4, ABL_NO_LDS_READ = 8, ABL_NO_VMWAIT = 16, ABL_NO_W_DMA = 32, ABL_NO_A_DMA = 64,
        ABL_EPI_NOACT = 512, ABL_EPI_NOSTORE = 1024,
        ABL_TIMING = 2048 /* s_memtime stamps between the segments of a step, summed per wave into ConvArgs::dbg */,
+       ABL_TWOLOADERS = 16384 /* the previous division of the DMA work in the 8-wave 3x3 / 5x5 shapes: weights by waves 0-3, board image by waves 4-7 */,
        ABL_PRIO = 8192 /* EXPERIMENT: waves 4-7 (the younger wave of each SIMD, which loses the issue arbitration) run the main loop at s_setprio 1 */,
        ABL_BP2 = 4096 /* EXPERIMENT, not an ablation: work-group barrier on even taps only (Geom::BP = 2). Carried in this
                          parameter so that the product kernels (ABL = 0) keep their symbols and their code. */ };
@@ -128,6 +129,53 @@ struct Geom {
 template <int N>
 __device__ __forceinline__ void waitVm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// s_waitcnt vmcnt(n) for an n that is a constant only after the tap loop is unrolled
+__device__ __forceinline__ void waitVmSel(int n) {
+  switch(n) {
+    case 0: waitVm<0>(); break;
+    case 1: waitVm<1>(); break;
+    case 2: waitVm<2>(); break;
+    case 3: waitVm<3>(); break;
+    case 4: waitVm<4>(); break;
+    case 5: waitVm<5>(); break;
+    case 6: waitVm<6>(); break;
+    case 7: waitVm<7>(); break;
+    case 8: waitVm<8>(); break;
+    case 9: waitVm<9>(); break;
+    case 10: waitVm<10>(); break;
+    case 11: waitVm<11>(); break;
+    case 12: waitVm<12>(); break;
+    case 13: waitVm<13>(); break;
+    case 14: waitVm<14>(); break;
+    case 15: waitVm<15>(); break;
+    case 16: waitVm<16>(); break;
+    case 17: waitVm<17>(); break;
+    case 18: waitVm<18>(); break;
+    case 19: waitVm<19>(); break;
+    case 20: waitVm<20>(); break;
+    case 21: waitVm<21>(); break;
+    case 22: waitVm<22>(); break;
+    case 23: waitVm<23>(); break;
+    case 24: waitVm<24>(); break;
+    case 25: waitVm<25>(); break;
+    case 26: waitVm<26>(); break;
+    case 27: waitVm<27>(); break;
+    case 28: waitVm<28>(); break;
+    case 29: waitVm<29>(); break;
+    case 30: waitVm<30>(); break;
+    case 31: waitVm<31>(); break;
+    case 32: waitVm<32>(); break;
+    case 33: waitVm<33>(); break;
+    case 34: waitVm<34>(); break;
+    case 35: waitVm<35>(); break;
+    case 36: waitVm<36>(); break;
+    case 37: waitVm<37>(); break;
+    case 38: waitVm<38>(); break;
+    case 39: waitVm<39>(); break;
+    case 40: waitVm<40>(); break;
+    default: waitVm<0>(); break;  // stricter than needed, never wrong
+  }
 }
 // LDS destinations are 32-bit LDS addresses (wave-uniform; lane l lands at +16 l), not generic pointers: a generic -> LDS
 // pointer cast carries a null check, and hipcc (ROCm 7.2) mis-selects that compare when the pointer is a select of uniform values
@@ -198,8 +246,15 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   // advance by one 32-channel chunk (64 bytes) each time they are used, so the main loop spends no vector ALU
   // work on DMA addresses (vector ALU instructions compete with the MFMAs for the issue slot).
   constexpr bool ROLES = G::ROLES;
+  // ONE: in the 8-wave 3x3 / 5x5 shapes waves 0-3 issue ALL the DMA (weight slabs and the next chunk's board image). They are
+  // the older wave of each SIMD: the matrix core serves them first, and they used to idle ~27 % of the loop at the barrier
+  // waiting for waves 4-7, which multiply at lower priority AND paid ~330 cycles per step for their image requests
+  // (an LDS-DMA instruction costs its wave 100-200 cycles of issue). With every request on the waves that have the slack,
+  // the younger waves only multiply. (tools/conv_timing.py; ABL_TWOLOADERS restores the previous division for comparison.)
+  // (possible when the image pieces have all been requested before the slab that is waited for at the last tap: LS <= NT + 1 - D)
+  constexpr bool ONE = ROLES && SPREAD && BP == 1 && G::LS <= NT + 1 - D && !(ABL & ABL_TWOLOADERS);
   const bool wLoader = !ROLES || wave < 4;        // wave-uniform
-  const bool aLoader = !ROLES || wave >= 4;
+  const bool aLoader = !ROLES || (ONE ? wave < 4 : wave >= 4);
   const int lw = wave;                            // index among the weight-loading waves
   const int la = ROLES ? (wave & 3) : wave;       // index among the image-loading waves
   unsigned srcOff[NPA];  // byte offset from this board's tensor, or (bit 31 set) into the zero page; +64 per chunk
@@ -348,7 +403,15 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
     dma4(psrc, ldsBase + G::PARAM_OFFSET + (j * NWAVES + wave) * 256);
   }
   // ---- prologue, part 2: fill the pipeline with the same per-step instruction pattern the loop uses ----
-  if(ROLES) {
+  if(ONE) {
+    if(wLoader) {
+#pragma unroll
+      for(int j = 0; j < NPA; j++) issueA(0, j);
+#pragma unroll
+      for(int s = 0; s < D; s++) issueW(s);
+    }
+  }
+  else if(ROLES) {
     if(wLoader) {
 #pragma unroll
       for(int s = 0; s < D; s++) issueW(s);
@@ -383,48 +446,13 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
     }
   }
 
-  // Accumulators start from the residual stream (trunk += conv(...), eigenbackend.cpp:659-686) instead of zero:
-  // the only global LOADS of the kernel besides the DMA are issued here, underneath the pipeline fill. Branch-free
-  // (out-of-range pieces read the zero page) so that a whole tile row of loads is in flight at once.
   f32x16 acc[WN][MT];
-  if(a.resid != nullptr) {
 #pragma unroll
-    for(int pt = 0; pt < MT; pt++) {
-      int cell = wm * (32 * MT) + pt * 32 + myPos;
-      cell = cellOf(cell < S ? cell : S - 1);
-      const T* const rrow = (const T*)a.resid + ((size_t)n * S + cell) * a.residC - a.rawBegin;
-      // 16-byte loads: lanes c and c + 32 of a tile column fetch the two 8-channel runs of each 16 channels and exchange
-      // halves afterwards (device_common.h unpair) - half the load instructions of 8-byte pieces for the same bytes
-      u32x4 rq[WN][2];
+  for(int ct = 0; ct < WN; ct++)
 #pragma unroll
-      for(int ct = 0; ct < WN; ct++)
+    for(int pt = 0; pt < MT; pt++)
 #pragma unroll
-        for(int j = 0; j < 2; j++) {
-          const int c = cout0 + wn * (32 * WN) + ct * 32 + 16 * j + 8 * khalf;
-          const T* src = (c >= a.rawBegin && c < a.rawEnd) ? rrow + c : (const T*)zero;
-          rq[ct][j] = *(const u32x4*)src;
-        }
-#pragma unroll
-      for(int ct = 0; ct < WN; ct++) {
-        u32x2 rp[4];
-        unpair(rq[ct], rp);
-#pragma unroll
-        for(int g = 0; g < 4; g++) {
-          const V4 rr = __builtin_bit_cast(V4, rp[g]);
-#pragma unroll
-          for(int i = 0; i < 4; i++) acc[ct][pt][4 * g + i] = TR::toFloat(rr[i]);
-        }
-      }
-    }
-  }
-  else {
-#pragma unroll
-    for(int ct = 0; ct < WN; ct++)
-#pragma unroll
-      for(int pt = 0; pt < MT; pt++)
-#pragma unroll
-        for(int r = 0; r < 16; r++) acc[ct][pt][r] = 0.0f;
-  }
+      for(int r = 0; r < 16; r++) acc[ct][pt][r] = 0.0f;
 
   // ---- main loop ----
   // Invariant at the top of step s: slab s (and its board image) landed and was barrier-published one step EARLIER, and
@@ -432,7 +460,23 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   //     wait+barrier (publishes slab s+1) | read F1(s) | MFMA F0(s) | DMA for step s+D | read F0(s+1) | MFMA F1(s)
   // so every LDS read has eight MFMAs (256 matrix-core cycles) to land in, and the matrix core only idles for the
   // barrier skew between waves.
+  // image pieces requested at tap tt of a chunk (ONE)
+  auto piecesAt = [&](int tt) -> int {
+    const int left = NPA - tt * G::PPS;
+    return left <= 0 ? 0 : left < G::PPS ? left : G::PPS;
+  };
   auto issueStep = [&](int chunk, int t, int step) {
+    if(ONE) {
+      // image pieces FIRST, then the slab: everything older than the slab that a later step waits for has then landed too.
+      // In the last chunk the pieces are dummies (the count per tap stays a compile-time constant).
+      if(wLoader) {
+#pragma unroll
+        for(int i = 0; i < G::PPS; i++)
+          if(t * G::PPS + i < NPA) issueA(chunk + 1, t * G::PPS + i);
+        issueW(step + D);
+      }
+      return;
+    }
     if(ROLES) {
       if(wLoader) issueW(step + D);
       else if(SPREAD) {
@@ -462,6 +506,17 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   // top-of-step wait of this wave's own requests: everything the barrier is about to publish
   auto waitStep = [&](int t) {
     if(ABL & (ABL_NO_DMA | ABL_NO_VMWAIT | ABL_NO_W_DMA | ABL_NO_A_DMA)) return;
+    if(ONE) {
+      // top of step s: slab s+1 (requested in step s+1-D, after that step's image pieces) has landed; younger: the requests of
+      // steps s+2-D .. s-1
+      if(wLoader) {
+        int n = 0;
+#pragma unroll
+        for(int k = 1; k <= D - 2; k++) n += NPW + piecesAt((t - k + NT * D) % NT);
+        waitVmSel(n);
+      }
+      return;
+    }
     if(!ROLES) waitVm<G::VMCNT>();
     else if(wLoader) {
       if constexpr(BP == 2) {
@@ -549,14 +604,46 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   const unsigned maskAddr = ldsBase + G::MASK_OFFSET;
   const unsigned scAddr = ldsBase + G::PARAM_OFFSET, biAddr = scAddr + G::NTP * 4, nbAddr = biAddr + G::NTP * 4;
   if(!waveActive) return;
+  const bool hasResid = a.resid != nullptr;               // uniform
   const bool hasNb = a.ncBias != nullptr;                 // uniform; only the stem convolution has a per-board bias
   const bool anyRaw = a.rawEnd > a.rawBegin, anyAct = a.actEnd > a.actBegin;  // uniform
   const int actKindRt = (ABL & ABL_EPI_NOACT) ? KMX_ACT_IDENTITY : a.actKind;  // uniform for the launch
   T* const rawBoard = (T*)a.rawOut + (size_t)n * S * a.rawC - a.rawBegin;
   T* const actBoard = (T*)a.actOut + (size_t)n * S * a.actC - a.actBegin;
+  // Stores are UNCONDITIONAL: a piece that must not be written (a column beyond the board's cells, a channel outside the
+  // output's range) goes to a 1 KiB trash area behind the zero page instead of being predicated off. Besides saving the
+  // exec-mask branches, this makes the number of stores per tile a compile-time constant - with stores inside branches the
+  // compiler waits for the residual loads below with s_waitcnt vmcnt(0), i.e. for every store issued before them to be
+  // acknowledged by memory, once per tile.
+  T* const trash = (T*)((char*)const_cast<void*>(a.zeroPage) + ZERO_PAGE_BYTES) + lane * 8;
+  int cellOfTile[MT];
+#pragma unroll
+  for(int pt = 0; pt < MT; pt++) {
+    const int rc = wm * (32 * MT) + pt * 32 + myPos;
+    cellOfTile[pt] = cellOf(rc < S ? rc : S - 1);
+  }
   float keep = 0.0f;  // ABL_NO_EPILOGUE: keeps the accumulators observable
-  withActKind(actKindRt, [&](auto kindTag) {
+  // The residual stream (trunk += conv(...), eigenbackend.cpp:659-686) is fetched HERE and added in fp32 before the rounding:
+  // 16-byte pieces in the layout of the stores (lane pair (c, c + 32): channels 16 j + 8 h + [0, 8)), branch-free
+  // (out-of-range pieces read the zero page), requested one (cell tile, channel tile) ahead of their use - two pieces in
+  // flight besides the two being consumed; the accumulators leave no room for more (256 registers per lane at two waves per
+  // SIMD). As the accumulators' initial value these loads sat in the prologue, on the critical path of every work-group at
+  // the moment all of them pull their first operands from HBM. The body is instantiated with and without a residual so that
+  // the launches without one carry no load bookkeeping at all.
+  auto epilogue = [&](auto kindTag, auto residTag) {
   constexpr int KIND = decltype(kindTag)::value;
+  constexpr bool RESID = decltype(residTag)::value != 0;
+  u32x4 rq[2][2];
+  auto loadResid = [&](int pt, int ct, u32x4 (&dst)[2]) {
+    const T* const rrow = (const T*)a.resid + ((size_t)n * S + cellOfTile[pt]) * a.residC - a.rawBegin;
+#pragma unroll
+    for(int j = 0; j < 2; j++) {
+      const int c = cout0 + wn * (32 * WN) + ct * 32 + 16 * j + 8 * khalf;
+      const T* src = (c >= a.rawBegin && c < a.rawEnd) ? rrow + c : (const T*)zero;
+      dst[j] = *(const u32x4*)src;
+    }
+  };
+  if(RESID) loadResid(0, 0, rq[0]);
 #pragma unroll
   for(int pt = 0; pt < MT; pt++) {
     const int cellBase = wm * (32 * MT) + pt * 32;
@@ -570,7 +657,7 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
     }
     const int col = cellBase + myPos;
     const bool live = col < S;                 // the same for both lanes of a pair
-    const int cell = cellOf(live ? col : S - 1);
+    const int cell = cellOfTile[pt];
     // off-board cells of the activated image are ZERO whatever the arithmetic gave (the raw residual stream is never masked
     // off the board, and an overflowed fp16 value there must not reach the halo of the next 3x3 convolution as inf * 0 =
     // NaN): the result bits are ANDed with an all-ones / all-zeros word - no select, no branch per element
@@ -586,6 +673,14 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
       unsigned pOff = (unsigned)(chTile + 4 * khalf) * 4u;
       asm volatile("" : "+v"(pOff));
       u32x2 rp[4], op[4];
+      u32x2 resP[4];
+      if(RESID) {
+        constexpr int NTILES = MT * WN;
+        const int k = pt * WN + ct;
+        // (a tile past the board still requests its pieces - of the last cell - so that the count in flight is a constant)
+        if(k + 1 < NTILES) loadResid((k + 1) / WN, (k + 1) % WN, rq[(k + 1) & 1]);
+        unpair(rq[k & 1], resP);
+      }
 #pragma unroll
       for(int g = 0; g < 4; g++) {
         const f32x4 sc = ldsF4(scAddr + pOff + 32 * g);
@@ -594,6 +689,11 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
         for(int i = 0; i < 4; i++) v[i] = acc[ct][pt][4 * g + i];
         if(hasNb) v += ldsF4(nbAddr + pOff + 32 * g);
+        if(RESID) {
+          const V4 rr = __builtin_bit_cast(V4, resP[g]);
+#pragma unroll
+          for(int i = 0; i < 4; i++) v[i] += TR::toFloat(rr[i]);
+        }
         V4 r, o;
 #pragma unroll
         for(int i = 0; i < 4; i++) {
@@ -606,32 +706,34 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
         op[g][1] &= onBits;
       }
       // this lane's two 16-byte pieces of the tile: channels chTile + 16 j + 8 h + [0, 8)
-      if(anyRaw) {
-        u32x4 rq[2];
-        pairUp(rp, rq);
+      if(RESID || anyRaw) {
+        u32x4 rawQ[2];
+        pairUp(rp, rawQ);
 #pragma unroll
         for(int j = 0; j < 2; j++) {
           const int c = cout0 + chTile + 16 * j + 8 * khalf;
-          if(live && c >= a.rawBegin && c < a.rawEnd) {
-            if(ABL & ABL_EPI_NOSTORE) asm volatile("" ::"v"(rq[j]));
-            else *(u32x4*)(rawRow + c) = rq[j];
-          }
+          T* const dst = (live && c >= a.rawBegin && c < a.rawEnd) ? rawRow + c : trash;
+          if(ABL & ABL_EPI_NOSTORE) asm volatile("" ::"v"(rawQ[j]));
+          else *(u32x4*)dst = rawQ[j];
         }
       }
-      if(anyAct) {
-        u32x4 oq[2];
-        pairUp(op, oq);
+      if(RESID || anyAct) {
+        u32x4 actQ[2];
+        pairUp(op, actQ);
 #pragma unroll
         for(int j = 0; j < 2; j++) {
           const int c = cout0 + chTile + 16 * j + 8 * khalf;
-          if(live && c >= a.actBegin && c < a.actEnd) {
-            if(ABL & ABL_EPI_NOSTORE) asm volatile("" ::"v"(oq[j]));
-            else *(u32x4*)(actRow + c) = oq[j];
-          }
+          T* const dst = (live && c >= a.actBegin && c < a.actEnd) ? actRow + c : trash;
+          if(ABL & ABL_EPI_NOSTORE) asm volatile("" ::"v"(actQ[j]));
+          else *(u32x4*)dst = actQ[j];
         }
       }
     }
   }
+  };
+  withActKind(actKindRt, [&](auto kindTag) {
+    if(hasResid) epilogue(kindTag, ActKindTag<1>());
+    else epilogue(kindTag, ActKindTag<0>());
   });
   if(ABL & ABL_NO_EPILOGUE) {
     if(keep == 12345.678f) ((float*)a.actOut)[lane] = keep;

@@ -165,7 +165,7 @@ void Engine::construct(const ModelDesc& model) {
   gin_ = model.numInputGlobalChannels;
   min_ = model.metaEncoderVersion > 0 ? model.numInputMetaChannels : 0;
   const size_t NS = (size_t)maxBatch_ * S_;
-  zeroPage_ = DevBuf(ZERO_PAGE_BYTES);
+  zeroPage_ = DevBuf(ZERO_PAGE_ALLOC);
   inputT_ = DevBuf(NS * KCHUNK * 2);
   mask_ = DevBuf(NS * sizeof(float));
   maskSum_ = DevBuf((size_t)maxBatch_ * sizeof(float));
@@ -990,7 +990,7 @@ struct HookCtx {
   DevBuf zero, mask;
   HookCtx(int dt, int n, int x, int y, const float* hostMask) : dtype(dt), N(n), X(x), Y(y), S(x * y), st(nullptr) {
     if(x < 2 || y < 2 || x > 19 || y > 19 || n < 1) throw Error(KMX_ERR_INVALID_ARG, "test hook: bad sizes");
-    zero = DevBuf(ZERO_PAGE_BYTES);
+    zero = DevBuf(ZERO_PAGE_ALLOC);
     std::vector<float> ones((size_t)n * S, 1.0f);
     mask = DevBuf((size_t)n * S * sizeof(float), false);
     mask.upload(hostMask ? hostMask : ones.data(), (size_t)n * S * sizeof(float));

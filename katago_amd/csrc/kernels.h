@@ -19,6 +19,8 @@ enum { DT_F16 = 0, DT_BF16 = 1 };
 
 constexpr int KCHUNK = 32;      // input channels per K chunk
 constexpr int ZERO_PAGE_BYTES = 16384;  // >= (inC/32 + 4) * 64
+constexpr int TRASH_BYTES = 1024;       // writable scratch BEHIND the zero page: where the convolution's stores that must not land go (16 bytes per lane)
+constexpr int ZERO_PAGE_ALLOC = ZERO_PAGE_BYTES + TRASH_BYTES;
 constexpr int WROW_HALFS = 32;  // halfs per weight/activation LDS row (64 bytes = four 16-byte slots, XOR-swizzled)
 
 // One fused convolution: out = epilogue( conv(in, w) ).
@@ -31,7 +33,7 @@ constexpr int WROW_HALFS = 32;  // halfs per weight/activation LDS row (64 bytes
 struct ConvArgs {
   const void* in;
   const void* w;
-  const void* zeroPage;  // ZERO_PAGE_BYTES of zeros (halo lanes walk it 64 bytes per input-channel chunk)
+  const void* zeroPage;  // ZERO_PAGE_BYTES of zeros (halo lanes walk it 64 bytes per input-channel chunk), followed by TRASH_BYTES of writable scratch
   int inC;               // channel stride of `in`
   int nChunks;           // ceil(real Cin / 32)
   int coutPad;           // multiple of 32

@@ -73,6 +73,17 @@ template <int N>
 __device__ __forceinline__ void waitVm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+__device__ __forceinline__ void waitVmSel(int n) {  // n becomes a constant once the caller's branches are resolved
+  switch(n) {
+    case 2: waitVm<2>(); break;
+    case 3: waitVm<3>(); break;
+    case 14: waitVm<14>(); break;
+    case 15: waitVm<15>(); break;
+    case 26: waitVm<26>(); break;
+    case 27: waitVm<27>(); break;
+    default: waitVm<0>(); break;  // stricter than needed, never wrong
+  }
+}
 // gfx950 barriers are "back-off" barriers: the compiler does not drain the LDS queue in front of them, so ds_writes that
 // other waves read after the barrier are waited for explicitly
 __device__ __forceinline__ void waitLds() {
@@ -146,7 +157,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
 
   // ---- GEMM 1: accumulators start from the residual stream ----
   const int wm1 = wave >> 2, wn1 = wave & 3;
+  // The residual pieces are requested here and added in epilogue 1 (in fp32, before the rounding) - the same order of
+  // operations as the convolution kernel's epilogue, which the unfused schedule runs: bit-identical results.
   f32x16 acc1[WN1][MT1];
+  u32x4 rq[MT1][WN1][2];
 #pragma unroll
   for(int pt = 0; pt < MT1; pt++) {
     const int cl = wm1 * (32 * MT1) + pt * 32 + myPos;
@@ -154,21 +168,12 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
     // 16-byte pieces: the lane pair (c, c + 32) of a tile column loads channels [16 j + 8 h, +8) and exchanges halves
     // afterwards (device_common.h unpair)
     const T* const rrow = live ? (const T*)a.resid + (size_t)(cell0 + cl) * a.trunkC + wn1 * (32 * WN1) + 8 * khalf : (const T*)zero;
-    u32x4 rq[WN1][2];
-#pragma unroll
-    for(int ct = 0; ct < WN1; ct++)
-#pragma unroll
-      for(int j = 0; j < 2; j++) rq[ct][j] = *(const u32x4*)(live ? rrow + ct * 32 + 16 * j : rrow);
 #pragma unroll
     for(int ct = 0; ct < WN1; ct++) {
-      u32x2 rp[4];
-      unpair(rq[ct], rp);
 #pragma unroll
-      for(int g = 0; g < 4; g++) {
-        const V4 rr = __builtin_bit_cast(V4, rp[g]);
+      for(int j = 0; j < 2; j++) rq[pt][ct][j] = *(const u32x4*)(live ? rrow + ct * 32 + 16 * j : rrow);
 #pragma unroll
-        for(int i = 0; i < 4; i++) acc1[ct][pt][4 * g + i] = TR::toFloat(rr[i]);
-      }
+      for(int r = 0; r < 16; r++) acc1[ct][pt][r] = 0.0f;
     }
   }
 
@@ -225,22 +230,28 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
     const bool live = cell0 + cl < a.cells;
     // off-board cells of the activated image are zero whatever the arithmetic gave: result bits ANDed with all-ones / zeros
     const unsigned onBits = maskS[cl] == 1.0f ? 0xffffffffu : 0u;
-    T* const rawRow = (T*)a.rawOut + (size_t)(cell0 + cl) * a.trunkC;
-    T* const actRow = a.actOut != nullptr ? (T*)a.actOut + (size_t)(cell0 + cl) * a.trunkC : nullptr;
+    // stores are unconditional (a cell past the end writes to the trash area behind the zero page): their number is then a
+    // constant, which the waits of GEMM 2's first steps count on
+    T* const trash = (T*)((char*)const_cast<void*>(a.zeroPage) + ZERO_PAGE_BYTES) + lane * 8;
+    T* const rawRow = live ? (T*)a.rawOut + (size_t)(cell0 + cl) * a.trunkC : nullptr;
+    T* const actRow = live && a.actOut != nullptr ? (T*)a.actOut + (size_t)(cell0 + cl) * a.trunkC : nullptr;
+    const bool hasActOut = a.actOut != nullptr;  // uniform
     const unsigned rowXor = ((unsigned)cl >> 2) & 3;
 #pragma unroll
     for(int ct = 0; ct < WN1; ct++) {
       const int chunk = wn1 * WN1 + ct;  // 32-channel chunk of the trunk this tile covers
-      u32x2 rp[4], op[4];
+      u32x2 rp[4], op[4], resP[4];
+      unpair(rq[pt][ct], resP);
 #pragma unroll
       for(int g = 0; g < 4; g++) {
         const int c = chunk * 32 + 8 * g + 4 * khalf;
         const f32x4 sc = *(const f32x4*)(sc1S + c);
         const f32x4 bi = *(const f32x4*)(bi1S + c);
         V4 r, o;
+        const V4 rr = __builtin_bit_cast(V4, resP[g]);
 #pragma unroll
         for(int i = 0; i < 4; i++) {
-          const float v = acc1[ct][pt][4 * g + i];
+          const float v = acc1[ct][pt][4 * g + i] + TR::toFloat(rr[i]);
           r[i] = TR::fromFloat(v);
           o[i] = TR::fromFloat(actK<KIND>(v * sc[i] + bi[i]));
         }
@@ -250,16 +261,14 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
         op[g][1] &= onBits;
       }
       // regroup into 16-byte runs (lane pair c, c + 32): this lane now holds channels chunk*32 + 16 j + 8 h + [0,8)
-      u32x4 rq[2], oq[2];
-      pairUp(rp, rq);
+      u32x4 rawQ[2], oq[2];
+      pairUp(rp, rawQ);
       pairUp(op, oq);
 #pragma unroll
       for(int j = 0; j < 2; j++) {
         const int c = chunk * 32 + 16 * j + 8 * khalf;
-        if(live) {
-          *(u32x4*)(rawRow + c) = rq[j];
-          if(actRow != nullptr) *(u32x4*)(actRow + c) = oq[j];
-        }
+        *(u32x4*)(live ? rawRow + c : trash) = rawQ[j];
+        if(hasActOut) *(u32x4*)(live ? actRow + c : trash) = oq[j];
         // image layout: chunk `chunk`, row cl, logical 16-byte slot 2 j + h at physical slot ^ rowXor
         *(u32x4*)(smem + chunk * G::CHUNK_BYTES + cl * ROWB + (((2 * j + khalf) ^ rowXor) << 4)) = oq[j];
       }
@@ -286,8 +295,12 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
       xXor[pt] = (q >> 2) & 3;
     }
     const unsigned wRow = (wn2 * (32 * WN2) + l31) * ROWB;
+    // requests in flight, oldest first: slab 0, slab 1, epilogue 1's stores, then slab c+1 (requested at step c-1). Waiting for
+    // slab c with "all but the youngest NPW2" would, in steps 0 and 1, also wait for the stores to be acknowledged.
+    const int nStores1 = MT1 * WN1 * 2 * (a.actOut != nullptr ? 2 : 1);
     for(int c = 0; c < K2; c++) {
-      waitVm<NPW2>();
+      if(c < 2) waitVmSel(NPW2 + nStores1);
+      else waitVm<NPW2>();
       __builtin_amdgcn_s_barrier();  // c == 0: also publishes the activated image written above
       asm volatile("" ::: "memory");
       issueW(a.w2, G::W2_SLAB, NPW2, G::W2_OFF, c + 2, K2);
