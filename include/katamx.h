@@ -193,27 +193,31 @@ int kmx_handle_sync(kmx_handle* handle);
 /* ---- persistent leaf batcher (north_star: "a persistent device-side leaf batcher over a thin C-ABI") ----
  * Replaces the server half of NNEvaluator — serve() popping up to maxBatch rows off a queue and calling getOutput
  * synchronously (nneval.cpp:562-752, core/threadsafequeue.h:173-189) — for callers that submit rows themselves:
- *   kmx_batcher_submit  thread-safe, called by the search thread that owns the leaf: reserves a row of the batch that is
- *                       filling and bit-packs the fp32 NHWC feature planes (all V7 planes are 0/1; any other value fails the
- *                       batch with KMX_ERR_INVALID_ARG) straight into that batch's pinned staging, outside the lock.
- *                       Blocks only while every staging set is busy. Returns a ticket.
- *   kmx_batcher_wait    blocks until the ticket's batch is back from the device and copies the row's outputs (layout as
- *                       kmx_eval: policy nn_x*nn_y+1, value 3, score 6, ownership nn_x*nn_y or NULL). Each ticket is
- *                       waited for exactly once.
- * Batching is greedy like the reference's (a batch is sealed as soon as the device has room for it and at least one row
- * is waiting; it never waits for more), but up to max_in_flight batches (default 2 when <= 0) are between H2D and D2H at
- * once on their own engines and streams, so copies and kernels of consecutive batches overlap and rows arriving while
- * the device is busy accumulate into the next batch. rows/batches as nneval.cpp:712-713. A row's outputs are
+ *   kmx_batcher_submit  thread-safe, called by the thread that owns the leaf (a search thread, or a server thread of the
+ *                       reference's NNEvaluator with the rows it popped): reserves a row of the batch that is filling and
+ *                       bit-packs the fp32 NHWC feature planes (all V7 planes are 0/1; any other value fails the batch with
+ *                       KMX_ERR_INVALID_ARG) straight into that batch's pinned staging, outside the lock. The out_* buffers
+ *                       (layout as kmx_eval: policy nn_x*nn_y+1, value 3, score 6, ownership nn_x*nn_y or NULL = not
+ *                       wanted) receive the row's results and must stay valid until kmx_batcher_wait returns. Blocks only
+ *                       while every staging set is filling or on the DEVICE - never on results that have not been
+ *                       collected, so a thread may hold any number of tickets. Returns a ticket.
+ *   kmx_batcher_wait    blocks until the ticket's row has been written to its out_* buffers (or its batch failed: the
+ *                       status and kmx_last_error say why). Each ticket is waited for exactly once.
+ * Batching is greedy like the reference's when the device is idle (a waiting row never waits for more rows); while a
+ * batch is on the device the next one accumulates, and FULL batches are launched behind it, up to max_in_flight
+ * (default 2 when <= 0) between H2D and D2H at once on their own engines and streams, so that copies and kernels of
+ * consecutive batches overlap. rows/batches as nneval.cpp:712-713. A row's outputs are
  * bit-identical to the same row through kmx_eval. */
 typedef struct kmx_batcher kmx_batcher;
 int kmx_batcher_create(kmx_context* ctx, const kmx_model* model, int max_batch_size, int max_in_flight, int gpu_idx,
                        kmx_batcher** out);
-void kmx_batcher_free(kmx_batcher* batcher); /* fails rows not yet launched, completes those on the device */
+void kmx_batcher_free(kmx_batcher* batcher); /* fails rows not yet launched, completes those on the device; no thread may be inside submit/wait */
 int kmx_batcher_submit(kmx_batcher* batcher, const float* row_spatial, const float* row_global, const float* row_meta,
-                       int symmetry, float policy_optimism, int want_ownership, uint64_t* ticket);
-int kmx_batcher_wait(kmx_batcher* batcher, uint64_t ticket, float* out_policy, float* out_value, float* out_score,
-                     float* out_ownership);
+                       int symmetry, float policy_optimism, float* out_policy, float* out_value, float* out_score,
+                       float* out_ownership, uint64_t* ticket);
+int kmx_batcher_wait(kmx_batcher* batcher, uint64_t ticket);
 int kmx_batcher_stats(kmx_batcher* batcher, uint64_t* rows, uint64_t* batches);
+int kmx_batcher_precision(const kmx_batcher* batcher); /* KMX_PREC_FP16 or KMX_PREC_BF16: what its engines compute in (isUsingFP16, nninterface.h:108) */
 
 /* NNEvaluator counters (nneval.cpp:330-347, incremented :712-713): rows = evaluated
  * positions, batches = kmx_eval calls. */

@@ -18,9 +18,12 @@
 #include "neuralnet/modelversion.h"
 #include "neuralnet/desc.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "katamx.h"
@@ -77,6 +80,19 @@ struct ComputeContext {
   int precisionMode;
 #ifndef KMX_USE_ORACLE
   kmx_context* ctx = NULL;
+  // katamxBatcher = true: every server thread of this context that serves the same (model, device) feeds ONE persistent leaf
+  // batcher (kmx_batcher_*) instead of owning a handle: its getOutput submits the rows NNEvaluator::serve popped and waits
+  // for their tickets. Rows of several server threads then share device batches (up to katamxBatcherInFlight of them
+  // between H2D and D2H), where separate handles would run small batches side by side.
+  bool useBatcher = false;
+  int batcherInFlight = 2;
+  struct SharedBatcher {
+    kmx_batcher* batcher = NULL;
+    int users = 0;
+    int maxBatchSize = 0;
+  };
+  std::mutex batcherMutex;
+  std::map<std::pair<const LoadedModel*, int>, SharedBatcher> batchers;
 #endif
 };
 
@@ -90,6 +106,8 @@ struct ComputeHandle {
   int numInputMetaChannels;
 #ifndef KMX_USE_ORACLE
   kmx_handle* handle = NULL;
+  kmx_batcher* batcher = NULL;  // shared (ComputeContext::batchers); NULL when katamxBatcher is off
+  int gpuIdx = 0;
 #endif
 };
 
@@ -110,6 +128,7 @@ struct InputBuffers {
   vector<float> score;
   vector<float> ownershipScratch;
   vector<float> nhwcScratch;  // only used when the host hands over NCHW rows
+  vector<uint64_t> tickets;   // katamxBatcher
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -182,6 +201,10 @@ ComputeContext* NeuralNet::createComputeContext(
   }
   context->precisionMode = precisionMode;
 #ifndef KMX_USE_ORACLE
+  if(cfg.contains("katamxBatcher")) context->useBatcher = cfg.getBool("katamxBatcher");
+  else if(const char* e = getenv("KATAMX_BATCHER")) context->useBatcher = atoi(e) != 0;
+  if(cfg.contains("katamxBatcherInFlight")) context->batcherInFlight = cfg.getInt("katamxBatcherInFlight", 1, 8);
+  else if(const char* e = getenv("KATAMX_BATCHER_IN_FLIGHT")) context->batcherInFlight = std::max(1, std::min(8, atoi(e)));
   check(
     kmx_context_create(gpuIdxs.data(), (int)gpuIdxs.size(), nnXLen, nnYLen, precisionMode, &context->ctx),
     "creating compute context");
@@ -218,17 +241,31 @@ ComputeHandle* NeuralNet::createComputeHandle(
   handle->numInputGlobalChannels = loadedModel->modelDesc.numInputGlobalChannels;
   handle->numInputMetaChannels = loadedModel->modelDesc.numInputMetaChannels;
 #ifndef KMX_USE_ORACLE
-  check(
-    kmx_handle_create(
-      context->ctx, loadedModel->model, maxBatchSize, requireExactNNLen ? 1 : 0, gpuIdxForThisThread, &handle->handle),
-    "creating compute handle");
+  handle->gpuIdx = gpuIdxForThisThread;
+  if(context->useBatcher) {
+    std::lock_guard<std::mutex> lock(context->batcherMutex);
+    ComputeContext::SharedBatcher& sb = context->batchers[std::make_pair(loadedModel, gpuIdxForThisThread)];
+    if(sb.batcher == NULL) {
+      check(
+        kmx_batcher_create(context->ctx, loadedModel->model, maxBatchSize, context->batcherInFlight, gpuIdxForThisThread, &sb.batcher),
+        "creating the leaf batcher");
+      sb.maxBatchSize = maxBatchSize;
+    }
+    sb.users++;
+    handle->batcher = sb.batcher;
+  }
+  else
+    check(
+      kmx_handle_create(
+        context->ctx, loadedModel->model, maxBatchSize, requireExactNNLen ? 1 : 0, gpuIdxForThisThread, &handle->handle),
+      "creating compute handle");
   if(logger != NULL) {
-    int prec = kmx_handle_precision(handle->handle);
+    int prec = handle->batcher != NULL ? kmx_batcher_precision(handle->batcher) : kmx_handle_precision(handle->handle);
     logger->write(
       "katamx (HIP/gfx950) backend thread " + Global::intToString(serverThreadIdx) + ": device " +
       Global::intToString(gpuIdxForThisThread) + " precision " +
-      (prec == KMX_PREC_FP32 ? "fp32" : prec == KMX_PREC_FP16 ? "fp16" : "bf16") + " model " +
-      loadedModel->modelDesc.name);
+      (prec == KMX_PREC_FP32 ? "fp32" : prec == KMX_PREC_FP16 ? "fp16" : "bf16") + (handle->batcher != NULL ? " (shared leaf batcher)" : "") +
+      " model " + loadedModel->modelDesc.name);
   }
 #else
   (void)maxBatchSize;
@@ -243,7 +280,17 @@ void NeuralNet::freeComputeHandle(ComputeHandle* handle) {
   if(handle == NULL)
     return;
 #ifndef KMX_USE_ORACLE
-  kmx_handle_free(handle->handle);
+  if(handle->batcher != NULL) {
+    ComputeContext* context = const_cast<ComputeContext*>(handle->context);
+    std::lock_guard<std::mutex> lock(context->batcherMutex);
+    auto it = context->batchers.find(std::make_pair(handle->loadedModel, handle->gpuIdx));
+    if(it != context->batchers.end() && --it->second.users == 0) {
+      kmx_batcher_free(it->second.batcher);
+      context->batchers.erase(it);
+    }
+  }
+  else
+    kmx_handle_free(handle->handle);
 #endif
   delete handle;
 }
@@ -253,7 +300,7 @@ bool NeuralNet::isUsingFP16(const ComputeHandle* handle) {
   (void)handle;
   return false;
 #else
-  return kmx_handle_precision(handle->handle) != KMX_PREC_FP32;
+  return (handle->batcher != NULL ? kmx_batcher_precision(handle->batcher) : kmx_handle_precision(handle->handle)) != KMX_PREC_FP32;
 #endif
 }
 bool NeuralNet::setIsWarmup(const ComputeHandle* handle, bool isWarmup) {
@@ -335,13 +382,43 @@ void NeuralNet::getOutput(
       buffers->score.data(), buffers->outOwnership.data(), 1),
     "evaluating batch");
 #else
-  check(
-    kmx_eval_meta(
-      handle->handle, batchSize, buffers->rowSpatial.data(), buffers->rowGlobal.data(),
-      handle->numInputMetaChannels > 0 ? buffers->rowMeta.data() : NULL, buffers->symmetry.data(),
-      buffers->policyOptimism.data(), buffers->outPolicy.data(), buffers->value.data(), buffers->score.data(),
-      buffers->outOwnership.data()),
-    "evaluating batch");
+  if(handle->batcher != NULL) {
+    // the rows join whatever batch is filling (other server threads' rows included); every ticket is waited for even after a
+    // failure, so that no staging slot stays occupied
+    buffers->tickets.resize(batchSize);
+    int firstError = KMX_OK;
+    string firstMessage;
+    int submitted = 0;
+    for(; submitted < batchSize; submitted++) {
+      int rc = kmx_batcher_submit(
+        handle->batcher, buffers->rowSpatial[submitted], buffers->rowGlobal[submitted],
+        handle->numInputMetaChannels > 0 ? buffers->rowMeta[submitted] : NULL, buffers->symmetry[submitted],
+        buffers->policyOptimism[submitted], buffers->outPolicy[submitted], buffers->value.data() + (size_t)submitted * 3,
+        buffers->score.data() + (size_t)submitted * 6, buffers->outOwnership[submitted], &buffers->tickets[submitted]);
+      if(rc != KMX_OK) {
+        firstError = rc;
+        firstMessage = kmx_last_error();
+        break;
+      }
+    }
+    for(int row = 0; row < submitted; row++) {
+      int rc = kmx_batcher_wait(handle->batcher, buffers->tickets[row]);
+      if(rc != KMX_OK && firstError == KMX_OK) {
+        firstError = rc;
+        firstMessage = kmx_last_error();
+      }
+    }
+    if(firstError != KMX_OK)
+      throw StringError("katamx backend: evaluating batch through the leaf batcher: " + firstMessage);
+  }
+  else
+    check(
+      kmx_eval_meta(
+        handle->handle, batchSize, buffers->rowSpatial.data(), buffers->rowGlobal.data(),
+        handle->numInputMetaChannels > 0 ? buffers->rowMeta.data() : NULL, buffers->symmetry.data(),
+        buffers->policyOptimism.data(), buffers->outPolicy.data(), buffers->value.data(), buffers->score.data(),
+        buffers->outOwnership.data()),
+      "evaluating batch");
 #endif
 
   // Scalars -> NNOutput, exactly the field mapping of eigenbackend.cpp:2569-2626.

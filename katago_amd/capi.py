@@ -109,9 +109,10 @@ SIGNATURES = {
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "kmx_batcher_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "kmx_batcher_free": (None, [ctypes.c_void_p]),
-    "kmx_batcher_submit": (ctypes.c_int, [ctypes.c_void_p, _FP, _FP, _FP, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]),
-    "kmx_batcher_wait": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, _FP, _FP, _FP, _FP]),
+    "kmx_batcher_submit": (ctypes.c_int, [ctypes.c_void_p, _FP, _FP, _FP, ctypes.c_int, ctypes.c_float, _FP, _FP, _FP, _FP, ctypes.POINTER(ctypes.c_uint64)]),
+    "kmx_batcher_wait": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64]),
     "kmx_batcher_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
+    "kmx_batcher_precision": (ctypes.c_int, [ctypes.c_void_p]),
     "kmx_handle_stream": (ctypes.c_void_p, [ctypes.c_void_p]),
     "kmx_handle_sync": (ctypes.c_int, [ctypes.c_void_p]),
     "kmx_handle_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),

@@ -6,13 +6,16 @@
 //   * kmx_batcher_submit is called by the SEARCH thread that owns the leaf. It reserves a row in the batch that is filling and
 //     bit-packs the row's feature planes straight into that batch's PINNED staging (1012 instead of 31768 bytes per 19x19 row;
 //     the reference's binaryInputNCHWPacked layout) — in parallel with the other submitters, outside the lock.
-//   * a dispatcher thread seals the filling batch as soon as the device has room (at most `max_in_flight` batches between H2D
-//     and D2H) and enqueues H2D -> schedule -> D2H asynchronously on that slot's own engine and stream: greedy, like
-//     waitPopUpToN — it never waits for more rows once one is waiting and the device can take it — but with several batches
-//     in flight, so H2D of batch k+1, the kernels of batch k and D2H of batch k-1 overlap, and rows that arrive while the
-//     device is busy accumulate into the next batch instead of queueing behind a synchronous call.
-//   * a completion thread waits for each batch's event and wakes exactly the threads whose rows were in it.
-//   * kmx_batcher_wait copies the row's results out of pinned memory.
+//   * a dispatcher thread seals the filling batch when the device is idle (greedy like waitPopUpToN: it never waits for more
+//     rows once one is waiting and the device has nothing to do) or when it is full (then up to `max_in_flight` batches are
+//     between H2D and D2H, each on its own engine and stream, so that H2D of batch k+1, the kernels of batch k and D2H of
+//     batch k-1 overlap); rows that arrive while the device is busy accumulate into the next batch instead of queueing
+//     behind a synchronous call.
+//   * a completion thread waits for each batch's event, copies every row's results out of pinned memory into the buffers its
+//     submitter named, frees the staging set and wakes exactly the threads whose rows were in it. A staging set is therefore
+//     never held by uncollected results: a thread with several tickets outstanding (a server thread that submitted a whole
+//     batch, a search thread with several leaves) can always submit more - submit() only ever waits for the DEVICE.
+//   * kmx_batcher_wait blocks until the ticket's row is done.
 // Rows/batches counters have the meaning of nneval.cpp:712-713. Rows never interact, so a row's outputs are bit-identical to
 // the same row through kmx_eval, whatever batch it lands in (tests/test_gpu_batcher.py).
 #include <hip/hip_runtime.h>
@@ -21,6 +24,9 @@
 #include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <map>
+#include <memory>
+#include <string>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -69,6 +75,7 @@ class Batcher {
       s.eng.reset(new Engine(model, nnXLen, nnYLen, maxBatch, dtype, device));
       s.sym.resize(maxBatch);
       s.opt.resize(maxBatch);
+      s.rows.resize(maxBatch);
     }
     cin_ = slots_[0].eng->numInputChannels();
     gin_ = slots_[0].eng->numInputGlobalChannels();
@@ -85,19 +92,20 @@ class Batcher {
     cvWork_.notify_all();
     cvComplete_.notify_all();
     cvFree_.notify_all();
-    for(Slot& s : slots_) s.cvDone.notify_all();
     if(dispatcher_.joinable()) dispatcher_.join();
     if(completer_.joinable()) completer_.join();
   }
 
-  uint64_t submit(const float* rowSpatial, const float* rowGlobal, const float* rowMeta, int symmetry, float optimism, bool wantOwnership) {
+  uint64_t submit(const float* rowSpatial, const float* rowGlobal, const float* rowMeta, int symmetry, float optimism, float* outPolicy,
+                  float* outValue, float* outScore, float* outOwnership) {
     if(!rowSpatial || !rowGlobal) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_submit: null row");
+    if(!outPolicy || !outValue || !outScore) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_submit: null output");
     if(symmetry < 0 || symmetry > 7) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_submit: symmetry must be in 0..7");
     if((min_ > 0) != (rowMeta != nullptr))
       throw Error(KMX_ERR_INVALID_ARG, min_ > 0 ? "this net has an sgf-metadata encoder: rows need the metadata input"
                                                 : "this net has no sgf-metadata encoder: the metadata input must be NULL");
     int si, r;
-    uint32_t gen;
+    uint64_t ticket;
     {
       std::unique_lock<std::mutex> l(mu_);
       for(;;) {
@@ -106,7 +114,7 @@ class Batcher {
           int f = -1;
           for(size_t i = 0; i < slots_.size(); i++)
             if(slots_[i].state == FREE) { f = (int)i; break; }
-          if(f < 0) {  // every staging set is filling, in flight or waiting to be collected
+          if(f < 0) {  // every staging set is filling, sealed or on the device
             cvFree_.wait(l);
             continue;
           }
@@ -114,19 +122,19 @@ class Batcher {
           s.state = FILLING;
           s.count = 0;
           s.copied.store(0, std::memory_order_relaxed);
-          s.collected = 0;
           s.anyOwner = false;
-          s.error = KMX_OK;
-          s.gen++;
           filling_ = f;
         }
         Slot& s = slots_[filling_];
         si = filling_;
         r = s.count++;
-        gen = s.gen;
+        ticket = nextTicket_++;
         s.sym[r] = symmetry;
         s.opt[r] = optimism;
-        s.anyOwner = s.anyOwner || wantOwnership;
+        s.anyOwner = s.anyOwner || outOwnership != nullptr;
+        Pending& p = pending_[ticket];
+        p.slot = si;
+        s.rows[r] = RowOut{ticket, outPolicy, outValue, outScore, outOwnership};
         if(s.count == maxBatch_) {  // full: no further reservations, the next row opens a new batch
           s.state = SEALED;
           sealed_.push_back(filling_);
@@ -143,39 +151,20 @@ class Batcher {
     if(min_ > 0) memcpy(s.eng->stagedMetaRow(r), rowMeta, (size_t)min_ * sizeof(float));
     if(!binary) s.nonBinary.store(true, std::memory_order_relaxed);
     s.copied.fetch_add(1, std::memory_order_release);
-    return ((uint64_t)gen << 32) | ((uint64_t)si << 16) | (uint64_t)r;
+    return ticket;
   }
 
-  void wait(uint64_t ticket, float* outPolicy, float* outValue, float* outScore, float* outOwnership) {
-    const uint32_t gen = (uint32_t)(ticket >> 32);
-    const int si = (int)((ticket >> 16) & 0xffff), r = (int)(ticket & 0xffff);
-    if(si < 0 || si >= (int)slots_.size() || !outPolicy || !outValue || !outScore) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_wait: bad ticket or null output");
-    Slot& s = slots_[si];
+  void wait(uint64_t ticket) {
     int err;
-    {
-      std::unique_lock<std::mutex> l(mu_);
-      if(s.gen != gen || r >= s.count || s.state == FREE) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_wait: stale ticket (already collected?)");
-      while(s.state != DONE) s.cvDone.wait(l);  // on shutdown the dispatcher fails the batches it will not launch
-      err = s.error;
-      if(err == KMX_OK && outOwnership && !s.anyOwner) {
-        err = KMX_ERR_INVALID_ARG;  // still counts as collected below
-        s.errorMsg = "kmx_batcher_wait: ownership requested for a batch in which no row was submitted with want_ownership";
-      }
-    }
-    if(err == KMX_OK) {
-      memcpy(outPolicy, s.eng->stagedPolicy(r), (size_t)(S_ + 1) * sizeof(float));
-      memcpy(outValue, s.eng->stagedValue(r), 3 * sizeof(float));
-      memcpy(outScore, s.eng->stagedScore(r), 6 * sizeof(float));
-      if(outOwnership) memcpy(outOwnership, s.eng->stagedOwnership(r), (size_t)S_ * sizeof(float));
-    }
     std::string msg;
     {
-      std::lock_guard<std::mutex> l(mu_);
-      if(err != KMX_OK) msg = s.errorMsg;
-      if(++s.collected == s.count) {
-        s.state = FREE;
-        cvFree_.notify_all();
-      }
+      std::unique_lock<std::mutex> l(mu_);
+      auto it = pending_.find(ticket);
+      if(it == pending_.end()) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_wait: unknown ticket (already waited for?)");
+      while(!it->second.done) slots_[it->second.slot].cvDone.wait(l);  // (std::map: the element stays where it is while other tickets come and go)
+      err = it->second.error;
+      if(err != KMX_OK) msg = *it->second.message;
+      pending_.erase(it);
     }
     if(err != KMX_OK) throw Error(err, msg);
   }
@@ -188,38 +177,59 @@ class Batcher {
   int numInputMetaChannels() const { return min_; }
 
  private:
-  enum State { FREE, FILLING, SEALED, RUNNING, DONE };
+  enum State { FREE, FILLING, SEALED, RUNNING };
+  struct RowOut {
+    uint64_t ticket;
+    float *policy, *value, *score, *ownership;
+  };
   struct Slot {
     std::unique_ptr<Engine> eng;
     State state = FREE;
     int count = 0;                 // rows reserved
     std::atomic<int> copied{0};    // rows staged
     std::atomic<bool> nonBinary{false};
-    int collected = 0;             // rows whose results were taken
-    uint32_t gen = 0;
     bool anyOwner = false;
     std::vector<int> sym;
     std::vector<float> opt;
+    std::vector<RowOut> rows;      // where each row's results go
     int error = KMX_OK;
     std::string errorMsg;
-    std::condition_variable cvDone;
+    std::condition_variable cvDone;  // the waiters of the rows that were in this set
   };
+  struct Pending {  // one per ticket, from submit to wait
+    int slot = -1;
+    bool done = false;
+    int error = KMX_OK;
+    std::shared_ptr<const std::string> message;  // shared by the rows of a failed batch
+  };
+  // finishes the rows of a set (lock held): marks their tickets, frees the set, wakes its waiters and one blocked submitter
+  void finishSlot(Slot& s, int err, const std::string& msg) {
+    std::shared_ptr<const std::string> m = err != KMX_OK ? std::make_shared<const std::string>(msg) : nullptr;
+    for(int r = 0; r < s.count; r++) {
+      auto it = pending_.find(s.rows[r].ticket);
+      if(it == pending_.end()) continue;
+      it->second.done = true;
+      it->second.error = err;
+      it->second.message = m;
+    }
+    s.state = FREE;
+    s.cvDone.notify_all();
+    cvFree_.notify_all();
+  }
 
   void dispatchLoop() {
     std::unique_lock<std::mutex> l(mu_);
     for(;;) {
+      // A FULL batch goes as soon as fewer than max_in_flight are on the device. A partial batch goes only when the device
+      // is idle: while a batch runs, arriving rows accumulate into the next one (sealing them at once - the reference's
+      // greedy rule applied per in-flight slot - produces many small batches that share the device inefficiently; measured
+      // with the reference's benchmark, 4 server threads: avg 45 rows per batch).
       cvWork_.wait(l, [&] {
-        return closing_ || (running_ < maxInFlight_ && (!sealed_.empty() || (filling_ >= 0 && slots_[filling_].count > 0)));
+        return closing_ || (running_ < maxInFlight_ && !sealed_.empty()) || (running_ == 0 && filling_ >= 0 && slots_[filling_].count > 0);
       });
       if(closing_) {
         // rows that were never launched: fail their waiters
-        auto fail = [&](int i) {
-          Slot& s = slots_[i];
-          s.error = KMX_ERR_INTERNAL;
-          s.errorMsg = "the batcher shut down before this row was evaluated";
-          s.state = DONE;
-          s.cvDone.notify_all();
-        };
+        auto fail = [&](int i) { finishSlot(slots_[i], KMX_ERR_INTERNAL, "the batcher shut down before this row was evaluated"); };
         for(int i : sealed_) fail(i);
         sealed_.clear();
         if(filling_ >= 0) {
@@ -271,25 +281,30 @@ class Batcher {
       inflight_.pop_front();
       Slot& s = slots_[si];
       l.unlock();
-      int err = KMX_OK;
-      std::string msg;
-      if(s.error == KMX_OK) {
-        try { s.eng->sync(); }
+      int err = s.error;
+      std::string msg = s.errorMsg;
+      if(err == KMX_OK) {
+        try {
+          s.eng->sync();
+          // results -> the buffers the submitters named (they stay valid until kmx_batcher_wait returns)
+          for(int r = 0; r < s.count; r++) {
+            const RowOut& o = s.rows[r];
+            memcpy(o.policy, s.eng->stagedPolicy(r), (size_t)(S_ + 1) * sizeof(float));
+            memcpy(o.value, s.eng->stagedValue(r), 3 * sizeof(float));
+            memcpy(o.score, s.eng->stagedScore(r), 6 * sizeof(float));
+            if(o.ownership) memcpy(o.ownership, s.eng->stagedOwnership(r), (size_t)S_ * sizeof(float));
+          }
+        }
         catch(const Error& e) { err = e.code; msg = e.what(); }
         catch(const std::exception& e) { err = KMX_ERR_INTERNAL; msg = e.what(); }
       }
       l.lock();
-      if(err != KMX_OK) {
-        s.error = err;
-        s.errorMsg = msg;
-      }
-      if(s.error == KMX_OK) {
+      if(err == KMX_OK) {
         rows_ += (uint64_t)s.count;
         batches_ += 1;
       }
-      s.state = DONE;
+      finishSlot(s, err, msg);
       running_--;
-      s.cvDone.notify_all();
       cvWork_.notify_one();
     }
   }
@@ -301,6 +316,9 @@ class Batcher {
   std::deque<int> sealed_, inflight_;
   int filling_ = -1, running_ = 0;
   bool closing_ = false;
+  uint64_t nextTicket_ = 1;
+  // node-based map: references to its elements stay valid while other tickets come and go (a waiter sleeps holding one)
+  std::map<uint64_t, Pending> pending_;
   uint64_t rows_ = 0, batches_ = 0;
   std::thread dispatcher_, completer_;
 };
@@ -311,6 +329,7 @@ using namespace kmx;
 
 struct kmx_batcher {
   std::unique_ptr<Batcher> b;
+  int precision = KMX_PREC_BF16;
 };
 
 // shared with kmx_api.cpp
@@ -339,25 +358,28 @@ int kmx_batcher_create(kmx_context* ctx, const kmx_model* model, int max_batch_s
     apiContextDims(ctx, &x, &y);
     std::unique_ptr<kmx_batcher> h(new kmx_batcher());
     // staging sets: the ones on the device, one filling, one being collected by its waiters
-    h->b.reset(new Batcher(apiModelDesc(model), x, y, max_batch_size, apiDtypeFor(ctx, model), dev, max_in_flight, max_in_flight + 2));
+    const int dtype = apiDtypeFor(ctx, model);
+    h->precision = dtype == DT_F16 ? KMX_PREC_FP16 : KMX_PREC_BF16;
+    h->b.reset(new Batcher(apiModelDesc(model), x, y, max_batch_size, dtype, dev, max_in_flight, max_in_flight + 2));
     *out = h.release();
   });
 }
 void kmx_batcher_free(kmx_batcher* b) { delete b; }
 
 int kmx_batcher_submit(kmx_batcher* b, const float* row_spatial, const float* row_global, const float* row_meta, int symmetry,
-                       float policy_optimism, int want_ownership, uint64_t* ticket) {
+                       float policy_optimism, float* out_policy, float* out_value, float* out_score, float* out_ownership, uint64_t* ticket) {
   return apiGuarded([&] {
     if(!b || !ticket) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_submit: null argument");
-    *ticket = b->b->submit(row_spatial, row_global, row_meta, symmetry, policy_optimism, want_ownership != 0);
+    *ticket = b->b->submit(row_spatial, row_global, row_meta, symmetry, policy_optimism, out_policy, out_value, out_score, out_ownership);
   });
 }
-int kmx_batcher_wait(kmx_batcher* b, uint64_t ticket, float* out_policy, float* out_value, float* out_score, float* out_ownership) {
+int kmx_batcher_wait(kmx_batcher* b, uint64_t ticket) {
   return apiGuarded([&] {
     if(!b) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_wait: null batcher");
-    b->b->wait(ticket, out_policy, out_value, out_score, out_ownership);
+    b->b->wait(ticket);
   });
 }
+int kmx_batcher_precision(const kmx_batcher* b) { return b ? b->precision : KMX_PREC_AUTO; }
 int kmx_batcher_stats(kmx_batcher* b, uint64_t* rows, uint64_t* batches) {
   if(!b) return apiSetError(KMX_ERR_INVALID_ARG, "kmx_batcher_stats: null batcher");
   b->b->stats(rows, batches);

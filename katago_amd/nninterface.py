@@ -12,6 +12,7 @@ reference throws StringError), so that the parity tests read like the reference'
 This file is host plumbing for tests and bench.py; the product is the C ABI underneath it.
 """
 import ctypes
+import threading
 
 import numpy as np
 
@@ -270,6 +271,60 @@ def getOutputDevice(handle, dSpatial, dGlobal, symmetries, policyOptimisms, dPol
     opt = np.ascontiguousarray(policyOptimisms if policyOptimisms is not None else np.zeros(n), dtype=np.float32)
     capi.check(handle._lib.kmx_eval_device(handle._p, n, dSpatial, dGlobal, sym.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _fp(opt),
                                            dPolicy, dValue, dScore, dOwnership, 1 if sync else 0), handle._lib)
+
+
+class Batcher:
+    """kmx_batcher_*: the persistent leaf batcher (include/katamx.h). The role of NNEvaluator's server half (nneval.cpp:562-752)
+    for callers that submit rows themselves: submit() from any thread returns a ticket, wait(ticket) returns that row's outputs.
+    Rows are bit-packed into pinned staging by their submitters, batches are sealed greedily and up to max_in_flight of them
+    are on the device at once. A thread may hold any number of tickets."""
+
+    def __init__(self, context, model, maxBatchSize, maxInFlight=2, gpuIdx=0):
+        self._lib = capi.load_library()
+        self.context, self.model = context, model
+        self._p = ctypes.c_void_p()
+        capi.check(self._lib.kmx_batcher_create(context._p, model._p, maxBatchSize, maxInFlight, gpuIdx, ctypes.byref(self._p)), self._lib)
+        self.S = context.nnXLen * context.nnYLen
+        self._out = {}
+        self._lock = threading.Lock()
+
+    def close(self):
+        if self._p:
+            self._lib.kmx_batcher_free(self._p)
+            self._p = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def submit(self, rowSpatial, rowGlobal, symmetry=0, policyOptimism=0.0, wantOwnership=True, rowMeta=None):
+        """Returns a ticket. The row's output arrays are allocated here (the library writes into them) and handed out by wait()."""
+        sp = np.ascontiguousarray(rowSpatial, dtype=np.float32)
+        gl = np.ascontiguousarray(rowGlobal, dtype=np.float32)
+        mt = None if rowMeta is None else np.ascontiguousarray(rowMeta, dtype=np.float32)
+        out = {"policy": np.empty(self.S + 1, np.float32), "value": np.empty(3, np.float32), "score": np.empty(6, np.float32),
+               "ownership": np.empty(self.S, np.float32) if wantOwnership else None}
+        t = ctypes.c_uint64()
+        capi.check(self._lib.kmx_batcher_submit(self._p, _fp(sp), _fp(gl), None if mt is None else _fp(mt), int(symmetry), float(policyOptimism),
+                                                _fp(out["policy"]), _fp(out["value"]), _fp(out["score"]),
+                                                None if out["ownership"] is None else _fp(out["ownership"]), ctypes.byref(t)), self._lib)
+        with self._lock:
+            self._out[t.value] = out
+        return t.value
+
+    def wait(self, ticket):
+        rc = self._lib.kmx_batcher_wait(self._p, ticket)
+        with self._lock:
+            out = self._out.pop(ticket, None)
+        capi.check(rc, self._lib)
+        return out
+
+    def stats(self):
+        r, b = ctypes.c_uint64(), ctypes.c_uint64()
+        capi.check(self._lib.kmx_batcher_stats(self._p, ctypes.byref(r), ctypes.byref(b)), self._lib)
+        return r.value, b.value
 
 
 # ---- layer test hooks (nninterface.h:134-180) ------------------------------------------------------

@@ -92,6 +92,71 @@ def api_variants(ctx):
     }
 
 
+def batcher_case(ctx):
+    """The persistent leaf batcher (kmx_batcher_*): rows submitted from several threads come back bit-identical to kmx_eval on the
+    same rows, whatever batch they land in; counters; a non-binary plane fails its batch with KMX_ERR_INVALID_ARG."""
+    import threading
+    p = os.path.join(os.environ.get("TMPDIR", "/tmp"), "kmx_emu_batcher.bin")
+    modelgen.write_model(p, "b2c32nbt", seed=6)
+    rng = np.random.default_rng(10)
+    n = 10
+    sp, gl = make_rows(rng, n, 19, [(19, 19), (13, 9), (9, 9), (19, 19), (7, 7)] * 2)
+    sym = (np.arange(n) % 8).astype(np.int32)
+    opt = np.linspace(0.0, 1.0, n).astype(np.float32)
+    model = nn.loadModelFile(p)
+    h = nn.createComputeHandle(ctx, model, n)
+    base = nn.getOutput(h, sp, gl, sym, opt)
+    h.close()
+    b = nn.Batcher(ctx, model, 4, maxInFlight=2)
+    got = [None] * n
+
+    def worker(i0):
+        for i in range(i0, n, 3):
+            t = b.submit(sp[i], gl[i], sym[i], opt[i], True)
+            got[i] = b.wait(t)
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    rows, batches = b.stats()
+    keys = ("policy", "value", "score", "ownership")
+    equal = bool(all(np.array_equal(base[k][i], got[i][k]) for k in keys for i in range(n)))
+    bad = sp[0].copy()
+    bad[5, 3] = 0.5
+    t = b.submit(bad, gl[0], 0, 0.0, True)
+    err = ""
+    try:
+        b.wait(t)
+    except Exception as e:  # KatamxError
+        err = str(e)
+    t = b.submit(sp[1], gl[1], sym[1], opt[1], False)  # the batcher keeps working after a failed batch
+    again = b.wait(t)
+    b.close()
+    # more tickets outstanding than the staging sets can hold (3 sets x 2 rows < 10 rows): every thread submits ALL its rows
+    # before it waits for the first, as a server thread of the reference's NNEvaluator does with the batch it popped
+    b2 = nn.Batcher(ctx, model, 2, maxInFlight=1)
+    got2 = [None] * n
+
+    def greedy(i0):
+        tickets = [(i, b2.submit(sp[i], gl[i], sym[i], opt[i], True)) for i in range(i0, n, 2)]
+        for i, t in tickets:
+            got2[i] = b2.wait(t)
+
+    th = [threading.Thread(target=greedy, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    hung = any(t.is_alive() for t in th)
+    equal2 = (not hung) and bool(all(np.array_equal(base[k][i], got2[i][k]) for k in keys for i in range(n)))
+    if not hung:
+        b2.close()
+    return {"equal": equal, "rows": int(rows), "batches": int(batches), "error": err, "many_tickets_equal": equal2,
+            "after_error_equal": bool(all(np.array_equal(base[k][1], again[k]) for k in ("policy", "value", "score")))}
+
+
 def main():
     nn.globalInitialize()
     out = {}
@@ -100,6 +165,9 @@ def main():
         ctx = nn.createComputeContext([0], 19, 19, precision=dtype)
         if what == "api_variants":
             out[case] = api_variants(ctx)
+            continue
+        if what == "batcher":
+            out[case] = batcher_case(ctx)
             continue
         if what.split("@")[0] in ("torch_nbt", "torch_tfa", "torch_tfb"):
             name, _, rows = what.partition("@")  # torch_tfa@2 = row 2 only

@@ -223,6 +223,16 @@ def test_entry_point_variants_emulated(emu_lib):
     assert res["stats"] == [7 + 7 + 1, 3, 7 + 3, 2], res
 
 
+def test_leaf_batcher_emulated(emu_lib):
+    """kmx_batcher_*: three submitter threads, batches of at most 4 rows, two in flight - every row bit-identical to kmx_eval;
+    rows/batches counters; a non-binary feature plane fails that batch only."""
+    res = run_cases(emu_lib, ["bf16:batcher"])["bf16:batcher"]
+    assert res["equal"] and res["after_error_equal"], res
+    assert res["many_tickets_equal"], res  # threads that hold more tickets than the staging sets have rows must not dead-lock
+    assert res["rows"] == 10 and 3 <= res["batches"] <= 10, res
+    assert "0 or 1" in res["error"], res
+
+
 def test_transformer_nets_emulated(emu_lib):
     """The transformer device path against the reference PyTorch goldens: attention + SwiGLU FFN trunk with fixed RoPE and a
     per-cell RMSNorm tip (tfa); grouped-query attention, learnable RoPE, a nested transformer bottleneck beside a

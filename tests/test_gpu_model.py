@@ -240,3 +240,33 @@ def test_packed_input_rows_bit_exact(ctx19, model_dir):
         for k in a:
             assert np.array_equal(a[k], b[k]), (n, k)
     h.close()
+
+
+@pytest.mark.parametrize("arch", ["b28c512nbt", "b40c256"])
+def test_large_nets_of_the_analysis_config(ctx19, model_dir, arch):
+    """BASELINE configs[3]: b28c512nbt / b40c256 (random weights), bf16, batch 512 (cpp/configs/analysis_example.cfg:95-132).
+    (a) 8 rows - full and small boards, symmetries - against the oracle at the 16-bit tolerance of the deep nets;
+    (b) a 512-row batch on a handle created for 512 rows (split over two engines, the 8-wave x 128/192-channel convolution
+        shapes at full batch) reproduces, bit for bit, the same rows evaluated 16 at a time; counters add up."""
+    p = os.path.join(model_dir, "big_%s.bin.gz" % arch)
+    if not os.path.exists(p):
+        modelgen.write_model(p, arch, seed=28)
+    rng = np.random.default_rng(28)
+    n = 512
+    sizes = ([(19, 19)] * 5 + [(13, 13), (9, 9), (19, 10)]) * (n // 8)
+    sp, gl = make_rows(rng, n, 19, sizes)
+    sym = rng.integers(0, 8, n).astype(np.int32)
+    opt = rng.random(n).astype(np.float32)
+    model = nn.loadModelFile(p)
+    h = nn.createComputeHandle(ctx19["bf16"], model, 512)
+    big = nn.getOutput(h, sp, gl, sym, opt)
+    want = oracle_outputs(("big", arch), p, sp[:8], gl[:8], sym[:8], opt[:8])
+    small = {k: v[:8] for k, v in big.items()}
+    assert outputs_close(small, want, sp[:8, :, 0] > 0, 0.05, 0.2)
+    for i in (0, 16, 240, 496):
+        part = nn.getOutput(h, sp[i:i + 16], gl[i:i + 16], sym[i:i + 16], opt[i:i + 16])
+        for k in part:
+            assert np.array_equal(part[k], big[k][i:i + 16]), (arch, i, k)
+    assert h.stats() == (512 + 64, 5)
+    assert all(np.isfinite(v).all() for v in big.values())
+    h.close()
