@@ -230,6 +230,15 @@ def main():
             callp()
         host_packed_rate = args.steps * B / (time.perf_counter() - th)
 
+    # What this box gives: the convolution's step shape (18 MFMAs per wave and step, its LDS reads and its barrier) without any
+    # memory traffic, and the shader clock observed during it. Whole-net numbers vary by ~20 % between gpurun boxes; this line
+    # says which kind of box a number came from.
+    box = None
+    if rank == 0:
+        ms_, tf_, mhz_ = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        if lib.kmx_bench_mfma(8, 256, 3, 540, 10, ctypes.byref(ms_), ctypes.byref(tf_), ctypes.byref(mhz_)) == 0:
+            box = {"mfma_lds_barrier_loop_tflops": round(tf_.value, 1), "shader_mhz_during_it": round(mhz_.value)}
+
     roofline = None
     if prof_entries:
         total_ms = sum(v[1] for v in prof_entries.values())
@@ -250,12 +259,14 @@ def main():
         out = {
             "metric": "nn_evals_per_s", "value": round(value, 1), "unit": "evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic positions (SURVEY 8d recipe) on random-init weights of the named architecture (no trained b18c384nbt is available offline)",
             "config": {"workload": "%s 19x19 random weights, batch %d per GPU, NeuralNet::getOutput pass (device-resident inputs)" % (args.model, B),
                        "gflop_per_eval": round(flops_eval / 1e9, 3), "parallelism": "replicas x%d" % world,
                        "whole_net_tflops": round(value * flops_eval / 1e12, 1),
                        "whole_net_frac_of_mfma_peak": round(value * flops_eval / 1e12 / (MFMA_PEAK_TFLOPS[args.dtype] * world), 4)},
             "roofline": roofline,
+            "box": box,
         }
         if host_rate is not None:
             out["host_buffer_evals_per_s"] = round(host_rate, 1)

@@ -48,3 +48,38 @@ def test_selfplay_writes_shards_on_hip(tmp_path):
             gt = z["globalTargetsNC"]
             assert np.all(np.isfinite(gt)) and np.all(np.abs(gt[:, 0:3].sum(axis=1) - 1.0) < 1e-5)
     assert total == rows
+
+
+def test_selfplay_rate_b18_19x19_on_hip(tmp_path):
+    """The second half of BASELINE's metric: games/hour = "Total games" * 3600 / "Total selfplay runtime (seconds)"
+    (command/selfplay.cpp:388-389) for b18c384nbt (random weights) on 19x19 through the reference's `selfplay` on the HIP
+    backend - BASELINE configs[2]'s 8 parallel games per GPU, and 128 game threads (batches the device can use). Games are
+    capped at 60 moves and 32 / 16 visits so that the test takes seconds: what is recorded (gpurun_out/, copied to profiles/)
+    is the rate AT THAT SETTING together with the NN rows per second it implies - not a full-length self-play figure."""
+    from katago_amd import modelgen
+
+    b = ref_binary("katago_hip")
+    d = str(tmp_path)
+    os.makedirs(os.path.join(d, "models"))
+    modelgen.write_model(os.path.join(d, "models", "b18c384nbt-s1-d1.bin.gz"), "b18c384nbt", seed=7)
+    lines = []
+    for threads in (8, 128):
+        out = os.path.join(d, "out%d" % threads)
+        over = ("numGameThreads=%d,nnMaxBatchSize=%d,dataBoardLen=19,bSizes=19,bSizeRelProbs=1,maxMovesPerGame=60,maxVisits=32,"
+                "cheapSearchVisits=16,reducedVisitsMin=16,maxRowsPerTrainFile=20000,maxDataQueueSize=2000,nnCacheSizePowerOfTwo=18,"
+                "nnMutexPoolSizePowerOfTwo=14,logGamesEvery=1000" % (threads, max(threads, 8)))
+        p = subprocess.run([b, "selfplay", "-config", CFG, "-models-dir", os.path.join(d, "models"), "-output-dir", out,
+                            "-max-games-total", str(threads), "-override-config", over], capture_output=True, text=True, timeout=600, cwd=d)
+        log = p.stdout + p.stderr
+        assert p.returncode == 0 and "All cleaned up, quitting" in log, log[-3000:]
+        games = int(log.split("Total games: ")[1].split()[0])
+        secs = float(log.split("Total selfplay runtime (seconds): ")[1].split()[0])
+        nn_rows = int(log.split("Final NN rows: ")[1].split()[0])
+        assert games >= threads and secs > 0 and nn_rows > 0
+        lines.append("b18c384nbt 19x19 selfplay, %3d game threads, <=60 moves, 32/16 visits: %d games in %.1f s = %.0f games/hour; %d NN rows = %.0f rows/s"
+                     % (threads, games, secs, games * 3600.0 / secs, nn_rows, nn_rows / secs))
+    print("\n".join(lines))
+    keep = os.path.join(REPO, "gpurun_out")
+    if os.path.isdir(keep):
+        with open(os.path.join(keep, "selfplay_rate_b18.txt"), "w") as f:
+            f.write("\n".join(lines) + "\n")
