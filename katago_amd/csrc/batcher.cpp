@@ -38,33 +38,6 @@
 
 namespace kmx {
 
-// One row of fp32 NHWC binary feature planes -> bit planes [C][ceil(S/8)], MSB first (packBits of
-// dataio/trainingwrite.cpp:314-337, plane by plane). Returns false if a value is neither 0 nor 1.
-bool packRowNHWC(const float* row, int S, int C, unsigned char* out) {
-  const int PB = (S + 7) / 8;
-  memset(out, 0, (size_t)C * PB);
-  bool binary = true;
-  for(int p = 0; p < S; p++) {
-    const float* cell = row + (size_t)p * C;
-    unsigned m = 0, bad = 0;
-    for(int c = 0; c < C; c++) {  // branch-free: which channels are set in this cell
-      uint32_t u;
-      memcpy(&u, cell + c, 4);
-      m |= (unsigned)(u != 0u) << c;
-      bad |= (unsigned)(u != 0u && u != 0x3f800000u);
-    }
-    binary = binary && bad == 0;
-    const int byte = p >> 3;
-    const unsigned char bit = (unsigned char)(1u << (7 - (p & 7)));
-    while(m) {
-      const int c = __builtin_ctz(m);
-      m &= m - 1;
-      out[(size_t)c * PB + byte] |= bit;
-    }
-  }
-  return binary;
-}
-
 class Batcher {
  public:
   Batcher(const ModelDesc& model, int nnXLen, int nnYLen, int maxBatch, int dtype, int device, int maxInFlight, int numSlots)

@@ -696,9 +696,15 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
         }
         V4 r, o;
 #pragma unroll
-        for(int i = 0; i < 4; i++) {
-          r[i] = TR::fromFloat(v[i]);
-          o[i] = TR::fromFloat(actK<KIND>(v[i] * sc[i] + bi[i]));
+        for(int i = 0; i < 4; i++) r[i] = TR::fromFloat(v[i]);
+#pragma unroll
+        for(int i = 0; i < 4; i += 2) {
+          f32x2 x;
+          x[0] = v[i] * sc[i] + bi[i];
+          x[1] = v[i + 1] * sc[i + 1] + bi[i + 1];
+          const f32x2 y = actK2<KIND>(x);
+          o[i] = TR::fromFloat(y[0]);
+          o[i + 1] = TR::fromFloat(y[1]);
         }
         rp[g] = __builtin_bit_cast(u32x2, r);
         op[g] = __builtin_bit_cast(u32x2, o);

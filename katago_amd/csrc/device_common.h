@@ -76,9 +76,8 @@ __device__ __forceinline__ void unpair(const u32x4 (&q)[2], u32x2 (&p)[4]) {
   }
 }
 
-// Activations in fp32. Mish follows the reference's form x*tanh(softplus(x)) with softplus linearised
-// above 20 (eigenbackend.cpp:754): tanh(log1p(e)) = (e^2+2e)/(e^2+2e+2), e = exp(min(x,20)); for x > 20
-// the tanh argument exceeds 20 and tanh saturates to exactly 1 in fp32, as does this rational form.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // min(x, c) as the single v_min_f32 it is on the hardware: fminf() makes the compiler canonicalise x first (a v_max_f32 x, x
 // per element, for signalling NaNs), and the epilogues evaluate this once per output value
 __device__ __forceinline__ float minPlain(float x, float c) {
@@ -90,11 +89,35 @@ __device__ __forceinline__ float minPlain(float x, float c) {
   return fminf(x, c);
 #endif
 }
+
+// Activations in fp32. Mish = x tanh(softplus(x)) with softplus linearised above 20 as in the reference
+// (eigenbackend.cpp:754). With u = 1 + e^min(x,20): tanh(log u) = (u^2 - 1) / (u^2 + 1), so
+//     mish(x) = x - 2x / (u^2 + 1)
+// - for x > 20 the quotient is below 1e-17 and the result is x exactly, as the saturated tanh gives. This form needs 5 plain
+// vector instructions per value where x n / (n + 2), n = e (e + 2) needed 8, and all of them pair up into the packed-fp32
+// instructions (v_pk_mul/add/fma_f32); the epilogues are bound by vector-ALU issue (~4 cycles per wave instruction), and the
+// activation is most of what they issue. The two transcendental instructions per value (v_exp_f32, v_rcp_f32, quarter rate)
+// become three per PAIR in actMish2: one reciprocal of the product serves both quotients (the product stays below 6e34).
+// Absolute error ~1e-7 |x| (the subtraction cancels for very negative x, where mish itself is below 1e-5): far inside the
+// 16-bit rounding of every output these feed.
 __device__ __forceinline__ float actMish(float x) {
-  // e = exp(min(x,20)) through the hardware base-2 exponential; n = e^2 + 2e; mish = x * n / (n + 2)
-  const float e = __builtin_amdgcn_exp2f(minPlain(x, 20.0f) * 1.4426950408889634f);
-  const float n = e * (e + 2.0f);
-  return x * n * __builtin_amdgcn_rcpf(n + 2.0f);  // v_rcp_f32 (1 ulp): outputs are rounded to 16 bits anyway
+  const float e = __builtin_amdgcn_exp2f(minPlain(x * 1.4426950408889634f, 20.0f * 1.4426950408889634f));
+  const float u = e + 1.0f;
+  return x + (-2.0f * x) * __builtin_amdgcn_rcpf(u * u + 1.0f);
+}
+__device__ __forceinline__ f32x2 actMish2(f32x2 x) {
+  const f32x2 tl = x * 1.4426950408889634f;
+  f32x2 e;
+  e[0] = __builtin_amdgcn_exp2f(minPlain(tl[0], 20.0f * 1.4426950408889634f));
+  e[1] = __builtin_amdgcn_exp2f(minPlain(tl[1], 20.0f * 1.4426950408889634f));
+  const f32x2 u = e + 1.0f;
+  const f32x2 q = u * u + 1.0f;
+  const float r = __builtin_amdgcn_rcpf(q[0] * q[1]);
+  f32x2 inv;
+  inv[0] = q[1];
+  inv[1] = q[0];
+  inv = inv * r;  // 1 / q[0], 1 / q[1]
+  return x + (x * -2.0f) * inv;
 }
 __device__ __forceinline__ float actSilu(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-x * 1.4426950408889634f));
@@ -116,6 +139,15 @@ template <int K>
 struct ActKindTag {
   static constexpr int value = K;
 };
+// the same on a pair of values (the mish pair shares a reciprocal)
+template <int KIND>
+__device__ __forceinline__ f32x2 actK2(f32x2 x) {
+  if(KIND == KMX_ACT_MISH) return actMish2(x);
+  f32x2 y;
+  y[0] = actK<KIND>(x[0]);
+  y[1] = actK<KIND>(x[1]);
+  return y;
+}
 template <class F>
 __device__ __forceinline__ void withActKind(int kind, F&& f) {
   if(kind == KMX_ACT_MISH) f(ActKindTag<KMX_ACT_MISH>());

@@ -160,6 +160,7 @@ void Engine::construct(const ModelDesc& model) {
   hipCheck(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
   if(const char* e = getenv("KMX_GRAPHS")) useGraphs_ = atoi(e) != 0;
   if(const char* e = getenv("KMX_FUSE_SEAMS")) fuseSeams_ = atoi(e) != 0;
+  if(const char* e = getenv("KMX_PACK_INPUTS")) packInputs_ = atoi(e) != 0;
   if(const char* e = getenv("KMX_FUSE_MIN_ROWS")) fuseMinRows_ = std::max(1, atoi(e));
   cin_ = model.numInputChannels;
   gin_ = model.numInputGlobalChannels;
@@ -902,6 +903,31 @@ void Engine::evalDevice(int n, const float* dSpatial, const float* dGlobal, cons
   if(doSync) sync();
 }
 
+bool packRowNHWC(const float* row, int S, int C, unsigned char* out) {
+  const int PB = (S + 7) / 8;
+  memset(out, 0, (size_t)C * PB);
+  bool binary = true;
+  for(int p = 0; p < S; p++) {
+    const float* cell = row + (size_t)p * C;
+    unsigned m = 0, bad = 0;
+    for(int c = 0; c < C; c++) {  // branch-free: which channels are set in this cell
+      uint32_t u;
+      memcpy(&u, cell + c, 4);
+      m |= (unsigned)(u != 0u) << c;
+      bad |= (unsigned)(u != 0u && u != 0x3f800000u);
+    }
+    binary = binary && bad == 0;
+    const int byte = p >> 3;
+    const unsigned char bit = (unsigned char)(1u << (7 - (p & 7)));
+    while(m) {
+      const int c = __builtin_ctz(m);
+      m &= m - 1;
+      out[(size_t)c * PB + byte] |= bit;
+    }
+  }
+  return binary;
+}
+
 void Engine::evalHostBegin(int n, const float* const* rowSpatial, const unsigned char* const* rowPacked,
                            const float* const* rowGlobal, const float* const* rowMeta, const int* symmetry,
                            const float* policyOptimism, float* const* outOwnership) {
@@ -910,12 +936,21 @@ void Engine::evalHostBegin(int n, const float* const* rowSpatial, const unsigned
   hipCheck(hipStreamSynchronize(stream_), "stream synchronize");  // the single-buffered row staging below
   const size_t rowElts = (size_t)S_ * cin_;
   const size_t rowBytes = (size_t)packedRowBytes();
+  // Opt-in (KMX_PACK_INPUTS=1, see engine.h for the measurement): fp32 rows of 0/1 feature planes (all V7 inputs are;
+  // nninputs.cpp:2288-2731) are bit-packed WHILE they are staged and cross PCIe as 1012 instead of 31768 bytes per 19x19 row
+  // (SURVEY 8f1). The device expands them to the same 16-bit image as fp32 rows (bit-identical, tested). A batch with any
+  // other value in a plane is staged as fp32 rows.
+  bool packedStaging = rowPacked != nullptr;
+  if(!rowPacked && cin_ <= 32 && packInputs_) {
+    packedStaging = true;
+    for(int i = 0; i < n && packedStaging; i++) packedStaging = packRowNHWC(rowSpatial[i], S_, cin_, hPacked_ + i * rowBytes);
+  }
   for(int i = 0; i < n; i++) {
     if(rowPacked) memcpy(hPacked_ + i * rowBytes, rowPacked[i], rowBytes);
-    else memcpy(hSpatial_ + i * rowElts, rowSpatial[i], rowElts * sizeof(float));
+    else if(!packedStaging) memcpy(hSpatial_ + i * rowElts, rowSpatial[i], rowElts * sizeof(float));
     memcpy(hGlobal_ + (size_t)i * gin_, rowGlobal[i], gin_ * sizeof(float));
   }
-  if(rowPacked) hipCheck(hipMemcpyAsync(dPackedIn_.get(), hPacked_, n * rowBytes, hipMemcpyHostToDevice, stream_), "H2D packed planes");
+  if(packedStaging) hipCheck(hipMemcpyAsync(dPackedIn_.get(), hPacked_, n * rowBytes, hipMemcpyHostToDevice, stream_), "H2D packed planes");
   else hipCheck(hipMemcpyAsync(dSpatialIn_.get(), hSpatial_, n * rowElts * sizeof(float), hipMemcpyHostToDevice, stream_), "H2D spatial");
   hipCheck(hipMemcpyAsync(dGlobalIn_.get(), hGlobal_, (size_t)n * gin_ * sizeof(float), hipMemcpyHostToDevice, stream_), "H2D global");
   if(min_ > 0 && rowMeta != nullptr) {
@@ -931,7 +966,7 @@ void Engine::evalHostBegin(int n, const float* const* rowSpatial, const unsigned
     for(int i = 0; i < n; i++) anyOwner = anyOwner || outOwnership[i] != nullptr;
   hostAnyOwner_ = anyOwner;
   stageRowParams(n, symmetry, policyOptimism);
-  runSchedule(n, rowPacked ? nullptr : dSpatialIn_.as<float>(), rowPacked ? dPackedIn_.as<unsigned char>() : nullptr,
+  runSchedule(n, packedStaging ? nullptr : dSpatialIn_.as<float>(), packedStaging ? dPackedIn_.as<unsigned char>() : nullptr,
               dGlobalIn_.as<float>(), (min_ > 0 && rowMeta) ? dMetaIn_.as<float>() : nullptr,
               dPolicy_.as<float>(), dValue_.as<float>(), dScore_.as<float>(), anyOwner ? dOwnership_.as<float>() : nullptr);
   hipCheck(hipMemcpyAsync(hPolicy_, dPolicy_.get(), (size_t)n * (S_ + 1) * sizeof(float), hipMemcpyDeviceToHost, stream_), "D2H policy");

@@ -199,6 +199,9 @@ class Engine {
   bool hostAnyOwner_ = false;
   int cfgScale_ = 1;
   bool fuseSeams_ = true;   // KMX_FUSE_SEAMS=0: always the two convolution launches
+  bool packInputs_ = false;  // KMX_PACK_INPUTS=1: kmx_eval bit-packs 0/1 planes while staging. Off: measured on MI355X (b18c384nbt, batch 256,
+                            // synchronous host entry) 32.9 k evals/s with it against 39.2 k without - the caller's thread packs while the GPU idles,
+                            // and that costs more than the 0.3 ms of PCIe it saves; the batcher packs on the submitters' threads instead
   int fuseMinRows_ = 24;    // KMX_FUSE_MIN_ROWS: smallest batch that takes the fused seam kernel
   int forkOps_ = 0;
   hipEvent_t forkEv_ = nullptr;
@@ -254,6 +257,10 @@ void testBnAct(int dtype, const kmx_bnact_desc* d, int batch, int X, int Y, cons
 void testResBlock(int dtype, const kmx_resblock_desc* d, int batch, int X, int Y, const float* in, const float* mask, float* out);
 void testGPoolBlock(int dtype, const kmx_gpoolblock_desc* d, int batch, int X, int Y, const float* in, const float* mask,
                     float* out);
+
+// One row of fp32 NHWC binary feature planes -> bit planes [C][ceil(S/8)], MSB first (packBits of dataio/trainingwrite.cpp:314-337,
+// plane by plane): the host half of row f1. Returns false if a value is neither 0 nor 1 (the row is then packed as garbage).
+bool packRowNHWC(const float* row, int S, int C, unsigned char* out);
 
 void testPointwisePair(int dtype, int batch, int X, int Y, int c1, int c2, int c3, const float* in, const float* resid, const float* w1,
                        const float* scale1, const float* bias1, int act1, const float* w2, const float* scale2, const float* bias2,

@@ -250,10 +250,16 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
         V4 r, o;
         const V4 rr = __builtin_bit_cast(V4, resP[g]);
 #pragma unroll
-        for(int i = 0; i < 4; i++) {
-          const float v = acc1[ct][pt][4 * g + i] + TR::toFloat(rr[i]);
-          r[i] = TR::fromFloat(v);
-          o[i] = TR::fromFloat(actK<KIND>(v * sc[i] + bi[i]));
+        for(int i = 0; i < 4; i += 2) {
+          const float v0 = acc1[ct][pt][4 * g + i] + TR::toFloat(rr[i]), v1 = acc1[ct][pt][4 * g + i + 1] + TR::toFloat(rr[i + 1]);
+          r[i] = TR::fromFloat(v0);
+          r[i + 1] = TR::fromFloat(v1);
+          f32x2 x;
+          x[0] = v0 * sc[i] + bi[i];
+          x[1] = v1 * sc[i + 1] + bi[i + 1];
+          const f32x2 y = actK2<KIND>(x);
+          o[i] = TR::fromFloat(y[0]);
+          o[i + 1] = TR::fromFloat(y[1]);
         }
         rp[g] = __builtin_bit_cast(u32x2, r);
         op[g] = __builtin_bit_cast(u32x2, o);
@@ -343,10 +349,16 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
         const f32x4 bi = *(const f32x4*)(bi2S + c);
         V4 r, o;
 #pragma unroll
-        for(int i = 0; i < 4; i++) {
-          const float v = acc2[ct][pt][4 * g + i];
-          r[i] = TR::fromFloat(v);
-          o[i] = TR::fromFloat(actK<KIND>(v * sc[i] + bi[i]));
+        for(int i = 0; i < 4; i += 2) {
+          const float v0 = acc2[ct][pt][4 * g + i], v1 = acc2[ct][pt][4 * g + i + 1];
+          r[i] = TR::fromFloat(v0);
+          r[i + 1] = TR::fromFloat(v1);
+          f32x2 x;
+          x[0] = v0 * sc[i] + bi[i];
+          x[1] = v1 * sc[i + 1] + bi[i + 1];
+          const f32x2 y = actK2<KIND>(x);
+          o[i] = TR::fromFloat(y[0]);
+          o[i + 1] = TR::fromFloat(y[1]);
         }
         rp[g] = __builtin_bit_cast(u32x2, r);
         op[g] = __builtin_bit_cast(u32x2, o);

@@ -262,7 +262,9 @@ def test_large_nets_of_the_analysis_config(ctx19, model_dir, arch):
     big = nn.getOutput(h, sp, gl, sym, opt)
     want = oracle_outputs(("big", arch), p, sp[:8], gl[:8], sym[:8], opt[:8])
     small = {k: v[:8] for k, v in big.items()}
-    assert outputs_close(small, want, sp[:8, :, 0] > 0, 0.05, 0.2)
+    # 52 (b28) / 80 (b40) convolutions deep in bf16: the layer tolerance of the reference (0.03 * max(|x|, 3), testnn.cpp:8-15)
+    # applied to the range of the outputs (policy logits up to ~13-20 here)
+    assert outputs_close(small, want, sp[:8, :, 0] > 0, 0.05, 0.4)
     for i in (0, 16, 240, 496):
         part = nn.getOutput(h, sp[i:i + 16], gl[i:i + 16], sym[i:i + 16], opt[i:i + 16])
         for k in part:
