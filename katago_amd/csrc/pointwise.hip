@@ -1,4 +1,6 @@
 // pointwise.hip — instantiations and dispatch of the fused 1x1 -> 1x1 seam kernel (pointwise_kernel.h).
+#include <cstdlib>
+
 #include "pointwise_kernel.h"
 
 namespace kmx {
@@ -9,10 +11,24 @@ using namespace pwk;
 // (K1 = C1/32, WN1 = C2/128, WN2 = C3/64): b18c384nbt is (6, 3, 3): 192 -> 384 -> 192.
 #define KMX_PW_LIST(X) X(6, 3, 3)
 
+// Default: 8 waves x 128 cells, one work-group per CU. KMX_PW_WAVES=4 selects 4 waves x 64 cells, two work-groups per CU
+// (pointwise_kernel.h): measured on MI355X (b18c384nbt, batch 256, A/B on one box) 41.0 k evals/s against 41.9 k, the
+// seam's share of the step 21.2 % against 20.3 % - two co-resident groups start together and stay in phase, so their
+// memory and compute phases do not interleave, and each group multiplies with half the tile per weight slab.
+int pwWaves() {
+  static const int w = [] {
+    const char* e = getenv("KMX_PW_WAVES");
+    return e && atoi(e) == 4 ? 4 : 8;
+  }();
+  return w;
+}
+
 template <class TR>
 hipError_t launchT(int c1, int c2, int c3, const PwPairArgs& a, hipStream_t stream) {
+  // the 4-wave shape: a wave of GEMM 1 owns C2/2 channels (WN1 doubles), of GEMM 2 C3/2 (WN2 as is)
 #define KMX_PW(K1_, WN1_, WN2_) \
-  if(c1 == 32 * K1_ && c2 == 128 * WN1_ && c3 == 64 * WN2_) return launchPair<TR, K1_, WN1_, WN2_, 128>(a, stream);
+  if(c1 == 32 * K1_ && c2 == 128 * WN1_ && c3 == 64 * WN2_) \
+    return pwWaves() == 8 ? launchPair<TR, K1_, WN1_, WN2_, 128, 8>(a, stream) : launchPair<TR, K1_, 2 * WN1_, WN2_, 64, 4>(a, stream);
   KMX_PW_LIST(KMX_PW)
 #undef KMX_PW
   return hipErrorInvalidValue;

@@ -34,19 +34,30 @@ namespace kmx {
 namespace pwk {
 
 constexpr int ROWB = WROW_HALFS * 2;  // 64-byte LDS rows: four 16-byte slots, slot s of row r stored at s ^ ((r>>2)&3)
-constexpr int NWAVES = 8;
-constexpr int NTHREADS = NWAVES * 64;
-constexpr int RING = 3;  // weight slabs in LDS; slab c+2 is requested in step c
-
-template <int K1, int WN1, int WN2, int TM>
+// Two shapes (the last template parameter NW of the kernel):
+//   8 waves, 128 cells, ring of 3 weight slabs: LDS ~133 KB -> one work-group per CU. GEMM 1 waves 2 (cells) x 4 (channels),
+//     GEMM 2 waves 4 x 2.
+//   4 waves,  64 cells, ring of 2 weight slabs: LDS < 80 KB -> TWO work-groups per CU, 8 waves in all as before. Built to let
+//     one group stream its tile in or its results out while the other multiplies (per work-group the seam spends ~30 k
+//     cycles on HBM traffic and ~28 k on matrix + vector work, nothing overlapped). EXPERIMENT (KMX_PW_WAVES=4): measured
+//     2 % slower than the 8-wave shape - the two groups of a CU start together and stay in phase. GEMM 1 waves 2 x 2 (a wave
+//     owns 192 channels), GEMM 2 waves 2 x 2.
+template <int K1, int WN1, int WN2, int TM, int NW>
 struct Geom {
-  static constexpr int C1 = 32 * K1;        // input channels of GEMM 1
-  static constexpr int C2 = 4 * 32 * WN1;   // trunk channels
+  static constexpr int NWAVES = NW;
+  static constexpr int NTHREADS = NWAVES * 64;
+  static constexpr int RING = NW == 8 ? 3 : 2;  // weight slabs in LDS; slab c+RING-1 is requested in step c
+  static constexpr int WM1 = 2;                 // wave rows (cells) of GEMM 1
+  static constexpr int WNG1 = NWAVES / WM1;     // wave columns (channel groups) of GEMM 1
+  static constexpr int WM2 = NW == 8 ? 4 : 2;
+  static constexpr int WNG2 = NWAVES / WM2;
+  static constexpr int C1 = 32 * K1;            // input channels of GEMM 1
+  static constexpr int C2 = WNG1 * 32 * WN1;    // trunk channels
   static constexpr int K2 = C2 / 32;
-  static constexpr int C3 = 2 * 32 * WN2;   // output channels of GEMM 2
-  static constexpr int MT1 = TM / 64;       // cell tiles per wave, GEMM 1 (2 wave rows)
-  static constexpr int MT2 = TM / 128;      // cell tiles per wave, GEMM 2 (4 wave rows)
-  static_assert(TM % 128 == 0, "a work-group's cells split into 4 wave rows of whole 32-cell tiles");
+  static constexpr int C3 = WNG2 * 32 * WN2;    // output channels of GEMM 2
+  static constexpr int MT1 = TM / (32 * WM1);   // cell tiles per wave, GEMM 1
+  static constexpr int MT2 = TM / (32 * WM2);   // cell tiles per wave, GEMM 2
+  static_assert(TM % (32 * WM1) == 0 && TM % (32 * WM2) == 0, "a work-group's cells split into wave rows of whole 32-cell tiles");
   static constexpr int CHUNK_BYTES = TM * ROWB;          // one 32-channel chunk of an image tile
   static constexpr int X_BYTES = K1 * CHUNK_BYTES;
   static constexpr int W1_SLAB = C2 * ROWB;
@@ -60,8 +71,8 @@ struct Geom {
   static constexpr int PIPE_END = PH1_END > PH2_END ? PH1_END : PH2_END;
   static constexpr int PARAM_OFF = PIPE_END;                              // scale1, bias1 [C2], scale2, bias2 [C3] as float
   static constexpr int MASK_OFF = PARAM_OFF + (2 * C2 + 2 * C3) * 4;      // TM floats
-  static constexpr int SLACK_OFF = MASK_OFF + TM * 4;                     // 1 KiB per wave: destination of padding DMA
-  static constexpr int LDS_BYTES = SLACK_OFF + NWAVES * 1024;
+  static constexpr int SLACK_OFF = MASK_OFF + TM * 4;                     // 1 KiB: destination of padding DMA (never read)
+  static constexpr int LDS_BYTES = SLACK_OFF + 1024;
   // DMA instructions (1 KiB each: 64 lanes x 16 bytes) per wave
   static constexpr int NPX = (K1 * TM * 4 + NTHREADS - 1) / NTHREADS;   // the X tile
   static constexpr int NPW1 = (C2 * 4 + NTHREADS - 1) / NTHREADS;       // one W1 slab
@@ -75,12 +86,46 @@ __device__ __forceinline__ void waitVm() {
 }
 __device__ __forceinline__ void waitVmSel(int n) {  // n becomes a constant once the caller's branches are resolved
   switch(n) {
+    case 1: waitVm<1>(); break;
     case 2: waitVm<2>(); break;
     case 3: waitVm<3>(); break;
+    case 4: waitVm<4>(); break;
+    case 5: waitVm<5>(); break;
+    case 6: waitVm<6>(); break;
+    case 7: waitVm<7>(); break;
+    case 8: waitVm<8>(); break;
+    case 9: waitVm<9>(); break;
+    case 10: waitVm<10>(); break;
+    case 11: waitVm<11>(); break;
+    case 12: waitVm<12>(); break;
+    case 13: waitVm<13>(); break;
     case 14: waitVm<14>(); break;
     case 15: waitVm<15>(); break;
+    case 16: waitVm<16>(); break;
+    case 17: waitVm<17>(); break;
+    case 18: waitVm<18>(); break;
+    case 19: waitVm<19>(); break;
+    case 20: waitVm<20>(); break;
+    case 21: waitVm<21>(); break;
+    case 22: waitVm<22>(); break;
+    case 23: waitVm<23>(); break;
+    case 24: waitVm<24>(); break;
+    case 25: waitVm<25>(); break;
     case 26: waitVm<26>(); break;
     case 27: waitVm<27>(); break;
+    case 28: waitVm<28>(); break;
+    case 29: waitVm<29>(); break;
+    case 30: waitVm<30>(); break;
+    case 31: waitVm<31>(); break;
+    case 32: waitVm<32>(); break;
+    case 33: waitVm<33>(); break;
+    case 34: waitVm<34>(); break;
+    case 35: waitVm<35>(); break;
+    case 36: waitVm<36>(); break;
+    case 37: waitVm<37>(); break;
+    case 38: waitVm<38>(); break;
+    case 39: waitVm<39>(); break;
+    case 40: waitVm<40>(); break;
     default: waitVm<0>(); break;  // stricter than needed, never wrong
   }
 }
@@ -93,12 +138,13 @@ __device__ __forceinline__ void dma16(const void* gsrc, char* ldsWaveBase) {
   __builtin_amdgcn_global_load_lds(
     (const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)ldsWaveBase, 16, 0, 0);
 }
-template <class TR, int K1, int WN1, int WN2, int TM>
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void pointwisePairKernel(const PwPairArgs a) {
+template <class TR, int K1, int WN1, int WN2, int TM, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void pointwisePairKernel(const PwPairArgs a) {
   typedef typename TR::T T;
   typedef typename TR::V8 V8;
   typedef typename TR::V4 V4;
-  typedef Geom<K1, WN1, WN2, TM> G;
+  typedef Geom<K1, WN1, WN2, TM, NW> G;
+  constexpr int NWAVES = G::NWAVES, NTHREADS = G::NTHREADS, RING = G::RING;
   constexpr int K2 = G::K2, MT1 = G::MT1, MT2 = G::MT2, NPX = G::NPX, NPW1 = G::NPW1, NPW2 = G::NPW2;
 
   extern __shared__ __attribute__((aligned(256))) char smemPw[];
@@ -113,7 +159,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int myPos = l31 < 4 ? l31 : l31 < 12 ? l31 + 12 : l31 < 16 ? l31 - 8 : l31 < 20 ? l31 + 8 : l31 < 28 ? l31 - 12 : l31;
   const long long cell0 = (long long)blockIdx.x * TM;
   const char* const zero = (const char*)a.zeroPage;
-  char* const mySlack = smem + G::SLACK_OFF + wave * 1024;
+  char* const mySlack = smem + G::SLACK_OFF;
   float* const sc1S = (float*)(smem + G::PARAM_OFF);
   float* const bi1S = sc1S + G::C2;
   float* const sc2S = bi1S + G::C2;
@@ -140,8 +186,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
       dma16(slab + (size_t)(inRange ? pbase + lane : lane) * 16, inRange ? dst + pbase * 16 : mySlack);
     }
   };
-  issueW(a.w1, G::W1_SLAB, NPW1, G::W1_OFF, 0, K1);
-  issueW(a.w1, G::W1_SLAB, NPW1, G::W1_OFF, 1, K1);
+#pragma unroll
+  for(int c = 0; c < RING - 1; c++) issueW(a.w1, G::W1_SLAB, NPW1, G::W1_OFF, c, K1);
 
   // ---- per-channel parameters and the mask tile -> LDS (plain loads; published by the first barrier) ----
   for(int i = tid; i < G::C2; i += NTHREADS) {
@@ -156,7 +202,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
   waitLds();  // published by the first barrier of the loop below
 
   // ---- GEMM 1: accumulators start from the residual stream ----
-  const int wm1 = wave >> 2, wn1 = wave & 3;
+  const int wm1 = wave / G::WNG1, wn1 = wave % G::WNG1;
   // The residual pieces are requested here and added in epilogue 1 (in fp32, before the rounding) - the same order of
   // operations as the convolution kernel's epilogue, which the unfused schedule runs: bit-identical results.
   f32x16 acc1[WN1][MT1];
@@ -194,10 +240,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
     const unsigned wRow = (wn1 * (32 * WN1) + l31) * ROWB;
     for(int c = 0; c < K1; c++) {
-      waitVm<NPW1>();  // everything but the youngest slab: X (oldest) and slab c
+      waitVm<(RING - 2) * NPW1>();  // everything but the younger slabs: X (oldest) and slab c
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      issueW(a.w1, G::W1_SLAB, NPW1, G::W1_OFF, c + 2, K1);
+      issueW(a.w1, G::W1_SLAB, NPW1, G::W1_OFF, c + RING - 1, K1);
       const unsigned wBase = ldsBase + G::W1_OFF + (c % RING) * G::W1_SLAB + wRow;
       const unsigned xBase = ldsBase + c * G::CHUNK_BYTES;
 #pragma unroll
@@ -218,8 +264,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
   waitVm<0>();  // the trailing padding requests
   __builtin_amdgcn_s_barrier();  // every wave is done with X and the W1 ring: the LDS changes hands
   asm volatile("" ::: "memory");
-  issueW(a.w2, G::W2_SLAB, NPW2, G::W2_OFF, 0, K2);
-  issueW(a.w2, G::W2_SLAB, NPW2, G::W2_OFF, 1, K2);
+#pragma unroll
+  for(int c = 0; c < RING - 1; c++) issueW(a.w2, G::W2_SLAB, NPW2, G::W2_OFF, c, K2);
 
   // ---- epilogue 1: trunk raw -> HBM, activated trunk -> LDS image of GEMM 2 ----
   withActKind(a.actKind1, [&](auto kindTag) {
@@ -284,7 +330,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
   waitLds();  // the image is read by other waves after the next barrier
 
   // ---- GEMM 2 ----
-  const int wm2 = wave >> 1, wn2 = wave & 1;
+  const int wm2 = wave / G::WNG2, wn2 = wave % G::WNG2;
   f32x16 acc2[WN2][MT2];
 #pragma unroll
   for(int ct = 0; ct < WN2; ct++)
@@ -301,15 +347,16 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
       xXor[pt] = (q >> 2) & 3;
     }
     const unsigned wRow = (wn2 * (32 * WN2) + l31) * ROWB;
-    // requests in flight, oldest first: slab 0, slab 1, epilogue 1's stores, then slab c+1 (requested at step c-1). Waiting for
-    // slab c with "all but the youngest NPW2" would, in steps 0 and 1, also wait for the stores to be acknowledged.
+    // requests in flight, oldest first: slabs 0 .. RING-2, epilogue 1's stores, then slab c+RING-1 (requested at step c).
+    // Waiting for slab c with "all but the youngest slabs" would, in the first RING-1 steps, also wait for the stores to be
+    // acknowledged: there the stores (younger than the slab) are counted in.
     const int nStores1 = MT1 * WN1 * 2 * (a.actOut != nullptr ? 2 : 1);
     for(int c = 0; c < K2; c++) {
-      if(c < 2) waitVmSel(NPW2 + nStores1);
-      else waitVm<NPW2>();
+      if(c < RING - 1) waitVmSel((RING - 2) * NPW2 + nStores1);
+      else waitVm<(RING - 2) * NPW2>();
       __builtin_amdgcn_s_barrier();  // c == 0: also publishes the activated image written above
       asm volatile("" ::: "memory");
-      issueW(a.w2, G::W2_SLAB, NPW2, G::W2_OFF, c + 2, K2);
+      issueW(a.w2, G::W2_SLAB, NPW2, G::W2_OFF, c + RING - 1, K2);
       const unsigned wBase = ldsBase + G::W2_OFF + (c % RING) * G::W2_SLAB + wRow;
       const unsigned xBase = ldsBase + c * G::CHUNK_BYTES;
 #pragma unroll
@@ -381,12 +428,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
   });
 }
 
-template <class TR, int K1, int WN1, int WN2, int TM>
+template <class TR, int K1, int WN1, int WN2, int TM, int NW>
 hipError_t launchPair(const PwPairArgs& a, hipStream_t stream) {
-  typedef Geom<K1, WN1, WN2, TM> G;
+  typedef Geom<K1, WN1, WN2, TM, NW> G;
+  static_assert(NW == 8 || G::LDS_BYTES <= 80 * 1024, "the 4-wave shape exists to fit two work-groups per CU");
   static_assert(G::LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
   static_assert(G::A2_BYTES <= G::PH1_END, "the activated image reuses the GEMM 1 operand area");
-  auto kern = pointwisePairKernel<TR, K1, WN1, WN2, TM>;
+  auto kern = pointwisePairKernel<TR, K1, WN1, WN2, TM, NW>;
   constexpr int MAX_DEVICES = 64;  // the >64 KiB LDS opt-in is per function AND device (conv_kernel.h launchOne)
   static std::atomic<bool> attrSet[MAX_DEVICES];
   int dev = 0;
@@ -400,7 +448,7 @@ hipError_t launchPair(const PwPairArgs& a, hipStream_t stream) {
   }
   if(a.cells <= 0) return hipErrorInvalidValue;
   const long long tiles = (a.cells + TM - 1) / TM;
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(NTHREADS), G::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(G::NTHREADS), G::LDS_BYTES, stream, a);
   return hipGetLastError();
 }
 

@@ -283,12 +283,13 @@ for dtype in ("bf16", "fp16"):
                   "off_board_zero": bool((fused[2][m != 1.0] == 0).all())}
 print("RESULT " + json.dumps(out))
 """ % (REPO, os.path.join(REPO, "tests"))
-    p = subprocess.run([sys.executable, "-c", code, emu_full_lib], capture_output=True, text=True, timeout=1800)
-    assert p.returncode == 0 and "RESULT " in p.stdout, (p.stdout + p.stderr)[-3000:]
-    res = json.loads(p.stdout.split("RESULT ")[1])
-    print(res)
-    for dtype, r in res.items():
-        assert all(r["same"]) and r["off_board_zero"], (dtype, r)
-        ulp = 2.0 ** -7 if dtype == "bf16" else 2.0 ** -10
-        for e, s, k in zip(r["err"], r["scale"], (1, 4, 4)):
-            assert e <= 2 * ulp * max(s, 1.0) * k, (dtype, r)
+    for waves in ("8", "4"):  # the product shape (8 waves x 128 cells) and the two-per-CU experiment (4 waves x 64 cells)
+        p = subprocess.run([sys.executable, "-c", code, emu_full_lib], capture_output=True, text=True, timeout=1800, env=dict(os.environ, KMX_PW_WAVES=waves))
+        assert p.returncode == 0 and "RESULT " in p.stdout, (p.stdout + p.stderr)[-3000:]
+        res = json.loads(p.stdout.split("RESULT ")[1])
+        print(waves, res)
+        for dtype, r in res.items():
+            assert all(r["same"]) and r["off_board_zero"], (waves, dtype, r)
+            ulp = 2.0 ** -7 if dtype == "bf16" else 2.0 ** -10
+            for e, s, k in zip(r["err"], r["scale"], (1, 4, 4)):
+                assert e <= 2 * ulp * max(s, 1.0) * k, (waves, dtype, r)
