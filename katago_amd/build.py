@@ -60,8 +60,28 @@ def up_to_date():
         return False
 
 
+PUMP = os.path.join(HERE, "leaf_pump")
+PUMP_SRC = os.path.join(HERE, "..", "integration", "leaf_pump.cpp")
+
+
+def build_leaf_pump(verbose=True):
+    """integration/leaf_pump.cpp -> katago_amd/leaf_pump: a plain C++ consumer of include/katamx.h (g++, no HIP) that keeps
+    many leaves in flight through the batcher; what tests/test_gpu_leaf_pump.py runs."""
+    if os.path.exists(PUMP) and _mtime(PUMP) >= max(_mtime(PUMP_SRC), _mtime(LIB)):
+        return PUMP
+    cmd = [os.environ.get("CXX", "g++"), "-std=c++17", "-O2", "-I" + os.path.join(HERE, "..", "include"), "-o", PUMP, PUMP_SRC,
+           "-L" + HERE, "-lkatamx", "-Wl,-rpath,$ORIGIN", "-pthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building leaf_pump failed:\n%s\n%s" % (r.stdout, r.stderr))
+    if verbose:
+        print("[katago_amd.build] built", PUMP, flush=True)
+    return PUMP
+
+
 def build(force=False, verbose=True):
     if not force and up_to_date():
+        build_leaf_pump(verbose)
         return LIB
     os.makedirs(OBJDIR, exist_ok=True)
     newest_header = max(_mtime(os.path.join(CSRC, h)) for h in HEADERS)
@@ -86,6 +106,7 @@ def build(force=False, verbose=True):
             print("[katago_amd.build] linked", LIB, flush=True)
     with open(STAMP, "w") as f:
         f.write(_source_hash() + "\n")
+    build_leaf_pump(verbose)
     return LIB
 
 

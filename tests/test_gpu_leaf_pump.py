@@ -1,0 +1,41 @@
+"""-m gpu: row f2 measured from the boundary. integration/leaf_pump.cpp is a plain C++ consumer of include/katamx.h that
+behaves as a search front end would: a few threads, each keeping many leaves in flight through kmx_batcher_submit /
+kmx_batcher_wait (tickets, not one blocked OS thread per leaf). From HOST rows - bit-packing, H2D, the pass, D2H and delivery
+included - the batcher is expected to sustain most of the device-resident rate of bench.py; the numbers are recorded
+(gpurun_out/ -> profiles/)."""
+import json
+import os
+import subprocess
+
+import pytest
+
+from conftest import REPO
+from katago_amd import modelgen
+
+pytestmark = pytest.mark.gpu
+PUMP = os.path.join(REPO, "katago_amd", "leaf_pump")
+
+
+def test_leaf_pump_keeps_the_device_busy(tmp_path):
+    if not os.path.exists(PUMP):
+        pytest.skip("katago_amd/leaf_pump not built (python -m katago_amd.build)")
+    model = str(tmp_path / "b18.bin")
+    modelgen.write_model(model, "b18c384nbt", seed=7)
+    lines = []
+    best = 0.0
+    # (max batch, batches in flight, threads, tickets per thread)
+    for cfg in ((256, 2, 8, 128), (256, 3, 8, 128), (256, 2, 32, 32), (256, 2, 2, 512)):
+        p = subprocess.run([PUMP, model, "19", str(cfg[0]), str(cfg[1]), str(cfg[2]), str(cfg[3]), "3"], capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, (p.stdout + p.stderr)[-2000:]
+        r = json.loads(p.stdout.strip().splitlines()[-1])
+        assert r["failed"] == 0 and r["rows_per_s"] > 0
+        best = max(best, r["rows_per_s"])
+        lines.append(json.dumps(r))
+    print("\n".join(lines))
+    keep = os.path.join(REPO, "gpurun_out")
+    if os.path.isdir(keep):
+        with open(os.path.join(keep, "leaf_pump_b18.txt"), "w") as f:
+            f.write("\n".join(lines) + "\n")
+    # bench.py's device-resident rate on the pool's boxes is 40-42 k evals/s; from host rows through the batcher at least
+    # three quarters of the slowest of those must arrive
+    assert best > 30000.0, lines
