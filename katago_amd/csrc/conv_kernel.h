@@ -35,13 +35,15 @@
 //     while D-1 steps of requests stay in flight across the single s_barrier per step.
 //   - LDS reads are software-pipelined too: each batch of fragment reads is issued right after the first MFMA of the
 //     other fragment set (the compiler's own s_waitcnt before an MFMA drains ALL outstanding LDS reads).
-//   - accumulators start from the residual stream, so the epilogue has no global loads (vmcnt counts
-//     stores too: an epilogue alternating loads and stores pays a memory round trip per row).
-//   - epilogue: each wave transposes its tiles through LDS (fp32) and walks them row-wise with 16-byte
-//     stores of whole NHWC runs; BN scale/bias, activation, mask, 16-bit rounding happen there.
-//   Measured cost split of a 3x3 192->192 layer at batch 256 (70 us; profiles/r01_v5/ablate_v5.log): launch+prologue 6,
-//   MFMA loop 34 (1.8 PFLOP/s), LDS reads +1, DMA feed +13, epilogue +16, residual fetch +8 when present. Variants that
-//   were built and measured slower are recorded under profiles/ (weights straight from global memory: r01_v6_experiment).
+//   - epilogue (round 2): straight from the accumulator layout - no LDS transpose, no work-group barrier. Per-channel
+//     parameters come from LDS (4-byte LDS-DMA in the prologue), the residual is fetched one tile ahead and added in fp32,
+//     lane pairs (c, c + 32) regroup their 8-byte runs into 16-byte pieces (v_permlane32_swap), stores are unconditional
+//     (pieces that must not land go to a trash area) so that every s_waitcnt count is a compile-time constant. BN
+//     scale/bias, activation, mask and the 16-bit rounding happen there; see the comments at the epilogue itself.
+//   - 8-wave 3x3/5x5 shapes: waves 0-3 issue all the DMA (they are served first by the matrix core and have the slack).
+//   Cycle account of a 3x3 192->192 work-group at batch 256 (profiles/r02_final/conv_timing.log): prologue 9.8 k, loop 82.8 k
+//   (62.2 k of pure MFMA time), epilogue 19 k without / 41 k with residual. Variants that were built and measured slower
+//   are listed in DESIGN.md 4.8 (profiles/r02_steps, r01_v6_experiment).
 #ifndef KMX_CONV_KERNEL_H_
 #define KMX_CONV_KERNEL_H_
 
