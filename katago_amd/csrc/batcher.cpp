@@ -197,8 +197,13 @@ class Batcher {
       // is idle: while a batch runs, arriving rows accumulate into the next one (sealing them at once - the reference's
       // greedy rule applied per in-flight slot - produces many small batches that share the device inefficiently; measured
       // with the reference's benchmark, 4 server threads: avg 45 rows per batch).
+      // ... unless what is on the device is small: a pass over a few dozen rows occupies a fraction of the CUs (one work-group
+      // per board and 32-96 channels) and is bound by its ~100 dependent launches, so a second small batch beside it is
+      // nearly free - the regime of self-play with few game threads.
       cvWork_.wait(l, [&] {
-        return closing_ || (running_ < maxInFlight_ && !sealed_.empty()) || (running_ == 0 && filling_ >= 0 && slots_[filling_].count > 0);
+        if(closing_ || (running_ < maxInFlight_ && !sealed_.empty())) return true;
+        if(filling_ < 0 || slots_[filling_].count == 0) return false;
+        return running_ == 0 || (running_ < maxInFlight_ && rowsOnDevice_ + slots_[filling_].count <= SMALL_ROWS);
       });
       if(closing_) {
         // rows that were never launched: fail their waiters
@@ -223,6 +228,7 @@ class Batcher {
       }
       Slot& s = slots_[si];
       running_++;
+      rowsOnDevice_ += s.count;
       const int n = s.count;
       const bool anyOwner = s.anyOwner;
       l.unlock();
@@ -276,6 +282,7 @@ class Batcher {
         rows_ += (uint64_t)s.count;
         batches_ += 1;
       }
+      rowsOnDevice_ -= s.count;
       finishSlot(s, err, msg);
       running_--;
       cvWork_.notify_one();
@@ -288,6 +295,8 @@ class Batcher {
   std::condition_variable cvWork_, cvComplete_, cvFree_;
   std::deque<int> sealed_, inflight_;
   int filling_ = -1, running_ = 0;
+  int rowsOnDevice_ = 0;                    // rows of the batches between launch and completion
+  static constexpr int SMALL_ROWS = 96;     // partial batches may run side by side while the device holds at most this many rows
   bool closing_ = false;
   uint64_t nextTicket_ = 1;
   // node-based map: references to its elements stay valid while other tickets come and go (a waiter sleeps holding one)

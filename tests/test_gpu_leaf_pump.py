@@ -31,6 +31,16 @@ def test_leaf_pump_keeps_the_device_busy(tmp_path):
         assert r["failed"] == 0 and r["rows_per_s"] > 0
         best = max(best, r["rows_per_s"])
         lines.append(json.dumps(r))
+    # the latency-bound regime of self-play with few game threads: 8 / 32 leaves in flight in all. One batch at a time against up
+    # to four small batches side by side (a pass over a few rows leaves most CUs idle)
+    small = {}
+    for cfg in ((64, 1, 8, 1), (64, 4, 8, 1), (64, 1, 32, 1), (64, 4, 32, 1)):
+        p = subprocess.run([PUMP, model, "19", str(cfg[0]), str(cfg[1]), str(cfg[2]), str(cfg[3]), "2"], capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, (p.stdout + p.stderr)[-2000:]
+        r = json.loads(p.stdout.strip().splitlines()[-1])
+        assert r["failed"] == 0 and r["rows_per_s"] > 0
+        small[cfg] = r["rows_per_s"]
+        lines.append(json.dumps(r))
     print("\n".join(lines))
     keep = os.path.join(REPO, "gpurun_out")
     if os.path.isdir(keep):

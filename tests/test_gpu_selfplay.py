@@ -63,11 +63,11 @@ def test_selfplay_rate_b18_19x19_on_hip(tmp_path):
     os.makedirs(os.path.join(d, "models"))
     modelgen.write_model(os.path.join(d, "models", "b18c384nbt-s1-d1.bin.gz"), "b18c384nbt", seed=7)
     lines = []
-    for threads in (8, 128):
-        out = os.path.join(d, "out%d" % threads)
+    for threads, servers in ((8, 1), (8, 4), (128, 1)):
+        out = os.path.join(d, "out%d_%d" % (threads, servers))
         over = ("numGameThreads=%d,nnMaxBatchSize=%d,dataBoardLen=19,bSizes=19,bSizeRelProbs=1,maxMovesPerGame=60,maxVisits=32,"
                 "cheapSearchVisits=16,reducedVisitsMin=16,maxRowsPerTrainFile=20000,maxDataQueueSize=2000,nnCacheSizePowerOfTwo=18,"
-                "nnMutexPoolSizePowerOfTwo=14,logGamesEvery=1000" % (threads, max(threads, 8)))
+                "nnMutexPoolSizePowerOfTwo=14,logGamesEvery=1000,numNNServerThreadsPerModel=%d" % (threads, max(threads, 8), servers))
         p = subprocess.run([b, "selfplay", "-config", CFG, "-models-dir", os.path.join(d, "models"), "-output-dir", out,
                             "-max-games-total", str(threads), "-override-config", over], capture_output=True, text=True, timeout=600, cwd=d)
         log = p.stdout + p.stderr
@@ -76,8 +76,8 @@ def test_selfplay_rate_b18_19x19_on_hip(tmp_path):
         secs = float(log.split("Total selfplay runtime (seconds): ")[1].split()[0])
         nn_rows = int(log.split("Final NN rows: ")[1].split()[0])
         assert games >= threads and secs > 0 and nn_rows > 0
-        lines.append("b18c384nbt 19x19 selfplay, %3d game threads, <=60 moves, 32/16 visits: %d games in %.1f s = %.0f games/hour; %d NN rows = %.0f rows/s"
-                     % (threads, games, secs, games * 3600.0 / secs, nn_rows, nn_rows / secs))
+        lines.append("b18c384nbt 19x19 selfplay, %3d game threads, %d NN server thread(s), <=60 moves, 32/16 visits: %d games in %.1f s = %.0f games/hour; %d NN rows = %.0f rows/s"
+                     % (threads, servers, games, secs, games * 3600.0 / secs, nn_rows, nn_rows / secs))
     print("\n".join(lines))
     keep = os.path.join(REPO, "gpurun_out")
     if os.path.isdir(keep):
