@@ -13,8 +13,8 @@ using namespace pwk;
 
 // Default: 8 waves x 128 cells, one work-group per CU. KMX_PW_WAVES=4 selects 4 waves x 64 cells, two work-groups per CU
 // (pointwise_kernel.h): measured on MI355X (b18c384nbt, batch 256, A/B on one box) 41.0 k evals/s against 41.9 k, the
-// seam's share of the step 21.2 % against 20.3 % - two co-resident groups start together and stay in phase, so their
-// memory and compute phases do not interleave, and each group multiplies with half the tile per weight slab.
+// seam's share of the step 21.2 % against 20.3 % - co-residence did not overlap the groups' memory and compute phases (neither
+// did staggering the two half-batch streams), and each group multiplies with half the tile per weight slab.
 int pwWaves() {
   static const int w = [] {
     const char* e = getenv("KMX_PW_WAVES");

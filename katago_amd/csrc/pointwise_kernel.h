@@ -40,7 +40,7 @@ constexpr int ROWB = WROW_HALFS * 2;  // 64-byte LDS rows: four 16-byte slots, s
 //   4 waves,  64 cells, ring of 2 weight slabs: LDS < 80 KB -> TWO work-groups per CU, 8 waves in all as before. Built to let
 //     one group stream its tile in or its results out while the other multiplies (per work-group the seam spends ~30 k
 //     cycles on HBM traffic and ~28 k on matrix + vector work, nothing overlapped). EXPERIMENT (KMX_PW_WAVES=4): measured
-//     2 % slower than the 8-wave shape - the two groups of a CU start together and stay in phase. GEMM 1 waves 2 x 2 (a wave
+//     2 % slower than the 8-wave shape (the phases of co-resident groups did not overlap). GEMM 1 waves 2 x 2 (a wave
 //     owns 192 channels), GEMM 2 waves 2 x 2.
 template <int K1, int WN1, int WN2, int TM, int NW>
 struct Geom {
