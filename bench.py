@@ -251,7 +251,8 @@ def main():
                     "profiled_ms_per_step": round(profiled_elapsed / args.steps * 1e3, 4),
                     "avg_launch_ms": round(ms / launches, 5), "launches": int(launches),
                     "flops_per_launch": flops / launches, "algorithmic_bytes_per_launch": nbytes / launches,
-                    "kernel_time_share": {k: round(v[1] / total_ms, 4) for k, v in prof_entries.items()}}
+                    "kernel_time_share": {k: round(v[1] / total_ms, 4) for k, v in prof_entries.items()},
+                    "kernel_avg_launch_us": {k: round(v[1] / max(v[0], 1) * 1e3, 2) for k, v in prof_entries.items()}}
 
     if rank == 0:
         value = total_rows / elapsed

@@ -257,6 +257,11 @@ int kmx_handle_get_profile(kmx_handle* handle, kmx_profile_entry* entries, int m
  * epilogue_mode 0 = BN+act output, 1 = residual + raw + BN+act outputs. Kernel tuning instrumentation. */
 int kmx_bench_conv(int ks, int wn, int variant, int cin, int cout, int batch, int nn_x_len, int nn_y_len,
                    int epilogue_mode, int iters, double* avg_ms);
+/* The same layer on n_streams streams at once (each its own `batch` boards, `launches` back-to-back launches), stream i
+ * started i * delay_us microseconds after stream 0: what a stagger of a FRACTION of a launch between co-resident
+ * work-groups buys. total_ms = wall time from the common start to the last stream's end. Kernel tuning instrumentation. */
+int kmx_bench_conv_streams(int ks, int cfg, int cin, int cout, int batch, int n_streams, double delay_us, int launches,
+                           int epilogue_mode, double* total_ms);
 /* Host-only introspection of the convolution launcher (no device needed): the work-group shape chosen for a kernel size,
  * a padded channel count (multiple of 64) and a batch, and whether a kernel of that shape exists and tiles the channels.
  * tests/test_conv_chooser.py walks every combination the engine can ask for. */

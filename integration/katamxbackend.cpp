@@ -19,6 +19,7 @@
 #include "neuralnet/desc.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -27,6 +28,7 @@
 #include <vector>
 
 #include "katamx.h"
+#include "katamx_leaf.h"
 #ifdef KMX_USE_ORACLE
 #include "kmx_oracle.h"
 #endif
@@ -443,6 +445,102 @@ void NeuralNet::getOutput(
       out->shorttermScoreError = 0;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Leaf ports (katamx_leaf.h): rows handed over by the thread that owns the leaf, results collected by ticket.
+struct KatamxLeaf::Port {
+  const ComputeContext* context = NULL;
+  const LoadedModel* loadedModel = NULL;
+  int numInputMetaChannels = 0;
+#ifdef KMX_USE_ORACLE
+  std::atomic<uint64_t> rows{0};
+#else
+  kmx_batcher* batcher = NULL;
+#endif
+};
+
+KatamxLeaf::Port* KatamxLeaf::openPort(
+  ComputeContext* context, const LoadedModel* loadedModel, Logger* logger, int maxBatchSize, int batchesInFlight, int gpuIdx
+) {
+  std::unique_ptr<Port> port(new Port());
+  port->context = context;
+  port->loadedModel = loadedModel;
+  port->numInputMetaChannels = loadedModel->modelDesc.numInputMetaChannels;
+#ifdef KMX_USE_ORACLE
+  (void)maxBatchSize;
+  (void)batchesInFlight;
+  if(logger != NULL)
+    logger->write("katamx CPU ORACLE leaf port " + Global::intToString(gpuIdx) + " model " + loadedModel->modelDesc.name);
+#else
+  check(
+    kmx_batcher_create(context->ctx, loadedModel->model, maxBatchSize, batchesInFlight, gpuIdx, &port->batcher),
+    "creating the leaf batcher");
+  if(logger != NULL) {
+    int prec = kmx_batcher_precision(port->batcher);
+    logger->write(
+      "katamx (HIP/gfx950) leaf port: device " + Global::intToString(gpuIdx < 0 ? 0 : gpuIdx) + " precision " +
+      (prec == KMX_PREC_FP16 ? "fp16" : "bf16") + " batch " + Global::intToString(maxBatchSize) + " model " + loadedModel->modelDesc.name);
+  }
+#endif
+  return port.release();
+}
+void KatamxLeaf::closePort(Port* port) {
+  if(port == NULL)
+    return;
+#ifndef KMX_USE_ORACLE
+  kmx_batcher_free(port->batcher);
+#endif
+  delete port;
+}
+bool KatamxLeaf::isUsingFP16(const Port* port) {
+#ifdef KMX_USE_ORACLE
+  (void)port;
+  return false;
+#else
+  return kmx_batcher_precision(port->batcher) != KMX_PREC_FP32;
+#endif
+}
+uint64_t KatamxLeaf::submit(
+  Port* port, const float* rowSpatial, const float* rowGlobal, const float* rowMeta, int symmetry, float policyOptimism,
+  float* outPolicy, float* outValue, float* outScore, float* outOwnership
+) {
+  testAssert((rowMeta != NULL) == (port->numInputMetaChannels > 0));
+#ifdef KMX_USE_ORACLE
+  const float* sp[1] = {rowSpatial};
+  const float* gl[1] = {rowGlobal};
+  const float* mt[1] = {rowMeta};
+  float* pol[1] = {outPolicy};
+  float* own[1] = {outOwnership};
+  check(
+    okmx_eval_meta(
+      port->loadedModel->model, port->context->nnXLen, port->context->nnYLen, 1, sp, gl, rowMeta != NULL ? mt : NULL, &symmetry,
+      &policyOptimism, pol, outValue, outScore, own, 1),
+    "evaluating a leaf");
+  return port->rows.fetch_add(1) + 1;
+#else
+  uint64_t ticket = 0;
+  check(
+    kmx_batcher_submit(port->batcher, rowSpatial, rowGlobal, rowMeta, symmetry, policyOptimism, outPolicy, outValue, outScore, outOwnership, &ticket),
+    "submitting a leaf");
+  return ticket;
+#endif
+}
+void KatamxLeaf::wait(Port* port, uint64_t ticket) {
+#ifdef KMX_USE_ORACLE
+  (void)port;
+  (void)ticket;
+#else
+  check(kmx_batcher_wait(port->batcher, ticket), "evaluating a leaf");
+#endif
+}
+void KatamxLeaf::stats(Port* port, uint64_t& rows, uint64_t& batches) {
+#ifdef KMX_USE_ORACLE
+  rows = port->rows.load();
+  batches = rows;
+#else
+  check(kmx_batcher_stats(port->batcher, &rows, &batches), "reading the leaf batcher's counters");
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

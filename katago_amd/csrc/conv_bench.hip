@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -19,23 +20,12 @@ hipError_t launchVariant(int ks, int cfg, int variant, const ConvArgs& a, hipStr
   typedef TraitsBF16 TR;
 #define V(KS_, WNW_, WN_, D_, ABL_) \
   if(ks == KS_ && cfg == 10 * WNW_ + WN_ && variant == D_ * 1000 + ABL_) return launchOne<TR, KS_, WN_, WNW_, D_, ABL_>(a, st);
-  V(3, 1, 1, 3, 0) V(3, 1, 1, 4, 0) V(3, 1, 1, 5, 0) V(3, 1, 2, 3, 0) V(3, 1, 2, 4, 0) V(3, 1, 3, 3, 0) V(3, 1, 3, 4, 0)
-  V(1, 1, 1, 3, 0) V(1, 1, 1, 4, 0) V(1, 1, 2, 3, 0) V(1, 1, 2, 4, 0) V(3, 2, 3, 4, 0) V(3, 2, 3, 5, 0)
-  V(1, 2, 3, 3, 0) V(1, 2, 3, 3, 1) V(1, 2, 3, 3, 2) V(1, 2, 3, 3, 3) V(1, 2, 3, 3, 4) V(1, 2, 3, 3, 5) V(1, 2, 3, 3, 6) V(1, 2, 3, 3, 7) V(1, 2, 3, 3, 8) V(1, 2, 3, 3, 9) V(1, 2, 3, 3, 12) V(1, 2, 3, 3, 13)
-  V(3, 2, 3, 3, 2048) V(3, 2, 3, 3, 2052) V(3, 2, 3, 3, 2056) V(3, 2, 3, 3, 2049) V(1, 2, 3, 3, 2048) V(3, 1, 3, 2, 2048) V(3, 1, 1, 2, 2048)
-  V(3, 1, 3, 2, 0) V(3, 2, 3, 2, 0) V(3, 2, 3, 3, 0) V(3, 2, 3, 4, 0)
-  V(3, 1, 3, 2, 1) V(3, 1, 3, 2, 2) V(3, 1, 3, 2, 4) V(3, 1, 3, 2, 5) V(3, 1, 3, 2, 8) V(3, 1, 3, 2, 512) V(3, 1, 3, 2, 1024)
-  V(3, 2, 3, 3, 16) V(3, 2, 3, 3, 17) V(3, 2, 3, 3, 33) V(3, 2, 3, 3, 65) V(3, 2, 3, 3, 25) V(3, 2, 3, 3, 41) V(3, 2, 3, 3, 73)
-  V(3, 2, 3, 3, 13) V(3, 2, 3, 3, 7) V(3, 2, 3, 3, 9) V(3, 2, 3, 3, 12) V(3, 2, 3, 3, 3) V(3, 2, 3, 3, 6) V(3, 2, 3, 3, 1) V(3, 2, 3, 3, 2) V(3, 2, 3, 3, 4) V(3, 2, 3, 3, 5) V(3, 2, 3, 3, 8)
-  V(3, 2, 3, 2, 13) V(3, 2, 3, 2, 7) V(3, 2, 3, 2, 9) V(3, 2, 3, 2, 12) V(3, 2, 3, 2, 3) V(3, 2, 3, 2, 6)
-  V(3, 2, 3, 2, 1) V(3, 2, 3, 2, 2) V(3, 2, 3, 2, 4) V(3, 2, 3, 2, 5) V(3, 2, 3, 2, 8) V(3, 2, 3, 2, 512) V(3, 2, 3, 2, 1024)
-  V(3, 1, 2, 2, 0) V(3, 2, 2, 2, 0) V(3, 2, 2, 3, 0)
-  V(3, 2, 3, 4, 2048) /* ring depth 4 with cycle stamps: the unexplained 2x slowdown */ V(3, 2, 3, 3, 4096) V(3, 2, 3, 4, 4096) V(3, 2, 2, 3, 4096) V(3, 2, 3, 3, 6144) V(3, 2, 3, 4, 6144)  // ABL_BP2 (+ ABL_TIMING): barrier on even taps
-  V(1, 1, 3, 2, 0) V(1, 2, 3, 2, 0) V(1, 2, 3, 3, 0)
-  V(3, 2, 3, 3, 8192) V(3, 2, 3, 3, 8192 + 2048)  // ABL_PRIO
-  V(3, 2, 3, 3, 16384) V(3, 2, 3, 3, 16384 + 2048) V(3, 2, 3, 3, 16384 + 1)  // ABL_TWOLOADERS
-  V(1, 1, 3, 2, 1) V(1, 1, 3, 2, 2) V(1, 1, 3, 2, 4) V(1, 1, 3, 2, 5)
-  V(1, 2, 3, 2, 1) V(1, 2, 3, 2, 2) V(1, 2, 3, 2, 4) V(1, 2, 3, 2, 5)
+  // The instantiated variants (each costs ~10 s of compile time; round 1-2 swept ~140 of them, results in profiles/r01*, r02_steps):
+  // cycle stamps of the product shapes, the ablations of the dominant shape, ring depths 2 and 4 of it.
+  V(3, 2, 3, 3, 2048) V(3, 2, 3, 3, 2049) V(3, 2, 3, 3, 2052) V(3, 2, 3, 3, 2056) V(1, 2, 3, 3, 2048) V(3, 1, 3, 2, 2048) V(3, 1, 1, 2, 2048)
+  V(3, 2, 3, 3, 1) V(3, 2, 3, 3, 2) V(3, 2, 3, 3, 4) V(3, 2, 3, 3, 5) V(3, 2, 3, 3, 512) V(3, 2, 3, 3, 1024)
+  V(3, 2, 3, 2, 0) V(3, 2, 3, 4, 0) V(3, 2, 3, 4, 2048)
+  V(3, 2, 3, 3, 16384 + 2048)  // ABL_TWOLOADERS
 #undef V
   return hipErrorInvalidValue;
 }
@@ -117,6 +107,104 @@ double benchConv(int ks, int cfg, int variant, int cin, int cout, int batch, int
   return (double)ms / iters;
 }
 
+
+// ---- two streams, half a launch apart --------------------------------------------------------------------------------
+// Round 2 staggered the second half-batch stream by WHOLE launches (after k launches both streams again start their kernels
+// at the same moment, so the phases of co-resident work-groups stay aligned). This measures what a stagger of a FRACTION of a
+// launch buys: each of `nStreams` streams runs `launches` back-to-back launches of the same layer on its own `batch` boards;
+// stream i first spins for i * delayUs microseconds. Returns the wall time (ms) from the common start to the last stream's end.
+__global__ void spinKernel(unsigned long long ticks100MHz) {
+  const unsigned long long t0 = wall_clock64();
+  while(wall_clock64() - t0 < ticks100MHz) __builtin_amdgcn_s_sleep(8);
+}
+
+double benchConvStreams(int ks, int cfg, int cin, int cout, int batch, int nStreams, double delayUs, int launches, int epilogueMode) {
+  const int dtype = DT_BF16, X = 19, Y = 19, S = X * Y;
+  if(nStreams < 1 || nStreams > 4) throw Error(KMX_ERR_INVALID_ARG, "benchConvStreams: 1..4 streams");
+  const size_t cells = (size_t)batch * S;
+  const int inStride = roundUp(cin, 32), outStride = roundUp(cout, 32);
+  ConvDesc c;
+  c.name = "bench";
+  c.ky = c.kx = ks;
+  c.inC = cin;
+  c.outC = cout;
+  c.w.resize((size_t)ks * ks * cin * cout);
+  uint32_t rng = 777;
+  auto rnd = [&]() {
+    rng = rng * 1664525u + 1013904223u;
+    return ((rng >> 8) & 0xffff) / 65536.0f - 0.5f;
+  };
+  for(float& v : c.w) v = rnd() * 0.1f;
+  BnDesc bn;
+  bn.c = cout;
+  bn.act = KMX_ACT_MISH;
+  bn.scale.assign(cout, 1.0f);
+  bn.bias.assign(cout, 0.1f);
+  FusedConv fc = buildFusedConv(dtype, {{&c, &bn}}, nullptr);
+  std::vector<uint16_t> hin(cells * inStride);
+  for(uint16_t& v : hin) v = floatToBf16Bits(rnd());
+  std::vector<float> ones(cells, 1.0f);
+  DevBuf zero(ZERO_PAGE_ALLOC);
+  struct PerStream {
+    DevBuf in, resid, raw, act, mask;
+    hipStream_t st = nullptr;
+    hipEvent_t done = nullptr;
+    ConvArgs a;
+  };
+  std::vector<std::unique_ptr<PerStream>> ps;
+  for(int i = 0; i < nStreams; i++) {
+    std::unique_ptr<PerStream> p(new PerStream());
+    p->in = DevBuf(hin.size() * 2, false);
+    p->in.upload(hin.data(), hin.size() * 2);
+    p->resid = DevBuf(cells * outStride * 2);
+    p->raw = DevBuf(cells * outStride * 2);
+    p->act = DevBuf(cells * outStride * 2);
+    p->mask = DevBuf(cells * sizeof(float), false);
+    p->mask.upload(ones.data(), cells * sizeof(float));
+    hipCheck(hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking), "stream");
+    hipCheck(hipEventCreate(&p->done), "event");
+    ConvArgs& a = p->a;
+    memset(&a, 0, sizeof(a));
+    a.in = p->in.get(); a.w = fc.w.get(); a.zeroPage = zero.get(); a.inC = inStride; a.nChunks = fc.nChunks; a.coutPad = fc.coutPad;
+    a.N = batch; a.X = X; a.Y = Y;
+    if(epilogueMode == 1) {
+      a.resid = p->resid.get(); a.residC = outStride;
+      a.rawOut = p->raw.get(); a.rawC = outStride; a.rawBegin = 0; a.rawEnd = std::min(fc.coutPad, outStride);
+    }
+    a.actOut = p->act.get(); a.actC = outStride; a.actBegin = 0; a.actEnd = std::min(fc.coutPad, outStride);
+    a.scale = fc.scale.as<float>(); a.bias = fc.bias.as<float>(); a.actKind = KMX_ACT_MISH; a.mask = p->mask.as<float>();
+    ps.push_back(std::move(p));
+  }
+  hipStream_t st0 = nullptr;
+  hipEvent_t e0, e1;
+  hipCheck(hipEventCreate(&e0), "event");
+  hipCheck(hipEventCreate(&e1), "event");
+  auto round = [&](int n) {
+    hipCheck(hipEventRecord(e0, st0), "record");
+    for(auto& p : ps) hipCheck(hipStreamWaitEvent(p->st, e0, 0), "wait");
+    for(int i = 0; i < nStreams; i++)
+      if(i > 0 && delayUs > 0) hipLaunchKernelGGL(spinKernel, dim3(1), dim3(64), 0, ps[i]->st, (unsigned long long)(delayUs * i * 100.0));
+    for(int l = 0; l < n; l++)
+      for(auto& p : ps) hipCheck(launchConv(dtype, ks, cfg, p->a, p->st), "bench conv launch");
+    for(auto& p : ps) {
+      hipCheck(hipEventRecord(p->done, p->st), "record");
+      hipCheck(hipStreamWaitEvent(st0, p->done, 0), "wait");
+    }
+    hipCheck(hipEventRecord(e1, st0), "record");
+    hipCheck(hipStreamSynchronize(st0), "sync");
+  };
+  round(2);
+  round(launches);
+  float ms = 0;
+  hipCheck(hipEventElapsedTime(&ms, e0, e1), "elapsed");
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  for(auto& p : ps) {
+    (void)hipEventDestroy(p->done);
+    (void)hipStreamDestroy(p->st);
+  }
+  return (double)ms;
+}
 
 // ---- MFMA issue-rate microbenchmark: the practical ceiling the convolution's main loop is measured against ----
 // mode bit 1: s_barrier after every 18 MFMAs (the convolution's step); bit 2: 12 ds_read_b128 per step feeding the MFMAs.

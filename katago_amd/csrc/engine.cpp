@@ -913,8 +913,9 @@ bool packRowNHWC(const float* row, int S, int C, unsigned char* out) {
     for(int c = 0; c < C; c++) {  // branch-free: which channels are set in this cell
       uint32_t u;
       memcpy(&u, cell + c, 4);
-      m |= (unsigned)(u != 0u) << c;
-      bad |= (unsigned)(u != 0u && u != 0x3f800000u);
+      const bool zero = (u & 0x7fffffffu) == 0u;  // +0.0f and -0.0f
+      m |= (unsigned)(!zero) << c;
+      bad |= (unsigned)(!zero && u != 0x3f800000u);
     }
     binary = binary && bad == 0;
     const int byte = p >> 3;

@@ -17,6 +17,7 @@ using namespace kmx;
 
 namespace kmx {
 double benchConv(int ks, int wn, int variant, int cin, int cout, int batch, int X, int Y, int epilogueMode, int iters);  // conv_bench.hip
+double benchConvStreams(int ks, int cfg, int cin, int cout, int batch, int nStreams, double delayUs, int launches, int epilogueMode);  // conv_bench.hip
 double benchMfma(int wavesPerWg, int wgs, int mode, int steps, int iters, double* tflops, double* coreMhz);       // conv_bench.hip
 }
 
@@ -48,7 +49,7 @@ struct kmx_handle {
   uint64_t batches = 0;
   Engine& e0() const { return *engines[0]; }
   int ways() const { return (int)engines.size(); }
-  bool splits(int n) const { return engines.size() > 1 && n >= splitMin; }
+  bool splits(int n) const { return engines.size() > 1 && n >= splitMin && n >= ways(); }  // no empty parts
   // rows [begin, begin + count) of part i of an n-row batch: parts differ by at most one row
   void part(int n, int i, int* begin, int* count) const {
     const int k = ways(), base = n / k, extra = n % k;
@@ -477,6 +478,15 @@ int kmx_bench_conv(int ks, int wn, int variant, int cin, int cout, int batch, in
     if(!avg_ms || iters < 1 || batch < 1 || cin < 1 || cout < 1) throw Error(KMX_ERR_INVALID_ARG, "kmx_bench_conv: bad argument");
     (void)deviceCountOrThrow();
     *avg_ms = benchConv(ks, wn, variant, cin, cout, batch, nn_x_len, nn_y_len, epilogue_mode, iters);
+  });
+}
+
+int kmx_bench_conv_streams(int ks, int cfg, int cin, int cout, int batch, int n_streams, double delay_us, int launches, int epilogue_mode,
+                           double* total_ms) {
+  return guarded([&] {
+    if(!total_ms || launches < 1 || batch < 1 || cin < 1 || cout < 1) throw Error(KMX_ERR_INVALID_ARG, "kmx_bench_conv_streams: bad argument");
+    (void)deviceCountOrThrow();
+    *total_ms = benchConvStreams(ks, cfg, cin, cout, batch, n_streams, delay_us, launches, epilogue_mode);
   });
 }
 
