@@ -262,6 +262,10 @@ int kmx_bench_conv(int ks, int wn, int variant, int cin, int cout, int batch, in
  * work-groups buys. total_ms = wall time from the common start to the last stream's end. Kernel tuning instrumentation. */
 int kmx_bench_conv_streams(int ks, int cfg, int cin, int cout, int batch, int n_streams, double delay_us, int launches,
                            int epilogue_mode, double* total_ms);
+/* Average duration (ms) of one launch of the fused seam kernel (192 -> 384 -> 192, mish, bf16) on `batch` 19x19 boards of
+ * synthetic data; timing != 0 runs the instrumented instantiation of the persistent kernel and prints per-wave cycle sums of
+ * its phases on stderr. KMX_PW_V2=0 selects the one-tile-per-work-group kernel. Kernel tuning instrumentation. */
+int kmx_bench_seam(int batch, int iters, int timing, double* avg_ms);
 /* Host-only introspection of the convolution launcher (no device needed): the work-group shape chosen for a kernel size,
  * a padded channel count (multiple of 64) and a batch, and whether a kernel of that shape exists and tiles the channels.
  * tests/test_conv_chooser.py walks every combination the engine can ask for. */

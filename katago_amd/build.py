@@ -17,9 +17,12 @@ OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libkatamx.so")
 
 SOURCES = ["conv_mfma.hip", "pointwise.hip", "conv_bench.hip", "misc_kernels.hip", "transformer_kernels.hip", "engine.cpp", "model_desc.cpp", "kmx_api.cpp", "batcher.cpp"]
-HEADERS = ["kernels.h", "device_common.h", "conv_kernel.h", "pointwise_kernel.h", "engine.h", "model_desc.h", os.path.join("..", "..", "include", "katamx.h")]
+HEADERS = ["kernels.h", "device_common.h", "conv_kernel.h", "pointwise_kernel.h", "pointwise2_kernel.h", "engine.h", "model_desc.h", os.path.join("..", "..", "include", "katamx.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-x", "hip"]
+# -fno-slp-vectorize: left on, the SLP vectoriser packs adjacent fp32 epilogue arithmetic into v_pk_*_f32 instructions - which
+# issue no faster than two plain ones on gfx950 and cost ~1.6 v_mov_b64 per value to marshal operands into aligned register
+# pairs (233 of them per tile of the seam kernel; profiles/r03_steps)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-x", "hip"]
 
 
 def _mtime(p):

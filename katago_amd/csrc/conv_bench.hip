@@ -206,6 +206,78 @@ double benchConvStreams(int ks, int cfg, int cin, int cout, int batch, int nStre
   return (double)ms;
 }
 
+// ---- the seam kernel alone (192 -> 384 -> 192, mish, bf16) on `batch` boards of 19x19 ----------------------------------------
+// timing != 0 runs the instrumented instantiation of the persistent kernel and prints work-group 0's per-wave phase sums.
+double benchSeam(int batch, int iters, int timing) {
+  const int dtype = DT_BF16, S = 361, C1 = 192, C2 = 384, C3 = 192;
+  const size_t cells = (size_t)batch * S;
+  uint32_t rng = 4711;
+  auto rnd = [&]() {
+    rng = rng * 1664525u + 1013904223u;
+    return ((rng >> 8) & 0xffff) / 65536.0f - 0.5f;
+  };
+  auto conv1x1 = [&](int ic, int oc) {
+    ConvDesc c;
+    c.name = "seam"; c.ky = c.kx = 1; c.inC = ic; c.outC = oc;
+    c.w.resize((size_t)ic * oc);
+    for(float& v : c.w) v = rnd() * 0.1f;
+    return c;
+  };
+  auto bnOf = [&](int c) {
+    BnDesc b;
+    b.c = c; b.act = KMX_ACT_MISH;
+    b.scale.assign(c, 1.0f);
+    b.bias.assign(c, 0.1f);
+    return b;
+  };
+  const ConvDesc cd1 = conv1x1(C1, C2), cd2 = conv1x1(C2, C3);
+  const BnDesc bn1 = bnOf(C2), bn2 = bnOf(C3);
+  FusedConv f1 = buildFusedConv(dtype, {{&cd1, &bn1}}, nullptr), f2 = buildFusedConv(dtype, {{&cd2, &bn2}}, nullptr);
+  std::vector<uint16_t> hx(cells * C1), hr(cells * C2);
+  for(uint16_t& v : hx) v = floatToBf16Bits(rnd());
+  for(uint16_t& v : hr) v = floatToBf16Bits(rnd());
+  DevBuf x(hx.size() * 2, false), trunk(hr.size() * 2, false), midRaw(cells * C3 * 2), midAct(cells * C3 * 2), zero(ZERO_PAGE_ALLOC);
+  x.upload(hx.data(), hx.size() * 2);
+  trunk.upload(hr.data(), hr.size() * 2);
+  std::vector<float> ones(cells, 1.0f);
+  DevBuf mask(cells * sizeof(float), false);
+  mask.upload(ones.data(), cells * sizeof(float));
+  DevBuf dbg(8 * 9 * sizeof(unsigned long long));
+  PwPairArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.in = x.get(); pa.inC = C1; pa.w1 = f1.w.get();
+  pa.resid = trunk.get(); pa.rawOut = trunk.get(); pa.trunkC = C2;
+  pa.scale1 = f1.scale.as<float>(); pa.bias1 = f1.bias.as<float>(); pa.actKind1 = KMX_ACT_MISH;
+  pa.w2 = f2.w.get(); pa.rawOut2 = midRaw.get(); pa.actOut2 = midAct.get(); pa.midC = C3;
+  pa.scale2 = f2.scale.as<float>(); pa.bias2 = f2.bias.as<float>(); pa.actKind2 = KMX_ACT_MISH;
+  pa.mask = mask.as<float>(); pa.cells = (long long)cells; pa.zeroPage = zero.get();
+  pa.dbg = timing ? dbg.as<unsigned long long>() : nullptr;
+  hipStream_t st = nullptr;
+  auto launch = [&]() { hipCheck(launchPointwisePair(dtype, C1, C2, C3, pa, st), "bench seam launch"); };
+  for(int i = 0; i < 3; i++) launch();
+  hipCheck(hipStreamSynchronize(st), "sync");
+  hipEvent_t e0, e1;
+  hipCheck(hipEventCreate(&e0), "event");
+  hipCheck(hipEventCreate(&e1), "event");
+  hipCheck(hipEventRecord(e0, st), "record");
+  for(int i = 0; i < iters; i++) launch();
+  hipCheck(hipEventRecord(e1, st), "record");
+  hipCheck(hipStreamSynchronize(st), "sync");
+  float ms = 0;
+  hipCheck(hipEventElapsedTime(&ms, e0, e1), "elapsed");
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if(timing) {
+    unsigned long long h[72];
+    hipCheck(hipMemcpy(h, dbg.get(), sizeof(h), hipMemcpyDeviceToHost), "copy timing");
+    for(int w = 0; w < 8; w++)
+      fprintf(stderr, "[seam timing] wave %d: top %llu | gemm1(0) %llu | P1 wait+barrier %llu | gemm1 next %llu | epilogue 1 %llu | P2/P3 wait+barrier %llu "
+                      "| gemm2 steps %llu | epilogue 2 %llu | kernel %llu cycles\n",
+              w, h[w * 9 + 0], h[w * 9 + 1], h[w * 9 + 2], h[w * 9 + 3], h[w * 9 + 4], h[w * 9 + 5], h[w * 9 + 6], h[w * 9 + 7], h[w * 9 + 8]);
+  }
+  return (double)ms / iters;
+}
+
 // ---- MFMA issue-rate microbenchmark: the practical ceiling the convolution's main loop is measured against ----
 // mode bit 1: s_barrier after every 18 MFMAs (the convolution's step); bit 2: 12 ds_read_b128 per step feeding the MFMAs.
 template <int MODE>

@@ -90,34 +90,26 @@ __device__ __forceinline__ float minPlain(float x, float c) {
 #endif
 }
 
-// Activations in fp32. Mish = x tanh(softplus(x)) with softplus linearised above 20 as in the reference
-// (eigenbackend.cpp:754). With u = 1 + e^min(x,20): tanh(log u) = (u^2 - 1) / (u^2 + 1), so
+// Activations in fp32. Mish = x tanh(softplus(x)) (the reference linearises softplus above 20, eigenbackend.cpp:754: there
+// tanh is 1 to the last bit). With u = 1 + e^x: tanh(log u) = (u^2 - 1) / (u^2 + 1), so
 //     mish(x) = x - 2x / (u^2 + 1)
-// - for x > 20 the quotient is below 1e-17 and the result is x exactly, as the saturated tanh gives. This form needs 5 plain
-// vector instructions per value where x n / (n + 2), n = e (e + 2) needed 8, and all of them pair up into the packed-fp32
-// instructions (v_pk_mul/add/fma_f32); the epilogues are bound by vector-ALU issue (~4 cycles per wave instruction), and the
-// activation is most of what they issue. The two transcendental instructions per value (v_exp_f32, v_rcp_f32, quarter rate)
-// become three per PAIR in actMish2: one reciprocal of the product serves both quotients (the product stays below 6e34).
-// Absolute error ~1e-7 |x| (the subtraction cancels for very negative x, where mish itself is below 1e-5): far inside the
-// 16-bit rounding of every output these feed.
+// - 5 plain vector instructions and 2 transcendentals (v_exp_f32, v_rcp_f32) per value, no clamp: for large x, e^x and the
+// denominator overflow to +inf, the reciprocal is 0 and the result is x exactly; for very negative x it is x - x = 0 where
+// mish itself is below 1e-30. Absolute error ~1e-7 |x|: far inside the 16-bit rounding of every output these feed.
+// Round 2 evaluated PAIRS with packed-fp32 instructions and one shared reciprocal (v_pk_*_f32, 3 transcendentals per pair).
+// The round-3 ISA of the seam kernel showed what that costs: 80 v_mov_b64 per 16 values to marshal operands into aligned
+// register pairs, on top of packed instructions that issue no faster than two plain ones (MI355X_MICROARCH.md: packed fp32 is
+// "an anti-lever" beside MFMAs). Plain scalar code it is, in every kernel (the epilogues stay bit-identical to one another).
 __device__ __forceinline__ float actMish(float x) {
-  const float e = __builtin_amdgcn_exp2f(minPlain(x * 1.4426950408889634f, 20.0f * 1.4426950408889634f));
+  const float e = __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
   const float u = e + 1.0f;
-  return x + (-2.0f * x) * __builtin_amdgcn_rcpf(u * u + 1.0f);
+  return __builtin_fmaf(x * -2.0f, __builtin_amdgcn_rcpf(__builtin_fmaf(u, u, 1.0f)), x);
 }
 __device__ __forceinline__ f32x2 actMish2(f32x2 x) {
-  const f32x2 tl = x * 1.4426950408889634f;
-  f32x2 e;
-  e[0] = __builtin_amdgcn_exp2f(minPlain(tl[0], 20.0f * 1.4426950408889634f));
-  e[1] = __builtin_amdgcn_exp2f(minPlain(tl[1], 20.0f * 1.4426950408889634f));
-  const f32x2 u = e + 1.0f;
-  const f32x2 q = u * u + 1.0f;
-  const float r = __builtin_amdgcn_rcpf(q[0] * q[1]);
-  f32x2 inv;
-  inv[0] = q[1];
-  inv[1] = q[0];
-  inv = inv * r;  // 1 / q[0], 1 / q[1]
-  return x + (x * -2.0f) * inv;
+  f32x2 y;
+  y[0] = actMish(x[0]);
+  y[1] = actMish(x[1]);
+  return y;
 }
 __device__ __forceinline__ float actSilu(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-x * 1.4426950408889634f));

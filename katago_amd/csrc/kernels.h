@@ -83,6 +83,7 @@ struct PwPairArgs {
   const float* mask;     // [cells]
   long long cells;       // N * S
   const void* zeroPage;  // >= 64 readable zero bytes
+  unsigned long long* dbg;  // instrumentation only (conv_bench.hip benchSeam): per-wave cycle sums of the persistent kernel's phases
 };
 hipError_t launchPointwisePair(int dtype, int c1, int c2, int c3, const PwPairArgs& a, hipStream_t stream);
 bool pointwisePairSupported(int c1, int c2, int c3);  // is there a kernel for these channel counts?

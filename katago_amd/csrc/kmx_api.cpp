@@ -18,6 +18,7 @@ using namespace kmx;
 namespace kmx {
 double benchConv(int ks, int wn, int variant, int cin, int cout, int batch, int X, int Y, int epilogueMode, int iters);  // conv_bench.hip
 double benchConvStreams(int ks, int cfg, int cin, int cout, int batch, int nStreams, double delayUs, int launches, int epilogueMode);  // conv_bench.hip
+double benchSeam(int batch, int iters, int timing);  // conv_bench.hip
 double benchMfma(int wavesPerWg, int wgs, int mode, int steps, int iters, double* tflops, double* coreMhz);       // conv_bench.hip
 }
 
@@ -487,6 +488,14 @@ int kmx_bench_conv_streams(int ks, int cfg, int cin, int cout, int batch, int n_
     if(!total_ms || launches < 1 || batch < 1 || cin < 1 || cout < 1) throw Error(KMX_ERR_INVALID_ARG, "kmx_bench_conv_streams: bad argument");
     (void)deviceCountOrThrow();
     *total_ms = benchConvStreams(ks, cfg, cin, cout, batch, n_streams, delay_us, launches, epilogue_mode);
+  });
+}
+
+int kmx_bench_seam(int batch, int iters, int timing, double* avg_ms) {
+  return guarded([&] {
+    if(!avg_ms || iters < 1 || batch < 1) throw Error(KMX_ERR_INVALID_ARG, "kmx_bench_seam: bad argument");
+    (void)deviceCountOrThrow();
+    *avg_ms = benchSeam(batch, iters, timing);
   });
 }
 

@@ -1,7 +1,9 @@
 // pointwise.hip — instantiations and dispatch of the fused 1x1 -> 1x1 seam kernel (pointwise_kernel.h).
+#include <atomic>
 #include <cstdlib>
 
 #include "pointwise_kernel.h"
+#include "pointwise2_kernel.h"
 
 namespace kmx {
 
@@ -23,8 +25,43 @@ int pwWaves() {
   return w;
 }
 
+// The persistent, software-pipelined form (pointwise2_kernel.h) exists for the shape and activation of b18c384nbt
+// (192 -> 384 -> 192, mish) and needs the activated trunk image to stay in LDS (actOut null, as the engine passes it);
+// everything else, and KMX_PW_V2=0, runs the one-tile-per-work-group kernel above.
+bool persistentWanted() {
+  static const bool on = [] {
+    const char* e = getenv("KMX_PW_V2");
+    return e == nullptr || atoi(e) != 0;
+  }();
+  return on;
+}
+int numComputeUnits() {  // per device: one persistent work-group per CU (KMX_PW_GRID overrides: tests walk several tiles per group)
+  static const int forced = [] {
+    const char* e = getenv("KMX_PW_GRID");
+    return e ? atoi(e) : 0;
+  }();
+  if(forced > 0) return forced;
+  constexpr int MAX_DEVICES = 64;
+  static std::atomic<int> cus[MAX_DEVICES];
+  int dev = 0;
+  if(hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return 256;
+  int n = cus[dev].load(std::memory_order_acquire);
+  if(n == 0) {
+    hipDeviceProp_t prop;
+    n = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    cus[dev].store(n, std::memory_order_release);
+  }
+  return n;
+}
+
 template <class TR>
 hipError_t launchT(int c1, int c2, int c3, const PwPairArgs& a, hipStream_t stream) {
+  if(c1 == 192 && c2 == 384 && c3 == 192 && a.actOut == nullptr && a.actKind1 == KMX_ACT_MISH && a.actKind2 == KMX_ACT_MISH &&
+     pwWaves() == 8 && persistentWanted())
+  {
+    if(a.dbg != nullptr) return pw2::launchPersistent<TR, 6, 12, 3, KMX_ACT_MISH, KMX_ACT_MISH, true>(a, numComputeUnits(), stream);
+    return pw2::launchPersistent<TR, 6, 12, 3, KMX_ACT_MISH, KMX_ACT_MISH>(a, numComputeUnits(), stream);
+  }
   // the 4-wave shape: a wave of GEMM 1 owns C2/2 channels (WN1 doubles), of GEMM 2 C3/2 (WN2 as is)
 #define KMX_PW(K1_, WN1_, WN2_) \
   if(c1 == 32 * K1_ && c2 == 128 * WN1_ && c3 == 64 * WN2_) \

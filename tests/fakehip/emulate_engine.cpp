@@ -22,7 +22,9 @@ bool pointwisePairSupported(int, int, int) { return false; }
 hipError_t launchPointwisePair(int, int, int, int, const PwPairArgs&, hipStream_t) { return 801; }
 #endif
 double benchConv(int, int, int, int, int, int, int, int, int, int) { return 0.0; }
+double benchConvStreams(int, int, int, int, int, int, double, int, int) { return 0.0; }
 double benchMfma(int, int, int, int, int, double*, double*) { return 0.0; }
+double benchSeam(int, int, int) { return 0.0; }
 
 #ifndef KMX_EMU_REAL_CONV  // the "real convolution" build compiles a transformed copy of conv_mfma.hip / conv_kernel.h instead
 namespace {

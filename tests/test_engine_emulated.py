@@ -69,6 +69,17 @@ PW_REWRITES = [
 ]
 
 
+# pointwise2_kernel.h (the persistent, software-pipelined seam kernel)
+PW2_REWRITES = [
+    (r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\(N\) : "memory"\);', ";", 1),
+    (r'asm volatile\("s_waitcnt lgkmcnt\(0\)" ::: "memory"\);', ";", 1),
+    (r'asm volatile\("" : "\+s"\((w1|w2)\)\);', ";", 2),
+    (r'extern __shared__ __attribute__\(\(aligned\(256\)\)\) char smemPw2\[\];', "char* const smemPw2 = (char*)emu::dynLds();", 1),
+    (r'__builtin_amdgcn_global_load_lds\(', "emu::globalLoadLds(", 2),
+    (r'__attribute__\(\(amdgpu_waves_per_eu\(2, 2\)\)\)', "", 1),
+]
+
+
 @pytest.fixture(scope="module")
 def emu_full_lib(tmp_path_factory):
     import re
@@ -86,6 +97,11 @@ def emu_full_lib(tmp_path_factory):
         src, k = re.subn(pat, rep, src)
         assert k == count, "pointwise_kernel.h changed: %r matched %d times, expected %d" % (pat, k, count)
     open(os.path.join(d, "pointwise_kernel.h"), "w").write(src)
+    src = open(os.path.join(CSRC, "pointwise2_kernel.h")).read()
+    for pat, rep, count in PW2_REWRITES:
+        src, k = re.subn(pat, rep, src)
+        assert k == count, "pointwise2_kernel.h changed: %r matched %d times, expected %d" % (pat, k, count)
+    open(os.path.join(d, "pointwise2_kernel.h"), "w").write(src)
     shutil.copy(os.path.join(CSRC, "pointwise.hip"), os.path.join(d, "pointwise.hip"))
     cxx = ["/opt/rocm/lib/llvm/bin/clang++", "-x", "c++", "-std=c++20", "-O2", "-fPIC", "-pthread", "-I" + os.path.join(FAKE, "emul"), "-I" + FAKE,
            "-I" + CSRC, "-DKMX_EMU_REAL_CONV"]
@@ -293,3 +309,38 @@ print("RESULT " + json.dumps(out))
             ulp = 2.0 ** -7 if dtype == "bf16" else 2.0 ** -10
             for e, s, k in zip(r["err"], r["scale"], (1, 4, 4)):
                 assert e <= 2 * ulp * max(s, 1.0) * k, (waves, dtype, r)
+
+
+def test_persistent_seam_kernel_emulated(emu_full_lib):
+    """pointwise2_kernel.h on the CPU: a work-group that walks three tiles (two full, one tail of 82 cells; KMX_PW_GRID=1) and two
+    work-groups that share them (KMX_PW_GRID=2) - the ring-slot reuse, the part order and the prefetch of the next tile's X are
+    all exercised with IMMEDIATE copies (a request into a slot some wave still reads would show as a wrong answer); bit for bit
+    against the one-tile-per-group kernel (KMX_PW_V2=0) and the two emulated convolution launches. The s_waitcnt counts are not
+    exercised here: that is tests/test_gpu_pointwise.py on the MI355X."""
+    code = r"""
+import sys, json
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+from katago_amd import capi
+capi._lib = capi.load_library(path=sys.argv[1])
+from katago_amd import nninterface as nn
+import pointwise_ref as ref
+rng = np.random.default_rng(5)
+batch, L = 2, 13
+mask = np.ones((batch, L, L), np.float32); mask[1, :, 9:] = 0; mask[0, 11:, :] = 0
+x, resid, w1, s1, b1, w2, s2, b2, m = ref.make_case(rng, batch * L * L, 192, 384, 192, mask.reshape(-1))
+fused = nn.testEvaluatePointwisePair(batch, L, L, "bf16", x, resid, w1, s1, b1, 2, w2, s2, b2, 2, m, True)
+plain = nn.testEvaluatePointwisePair(batch, L, L, "bf16", x, resid, w1, s1, b1, 2, w2, s2, b2, 2, m, False)
+want = ref.seam(x, resid, w1, s1, b1, 2, w2, s2, b2, 2, m, "bf16")
+print("RESULT " + json.dumps({"same": [bool(np.array_equal(f, p)) for f, p in zip(fused, plain)],
+                              "err": [float(np.abs(f - w).max()) for f, w in zip(fused, want)], "scale": [float(np.abs(w).max()) for w in want],
+                              "off_board_zero": bool((fused[2][m != 1.0] == 0).all())}))
+""" % (REPO, os.path.join(REPO, "tests"))
+    for env in ({"KMX_PW_GRID": "1"}, {"KMX_PW_GRID": "2"}, {"KMX_PW_V2": "0"}):
+        p = subprocess.run([sys.executable, "-c", code, emu_full_lib], capture_output=True, text=True, timeout=1800, env=dict(os.environ, **env))
+        assert p.returncode == 0 and "RESULT " in p.stdout, (p.stdout + p.stderr)[-3000:]
+        r = json.loads(p.stdout.split("RESULT ")[1])
+        print(env, r)
+        assert all(r["same"]) and r["off_board_zero"], (env, r)
+        for e, sc, k in zip(r["err"], r["scale"], (1, 4, 4)):
+            assert e <= 2 * 2.0 ** -7 * max(sc, 1.0) * k, (env, r)

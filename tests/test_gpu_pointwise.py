@@ -15,9 +15,11 @@ C1, C2, C3 = 192, 384, 192  # b18c384nbt: mid -> trunk -> mid
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("batch,L,acts", [(1, 19, (2, 2)), (3, 13, (2, 1)), (2, 9, (1, 0)), (40, 19, (2, 2))])
+@pytest.mark.parametrize("batch,L,acts", [(1, 19, (2, 2)), (3, 13, (2, 1)), (2, 9, (1, 0)), (40, 19, (2, 2)), (131, 19, (2, 2)), (256, 19, (2, 2))])
 def test_seam_kernel_against_numpy_and_against_two_launches(dtype, batch, L, acts):
-    """cells = batch * L * L is in general not a multiple of the 128-cell tile (tail tile), boards carry masks."""
+    """cells = batch * L * L is in general not a multiple of the 128-cell tile (tail tile), boards carry masks. (mish, mish) on
+    19x19 runs the persistent kernel (pointwise2_kernel.h): batch 131 gives 370 tiles - work-groups with two tiles and with one -
+    batch 256 the bench shape (722 tiles: three and two per work-group)."""
     rng = np.random.default_rng(batch * 100 + L)
     cells = batch * L * L
     mask = np.ones((batch, L, L), np.float32)
