@@ -24,6 +24,7 @@
 #include <unordered_map>
 
 #include "core/test.h"
+#include "katamx_fibers.h"
 #include "katamx_leaf.h"
 #include "neuralnet/modelversion.h"
 
@@ -513,7 +514,10 @@ void KatamxNNEval::finish(NNEvaluator& nnEval, Leaf& leaf) {
   leaf.inFlight = false;
   if(leaf.port != NULL) {
     try {
-      KatamxLeaf::wait(leaf.port, leaf.ticket);
+      if(!leaf.ticketCollected)
+        KatamxLeaf::wait(leaf.port, leaf.ticket);
+      else if(leaf.collectError)
+        std::rethrow_exception(leaf.collectError);
     }
     catch(...) {
       flightEnd(st);
@@ -760,6 +764,16 @@ void NNEvaluator::evaluate(
 ) {
   KatamxNNEval::Leaf leaf;
   KatamxNNEval::begin(*this, board, history, nextPlayer, sgfMeta, nnInputParams, buf, skipCache, includeOwnerMap, leaf);
+  // A search thread that runs on a fiber (katamx_fibers.h) gives its OS thread to the next descent while the row is on the device
+  if(leaf.inFlight && leaf.port != NULL && KatamxFibers::onFiber()) {
+    try {
+      leaf.ticketCollected = KatamxFibers::park(leaf.port, leaf.ticket);
+    }
+    catch(...) {
+      leaf.ticketCollected = true;
+      leaf.collectError = std::current_exception();
+    }
+  }
   KatamxNNEval::finish(*this, leaf);
 }
 
@@ -799,6 +813,10 @@ std::shared_ptr<NNOutput>* NNEvaluator::averageMultipleSymmetries(
 }
 
 void NNEvaluator::waitForNextNNEvalIfAny() {
+  // on a fiber the evaluations "in flight" may all belong to parked fibers of this very OS thread: let them finish instead of
+  // sleeping on completions nobody else would produce
+  if(KatamxFibers::yieldToOthers())
+    return;
   const std::shared_ptr<EvalState> st = stateOf(this);
   std::unique_lock<std::mutex> lock(st->flightMutex);
   if(st->inFlight <= 0)

@@ -13,10 +13,12 @@
 //     KatamxNNEval::begin   hash -> cache -> featurise -> submit; returns at once (leaf.ready() if it was a cache hit)
 //     KatamxNNEval::finish  wait for the ticket -> post-process -> cache store; the result is in leaf.buf->result
 // so that a search thread can descend again (virtual losses applied) before it waits. begin + finish on the same thread
-// is exactly evaluate(). integration/leaf_search.cpp is a caller that keeps K leaves per thread in flight.
+// is exactly evaluate(). The caller that keeps K leaves per OS thread in flight is the reference's own search, run on fibers
+// (integration/katamx_fibers.h): evaluate() parks the calling fiber between begin and finish.
 #ifndef KATAMX_NNEVAL_H_
 #define KATAMX_NNEVAL_H_
 
+#include <exception>
 #include <memory>
 
 #include "neuralnet/nneval.h"
@@ -40,6 +42,8 @@ struct Leaf {
   bool inFlight = false;   // handed to the device, finish() must be called
   bool done = false;       // buf->result is final (cache hit, or finish() ran)
   bool skipCacheStore = false;
+  bool ticketCollected = false;  // the ticket was waited for while the owner's fiber was parked (katamx_fibers.h); finish() must not wait again
+  std::exception_ptr collectError;  // ... and this is what that wait threw
   std::shared_ptr<NNOutput> cachedWithoutOwnerMap;  // nneval.cpp:922-936: only the ownership map was missing
   float value[3];
   float score[6];

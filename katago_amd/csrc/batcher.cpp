@@ -22,6 +22,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -43,6 +44,20 @@ class Batcher {
   Batcher(const ModelDesc& model, int nnXLen, int nnYLen, int maxBatch, int dtype, int device, int maxInFlight, int numSlots)
     : maxBatch_(maxBatch), maxInFlight_(maxInFlight) {
     S_ = nnXLen * nnYLen;
+    // Seal at the device's granule. The convolutions give a board to a work-group and a work-group to a CU: a pass over 430 boards
+    // on 256 CUs costs what a pass over 512 does. A filling batch therefore counts as FULL at (a multiple of) the CU count and
+    // goes behind the running one at once, instead of growing to an odd size while the device is busy - measured with the
+    // reference's benchmark at 1024 leaves in flight: avg batch 432 -> 256, 34.8 k -> see profiles/r03_steps/fibers.txt.
+    // KMX_BATCH_QUANTUM overrides (0 = off: only max_batch_size seals).
+    {
+      int q = -1;
+      if(const char* e = getenv("KMX_BATCH_QUANTUM")) q = atoi(e);
+      if(q < 0) {
+        hipDeviceProp_t prop;
+        q = hipGetDeviceProperties(&prop, device < 0 ? 0 : device) == hipSuccess ? prop.multiProcessorCount : 0;
+      }
+      sealAt_ = q > 0 && q < maxBatch ? q : maxBatch;
+    }
     for(int i = 0; i < numSlots; i++) slots_.emplace_back();
     for(Slot& s : slots_) {
       s.eng.reset(new Engine(model, nnXLen, nnYLen, maxBatch, dtype, device));
@@ -108,7 +123,7 @@ class Batcher {
         Pending& p = pending_[ticket];
         p.slot = si;
         s.rows[r] = RowOut{ticket, outPolicy, outValue, outScore, outOwnership};
-        if(s.count == maxBatch_) {  // full: no further reservations, the next row opens a new batch
+        if(s.count == sealAt_) {  // full: no further reservations, the next row opens a new batch
           s.state = SEALED;
           sealed_.push_back(filling_);
           filling_ = -1;
@@ -289,7 +304,7 @@ class Batcher {
     }
   }
 
-  int maxBatch_, maxInFlight_, S_ = 0, cin_ = 0, gin_ = 0, min_ = 0;
+  int maxBatch_, maxInFlight_, sealAt_ = 0, S_ = 0, cin_ = 0, gin_ = 0, min_ = 0;
   std::deque<Slot> slots_;  // a Slot holds a condition variable: never moved
   std::mutex mu_;
   std::condition_variable cvWork_, cvComplete_, cvFree_;
