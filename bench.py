@@ -18,9 +18,16 @@ Rank 0 prints ONE JSON line, including
                  would understate `value`); min(K, 20) of the same steps are then repeated with the events on and that pass gives
                  `roofline` (its own ms_per_step is reported next to it); that pass runs the batch on ONE stream so that
                  a launch has the chip to itself, whereas the timed pass uses the product default for batch 256 — two
-                 half-batches on two streams, whose kernels share the CUs (+6 % evals/s). `traffic` = HBM bytes per launch from the
-                 rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, the gfx950 correction of
-                 MI355X_MICROARCH.md), or null when no committed measurement matches this kernel;
+                 half-batches on two streams, whose kernels share the CUs (+6 % evals/s). `traffic` = HBM bytes per launch measured
+                 IN THIS RUN when --pmc is given (bench.py re-runs itself for 3 steps under `rocprofv3 --pmc FETCH_SIZE` and
+                 `--pmc WRITE_SIZE`, separate passes, and applies the gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE x2),
+                 null otherwise - a constant read from a committed file is not a measurement of the run that prints it;
+  roofline_seam: the second kernel family (the fused 1x1 -> 1x1 seam between nested-bottleneck blocks, HBM-bound): algorithmic
+                 bytes per launch / average launch duration of the same instrumented pass, against 8 TB/s;
+  callers      : (N = 1, outside the timed region, ~15 s; --no-callers skips) what the callers of the path get on this box:
+                 host rows through the persistent leaf batcher (katago_amd/leaf_pump, this repo's C++ consumer of the C ABI)
+                 and, when oracle/_ref/katago_hipx was built, the reference's own `benchmark` (nnEvals/s as
+                 cpp/program/playutils.cpp:843,991-1000 defines it) from its unmodified search on 1024 fibers;
   cpu_baseline : the CPU oracle (a port of the reference's Eigen path; Eigen itself is not buildable offline)
                  timed on this host's cores on a bounded sample of the same workload. Reported, not optimised against.
 """
@@ -38,6 +45,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
 
 
 def synthetic_rows(n, seed):
@@ -79,19 +87,104 @@ def cpu_baseline(model_path, batch_rows, min_seconds=10.0, max_seconds=30.0):
             "sample": "%d b18c384nbt 19x19 evals in batches of %d, fp32 C oracle (OpenMP), %.1f s" % (rows, batch_rows, el)}
 
 
-def committed_traffic(kernel, args):
-    """HBM bytes per launch of `kernel` from the newest profiles/*/traffic.json whose workload matches, else None."""
-    import glob
+def measured_traffic(args):
+    """HBM bytes per launch of the two dominant kernel families, measured NOW: this script re-run for 3 steps under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (counters in their own runs, one stream so that a launch is a whole
+    batch), summed per kernel over its dispatches. FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts the 128-byte
+    requests of wide streaming reads at 64 bytes and is doubled (MI355X_MICROARCH.md, HBM section)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
 
-    best = None
-    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*", "traffic.json"))):
-        try:
-            t = json.load(open(f))
-        except (OSError, ValueError):
-            continue
-        if t.get("kernel") == kernel and t.get("model") == args.model and t.get("batch") == args.batch and t.get("dtype") == args.dtype:
-            best = t
-    return None if best is None else {"hbm_bytes_per_launch": best["hbm_bytes_per_launch"], "source": best.get("source")}
+    if shutil.which("rocprofv3") is None:
+        return None
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import rocpd_summary
+
+    keep = os.path.join(REPO, "gpurun_out")
+    d = os.path.join(keep, "bench_pmc") if os.path.isdir(keep) else tempfile.mkdtemp(prefix="kmx_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d)
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-profile", "--no-callers",
+           "--batch", str(args.batch), "--model", args.model, "--dtype", args.dtype]
+    env = dict(os.environ, KMX_SPLIT_MIN="0")
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        r = subprocess.run(["rocprofv3", "--pmc", c, "-d", os.path.join(d, "benchpmc_" + c), "-o", "bench", "--"] + cmd,
+                           capture_output=True, text=True, timeout=600, env=env, cwd=os.environ.get("TMPDIR", "/tmp"))
+        if r.returncode != 0:
+            return {"error": "rocprofv3 --pmc %s failed: %s" % (c, (r.stdout + r.stderr)[-300:])}
+    rocpd_summary.main(d, os.path.join(d, "summary"))
+
+    def per_dispatch(counter, key):
+        tot = disp = 0.0
+        for r in csv.DictReader(open(os.path.join(d, "summary", "benchpmc_%s_pmc.csv" % counter))):
+            if r["Counter"] == counter and key in r["Kernel"]:
+                tot += float(r["Sum"])
+                disp += float(r["Dispatches"])
+        return (tot / disp, int(disp)) if disp else (None, 0)
+
+    out = {}
+    for name, key in (("conv3x3", "KS=3"), ("conv1x1_pair", "pointwisePair")):
+        f, nf = per_dispatch("FETCH_SIZE", key)
+        w, nw = per_dispatch("WRITE_SIZE", key)
+        if f is not None and w is not None:
+            out[name] = {"hbm_bytes_per_launch": round((2.0 * f + w) * 1024.0), "fetch_kib_raw": round(f, 1), "write_kib_raw": round(w, 1),
+                         "dispatches": [nf, nw],
+                         "source": "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 3 --warmup 2`, one stream; "
+                                   "FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE x1"}
+    return out
+
+
+CALLER_CFG = """logDir = %s
+logAllGTPCommunication = false
+logSearchInfo = false
+logToStderr = false
+rules = tromp-taylor
+allowResignation = false
+maxVisits = 200
+numSearchThreads = 8
+nnCacheSizePowerOfTwo = 18
+nnMutexPoolSizePowerOfTwo = 14
+nnRandomize = true
+ponderingEnabled = false
+lagBuffer = 1.0
+searchFactorAfterOnePass = 0.5
+searchFactorAfterTwoPass = 0.25
+searchFactorWhenWinning = 0.4
+searchFactorWhenWinningThreshold = 0.95
+nnMaxBatchSize = 256
+numNNServerThreadsPerModel = 2
+"""
+
+
+def caller_rates(model_path, tmp):
+    """What the CALLERS of the path get on this box (outside the timed region): (1) host rows through the persistent leaf batcher
+    from this repo's C++ consumer of the C ABI; (2) the reference's `benchmark` - its own definition of nnEvals/s - from its
+    unmodified search running 1024 search threads as fibers on 64 OS threads, through this repo's NNEvaluator."""
+    import re
+    import subprocess
+
+    out = {}
+    pump = os.path.join(REPO, "katago_amd", "leaf_pump")
+    if os.path.exists(pump):
+        r = subprocess.run([pump, model_path, "19", "256", "2", "8", "128", "3"], capture_output=True, text=True, timeout=120)
+        if r.returncode == 0:
+            out["host_rows_through_batcher_per_s"] = round(json.loads(r.stdout.strip().splitlines()[-1])["rows_per_s"], 1)
+    hipx = os.path.join(REPO, "oracle", "_ref", "katago_hipx")
+    if os.path.exists(hipx):
+        cfg = os.path.join(tmp, "kmx_bench_callers.cfg")
+        with open(cfg, "w") as f:
+            f.write(CALLER_CFG % os.path.join(tmp, "kmx_bench_gtp_logs"))
+        env = dict(os.environ, KATAMX_LEAVES_PER_THREAD="16")
+        r = subprocess.run([hipx, "benchmark", "-model", model_path, "-config", cfg, "-v", "8000", "-t", "1024", "-boardsize", "19", "-n", "4"],
+                           capture_output=True, text=True, timeout=300, env=env, cwd=tmp)
+        m = re.findall(r"visits/s = ([\d.]+) nnEvals/s = ([\d.]+).*avgBatchSize = ([\d.]+)", (r.stdout + r.stderr).replace("\r", "\n"))
+        if r.returncode == 0 and m:
+            out["reference_benchmark_nn_evals_per_s"] = float(m[-1][1])
+            out["reference_benchmark"] = ("katago benchmark -v 8000 -t 1024 -boardsize 19 (4 positions), unmodified reference search on fibers "
+                                          "(16 per OS thread), this repo's NNEvaluator + leaf batcher: %s visits/s, avg device batch %s rows" % (m[-1][0], m[-1][2]))
+    return out
 
 
 def main():
@@ -101,7 +194,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--model", default="b18c384nbt")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--dtype", default="auto", choices=["auto", "bf16", "fp16"],
+                    help="auto = the backend's default: fp16 with the reference's 1/8 range transform for convolutional nets")
+    ap.add_argument("--pmc", action="store_true", help="measure HBM traffic per launch in this run (two extra rocprofv3 passes of 3 steps, ~1 min)")
+    ap.add_argument("--no-callers", action="store_true", help="skip the caller-side rates (leaf pump, reference benchmark on fibers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the second, hipEvent-instrumented pass (no roofline object)")
     ap.add_argument("--host-buffers", action="store_true",
@@ -124,6 +220,10 @@ def main():
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    traffic = None
+    if args.pmc and rank == 0 and world == 1:
+        traffic = measured_traffic(args)  # before this process touches the GPU: the passes have the device to themselves
+
     from katago_amd import capi, modelgen, nninterface as nn
 
     lib = capi.load_library()
@@ -134,6 +234,7 @@ def main():
     model = nn.loadModelFile(model_path)
     ctx = nn.createComputeContext([local_rank], 19, 19, precision=args.dtype)
     handle = nn.createComputeHandle(ctx, model, args.batch, True, local_rank)
+    dtype = handle.precision  # what "auto" resolved to: "fp16" / "bf16"
 
     S, B = 361, args.batch
     sp, gl = synthetic_rows(B, 20260921 + rank)
@@ -244,9 +345,9 @@ def main():
         total_ms = sum(v[1] for v in prof_entries.values())
         name, (launches, ms, flops, nbytes) = max(prof_entries.items(), key=lambda kv: kv[1][1])
         achieved = flops / (ms * 1e-3) / 1e12
-        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        peak = MFMA_PEAK_TFLOPS[dtype]
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": committed_traffic(name, args),
+                    "frac": round(achieved / peak, 4), "traffic": (traffic or {}).get(name),
                     "pass": "single stream, hipEvent pair per launch (the timed pass runs two half-batch streams)",
                     "profiled_ms_per_step": round(profiled_elapsed / args.steps * 1e3, 4),
                     "avg_launch_ms": round(ms / launches, 5), "launches": int(launches),
@@ -254,21 +355,40 @@ def main():
                     "kernel_time_share": {k: round(v[1] / total_ms, 4) for k, v in prof_entries.items()},
                     "kernel_avg_launch_us": {k: round(v[1] / max(v[0], 1) * 1e3, 2) for k, v in prof_entries.items()}}
 
+    roofline_seam = None
+    if prof_entries and prof_entries.get("conv1x1_pair", (0, 0, 0, 0))[0] > 0:
+        launches, ms, flops, nbytes = prof_entries["conv1x1_pair"]
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        roofline_seam = {"bound": "hbm", "kernel": "conv1x1_pair", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": (traffic or {}).get("conv1x1_pair"),
+                         "avg_launch_ms": round(ms / launches, 5), "launches": int(launches),
+                         "algorithmic_bytes_per_launch": nbytes / launches, "flops_per_launch": flops / launches}
+
+    callers = None
+    if rank == 0 and world == 1 and not args.no_callers:
+        handle.sync()
+        callers = caller_rates(model_path, tmp)
+
     if rank == 0:
         value = total_rows / elapsed
         flops_eval = model.info.flops_per_position * S
         out = {
             "metric": "nn_evals_per_s", "value": round(value, 1), "unit": "evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype,
+            "vs_baseline": None, "dtype": dtype,
+            "precision": ("fp16 storage with the reference's 1/8 activation-range transform (desc.cpp:2718-2736), fp32 accumulate"
+                          if dtype == "fp16" else "bf16 storage, fp32 accumulate") + (" (backend default)" if args.dtype == "auto" else ""),
             "data": "synthetic positions (SURVEY 8d recipe) on random-init weights of the named architecture (no trained b18c384nbt is available offline)",
             "config": {"workload": "%s 19x19 random weights, batch %d per GPU, NeuralNet::getOutput pass (device-resident inputs)" % (args.model, B),
                        "gflop_per_eval": round(flops_eval / 1e9, 3), "parallelism": "replicas x%d" % world,
                        "whole_net_tflops": round(value * flops_eval / 1e12, 1),
-                       "whole_net_frac_of_mfma_peak": round(value * flops_eval / 1e12 / (MFMA_PEAK_TFLOPS[args.dtype] * world), 4)},
+                       "whole_net_frac_of_mfma_peak": round(value * flops_eval / 1e12 / (MFMA_PEAK_TFLOPS[dtype] * world), 4)},
             "roofline": roofline,
+            "roofline_seam": roofline_seam,
             "box": box,
         }
+        if callers:
+            out.update(callers)
         if host_rate is not None:
             out["host_buffer_evals_per_s"] = round(host_rate, 1)
             out["host_buffer_packed_evals_per_s"] = round(host_packed_rate, 1)

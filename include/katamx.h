@@ -50,12 +50,14 @@ typedef enum kmx_status {
 } kmx_status;
 
 /* Activation kinds — numeric values equal the reference's (cpp/neuralnet/activations.h:4-17). */
-enum { KMX_ACT_IDENTITY = 0, KMX_ACT_RELU = 1, KMX_ACT_MISH = 2, KMX_ACT_SILU = 3 };
+enum { KMX_ACT_IDENTITY = 0, KMX_ACT_RELU = 1, KMX_ACT_MISH = 2, KMX_ACT_SILU = 3,
+       KMX_ACT_MISH_SCALE8 = 4 /* x tanh(softplus(8x)): mish of a net whose tensors carry 1/8 of their values (desc.cpp:421-445) */ };
 
 /* Arithmetic of the device path. The reference's tri-state useFP16Mode
  * (cpp/core/commontypes.h:4-30) maps as: False -> KMX_PREC_FP32, True/Auto -> KMX_PREC_AUTO. */
 enum {
-  KMX_PREC_AUTO = 0, /* backend default 16-bit storage (bf16), fp32 accumulate */
+  KMX_PREC_AUTO = 0, /* backend default: fp16 storage (convolutional nets run at 1/8 of their values, the reference's fp16 range
+                        transform, desc.cpp:2718-2736; outputs unchanged), bf16 for nets that transform does not cover; fp32 accumulate */
   KMX_PREC_FP32 = 1, /* fp32 storage and arithmetic (slow verification mode) */
   KMX_PREC_FP16 = 2, /* fp16 storage, fp32 accumulate */
   KMX_PREC_BF16 = 3  /* bf16 storage, fp32 accumulate */

@@ -105,6 +105,12 @@ __device__ __forceinline__ float actMish(float x) {
   const float u = e + 1.0f;
   return __builtin_fmaf(x * -2.0f, __builtin_amdgcn_rcpf(__builtin_fmaf(u, u, 1.0f)), x);
 }
+// mish of a tensor that carries 1/8 of its values: f(8x)/8 = x tanh(softplus(8x)) (desc.cpp:421-445; model_desc.cpp scaledBy8)
+__device__ __forceinline__ float actMishScale8(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * (8.0f * 1.4426950408889634f));
+  const float u = e + 1.0f;
+  return __builtin_fmaf(x * -2.0f, __builtin_amdgcn_rcpf(__builtin_fmaf(u, u, 1.0f)), x);
+}
 __device__ __forceinline__ f32x2 actMish2(f32x2 x) {
   f32x2 y;
   y[0] = actMish(x[0]);
@@ -118,6 +124,7 @@ __device__ __forceinline__ float actApply(float x, int kind) {
   if(kind == KMX_ACT_RELU) return fmaxf(x, 0.0f);
   if(kind == KMX_ACT_MISH) return actMish(x);
   if(kind == KMX_ACT_SILU) return actSilu(x);
+  if(kind == KMX_ACT_MISH_SCALE8) return actMishScale8(x);
   return x;
 }
 
@@ -125,7 +132,8 @@ __device__ __forceinline__ float actApply(float x, int kind) {
 // once per element or per row - and only that body's code is fetched.
 template <int KIND>
 __device__ __forceinline__ float actK(float x) {
-  return KIND == KMX_ACT_MISH ? actMish(x) : KIND == KMX_ACT_RELU ? fmaxf(x, 0.0f) : KIND == KMX_ACT_SILU ? actSilu(x) : x;
+  return KIND == KMX_ACT_MISH ? actMish(x) : KIND == KMX_ACT_RELU ? fmaxf(x, 0.0f) : KIND == KMX_ACT_SILU ? actSilu(x)
+         : KIND == KMX_ACT_MISH_SCALE8 ? actMishScale8(x) : x;
 }
 template <int K>
 struct ActKindTag {
@@ -145,6 +153,7 @@ __device__ __forceinline__ void withActKind(int kind, F&& f) {
   if(kind == KMX_ACT_MISH) f(ActKindTag<KMX_ACT_MISH>());
   else if(kind == KMX_ACT_RELU) f(ActKindTag<KMX_ACT_RELU>());
   else if(kind == KMX_ACT_SILU) f(ActKindTag<KMX_ACT_SILU>());
+  else if(kind == KMX_ACT_MISH_SCALE8) f(ActKindTag<KMX_ACT_MISH_SCALE8>());
   else f(ActKindTag<KMX_ACT_IDENTITY>());
 }
 

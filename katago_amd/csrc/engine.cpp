@@ -147,7 +147,16 @@ Engine::Engine(const ModelDesc& model, int nnXLen, int nnYLen, int maxBatch, int
   // A constructor that throws does not run the destructor: release the stream, events and pinned buffers acquired so far
   // (an unsupported layer, or a device out of memory half-way through, must not leak them).
   try {
-    construct(model);
+    // fp16 has five exponent bits: run the net at 1/8 of its values, as the reference's fp16 backends do (desc.cpp:2718-2736;
+    // model_desc.cpp scaledBy8 - outputs unchanged). KMX_FP16_SCALE8=0 runs the file's own values (A/B, tests).
+    bool scale8 = dtype == DT_F16 && model.scale8Applies() && !model.scale8Applied;
+    if(const char* e = getenv("KMX_FP16_SCALE8")) scale8 = scale8 && atoi(e) != 0;
+    if(scale8) {
+      const std::unique_ptr<ModelDesc> scaled = model.scaledBy8();
+      construct(*scaled);
+      scale8_ = true;
+    }
+    else construct(model);
   }
   catch(...) {
     destroy();

@@ -73,6 +73,7 @@ FusedConv buildFusedConv(int dtype, const std::vector<ConvSegment>& segs, std::v
 class Engine {
  public:
   Engine(const ModelDesc& model, int nnXLen, int nnYLen, int maxBatch, int dtype, int device);
+  bool usesScale8() const { return scale8_; }
   ~Engine();
 
   int dtype() const { return dtype_; }
@@ -145,6 +146,7 @@ class Engine {
     double bytesPerRow;    // algorithmic HBM bytes per evaluated position
   };
   void construct(const ModelDesc& model);  // the body of the constructor
+  bool scale8_ = false;  // the net runs at 1/8 of its values (fp16 range transform)
   void destroy() noexcept;                 // everything the destructor releases; also run when construct() throws
   int opClass(const std::string& name);
   void addOp(const std::string& cls, double flopsPerRow, double bytesPerRow, std::function<void(int, hipStream_t)> fn);

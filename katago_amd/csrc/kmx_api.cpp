@@ -112,14 +112,18 @@ void apiContextDims(const kmx_context* ctx, int* x, int* y) {
   *x = ctx->nnXLen;
   *y = ctx->nnYLen;
 }
-// AUTO: bf16 for convolutional nets (no overflow risk on trained nets without the reference's scale-8 rewrite), fp16 for
-// nets with transformer blocks or an RMSNorm trunk tip: their normalisations amplify bf16's 8-bit mantissa to 4.1x / 1.1x of
-// the reference's reduced-precision limits on its two trained transformer nets, where fp16 sits at 0.24x / 0.06x
-// (testgpuerror, profiles/r02/transformer/); the reference runs such nets in plain fp16 too (scale-8 does not apply to
-// them, desc.cpp:2718-2736).
+// AUTO: fp16 wherever its five exponent bits are safe - convolutional nets that take the reference's 1/8 range transform
+// (desc.cpp:2718-2736; model_desc.cpp scaledBy8, applied by the Engine), the reference's own answer to fp16 overflow - and for nets
+// with transformer blocks or an RMSNorm trunk tip, which the reference also runs in plain fp16 and whose normalisations amplify
+// bf16's 8-bit mantissa to 4.1x / 1.1x of the reference's reduced-precision limits (fp16: 0.24x / 0.06x; testgpuerror,
+// profiles/r02/transformer/). What is left (standard-norm nets with an activation the transform has no counterpart for, i.e.
+// SiLU) runs in bf16. Round 2 defaulted convolutional nets to bf16: 8x less accurate (1.67x of the strict limits against
+// 0.21x) for ~3 % of speed.
 int apiDtypeFor(const kmx_context* ctx, const kmx_model* model) {
   int dtype = dtypeForPrecision(ctx->precisionMode);
-  if(ctx->precisionMode == KMX_PREC_AUTO && (model->desc->hasTransformerBlocks || model->desc->trunkNormKind != 0)) dtype = DT_F16;
+  if(ctx->precisionMode == KMX_PREC_AUTO &&
+     (model->desc->hasTransformerBlocks || model->desc->trunkNormKind != 0 || model->desc->scale8Applies()))
+    dtype = DT_F16;
   return dtype;
 }
 }  // namespace kmx

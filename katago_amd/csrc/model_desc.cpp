@@ -599,4 +599,69 @@ std::unique_ptr<ModelDesc> ModelDesc::loadFromFile(const std::string& path, cons
   return mp;
 }
 
+// ---- the fp16 range transform (SURVEY 8 row a23 ii; reference: ModelDesc::applyScale8ToReduceActivations, desc.cpp:2718-2736,
+// and the per-layer pieces :355-366 batch norm, :421-445 activation, :552-556 bias, :1974-1986 trunk, :2217-2224 policy head,
+// :2389-2396 value head). Every tensor of the net carries 1/8 of its value: the stem's outputs are scaled (initial convolution,
+// global-feature matmul, metadata encoder's last matmul), every additive constant follows (merged BN biases, head biases),
+// convolutions and matmuls are linear and need nothing, and an activation f becomes g(x) = f(8x)/8 - identity and relu are
+// their own g, mish becomes x * tanh(softplus(8x)) (KMX_ACT_MISH_SCALE8). Global pooling is linear in the values (its off-board
+// filler of -1 for the max stays below every activated value). The reference undoes the factor in NNEvaluator's
+// post-processing (outputScaleMultiplier = 8, nneval.cpp:962,1123-1131,1245); here the LAST linear layer of each output -
+// p2Conv, the pass head's final matmul, v3, sv3, the ownership convolution, all of which the engine evaluates in fp32 - carries
+// the factor 8 (exact in binary floating point), so the C ABI keeps returning plain logits whatever the precision.
+static bool actScales(int act) { return act == KMX_ACT_IDENTITY || act == KMX_ACT_RELU || act == KMX_ACT_MISH; }
+static int actScaled8(int act) { return act == KMX_ACT_MISH ? KMX_ACT_MISH_SCALE8 : act; }
+static bool blocksScale(const std::vector<BlockDesc>& blocks) {
+  for(const BlockDesc& b : blocks) {
+    if(b.isTransformer()) return false;
+    if(!actScales(b.preBN.act) || !actScales(b.midBN.act)) return false;
+    if(b.kind == BlockKind::GPool && !actScales(b.gpoolBN.act)) return false;
+    if(b.kind == BlockKind::Nested && !blocksScale(b.inner)) return false;
+  }
+  return true;
+}
+bool ModelDesc::scale8Applies() const {
+  if(trunkNormKind != 0 || hasTransformerBlocks) return false;  // an RMSNorm would undo the factor (desc.cpp:2721-2729)
+  if(!blocksScale(blocks)) return false;
+  return actScales(trunkTipBN.act) && actScales(g1BN.act) && actScales(p1BN.act) && actScales(v1BN.act) && actScales(passAct) && actScales(v2Act);
+}
+static void scaleBn(BnDesc& bn) {
+  for(float& b : bn.bias) b *= 0.125f;
+  bn.act = actScaled8(bn.act);
+}
+static void scaleBlocks(std::vector<BlockDesc>& blocks) {
+  for(BlockDesc& b : blocks) {
+    scaleBn(b.preBN);
+    scaleBn(b.midBN);
+    if(b.kind == BlockKind::GPool) scaleBn(b.gpoolBN);
+    if(b.kind == BlockKind::Nested) scaleBlocks(b.inner);
+  }
+}
+std::unique_ptr<ModelDesc> ModelDesc::scaledBy8() const {
+  if(!scale8Applies()) throw ModelError(KMX_ERR_UNSUPPORTED, name + ": the 1/8 activation scaling does not apply to this architecture");
+  std::unique_ptr<ModelDesc> mp(new ModelDesc(*this));
+  ModelDesc& m = *mp;
+  for(float& w : m.initialConv.w) w *= 0.125f;
+  for(float& w : m.initialMatMul.w) w *= 0.125f;
+  if(m.metaEncoderVersion > 0)
+    for(float& w : m.metaMul3.w) w *= 0.125f;
+  scaleBlocks(m.blocks);
+  scaleBn(m.trunkTipBN);
+  scaleBn(m.g1BN);
+  scaleBn(m.p1BN);
+  scaleBn(m.v1BN);
+  for(float& w : m.gpoolToPassBias.w) w *= 0.125f;
+  m.passAct = actScaled8(m.passAct);
+  for(float& w : m.v2Bias.w) w *= 0.125f;
+  m.v2Act = actScaled8(m.v2Act);
+  // outputs back to their own scale: v3 / sv3 biases stay as they are in the file (0.125 b * 8)
+  for(float& w : m.p2Conv.w) w *= 8.0f;
+  for(float& w : (m.hasPassMLP ? m.gpoolToPassMul2 : m.gpoolToPassMul).w) w *= 8.0f;
+  for(float& w : m.v3Mul.w) w *= 8.0f;
+  for(float& w : m.sv3Mul.w) w *= 8.0f;
+  for(float& w : m.vOwnershipConv.w) w *= 8.0f;
+  m.scale8Applied = true;
+  return mp;
+}
+
 }  // namespace kmx

@@ -120,6 +120,13 @@ struct ModelDesc {
   double macPerPosition = 0.0;  // direct-convolution MACs per board point
   std::string sha256;           // hex digest of the uncompressed file contents
 
+  // The fp16 range transform of the reference (desc.cpp:2718-2736; see model_desc.cpp): a copy of this net whose tensors all
+  // carry 1/8 of their values and whose outputs are unchanged. scale8Applies(): standard batch norm trunk, no transformer
+  // blocks, activations among identity / relu / mish.
+  bool scale8Applied = false;
+  bool scale8Applies() const;
+  std::unique_ptr<ModelDesc> scaledBy8() const;
+
   // Throws ModelError. expectedSha256 may be empty (no check).
   static std::unique_ptr<ModelDesc> loadFromFile(const std::string& path, const std::string& expectedSha256);
 };

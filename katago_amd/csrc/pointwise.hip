@@ -56,11 +56,14 @@ int numComputeUnits() {  // per device: one persistent work-group per CU (KMX_PW
 
 template <class TR>
 hipError_t launchT(int c1, int c2, int c3, const PwPairArgs& a, hipStream_t stream) {
-  if(c1 == 192 && c2 == 384 && c3 == 192 && a.actOut == nullptr && a.actKind1 == KMX_ACT_MISH && a.actKind2 == KMX_ACT_MISH &&
-     pwWaves() == 8 && persistentWanted())
-  {
-    if(a.dbg != nullptr) return pw2::launchPersistent<TR, 6, 12, 3, KMX_ACT_MISH, KMX_ACT_MISH, true>(a, numComputeUnits(), stream);
-    return pw2::launchPersistent<TR, 6, 12, 3, KMX_ACT_MISH, KMX_ACT_MISH>(a, numComputeUnits(), stream);
+  if(c1 == 192 && c2 == 384 && c3 == 192 && a.actOut == nullptr && a.actKind1 == a.actKind2 && pwWaves() == 8 && persistentWanted()) {
+    if(a.actKind1 == KMX_ACT_MISH) {
+      if(a.dbg != nullptr) return pw2::launchPersistent<TR, 6, 12, 3, KMX_ACT_MISH, KMX_ACT_MISH, true>(a, numComputeUnits(), stream);
+      return pw2::launchPersistent<TR, 6, 12, 3, KMX_ACT_MISH, KMX_ACT_MISH>(a, numComputeUnits(), stream);
+    }
+    // the same net under the fp16 range transform (model_desc.cpp scaledBy8)
+    if(a.actKind1 == KMX_ACT_MISH_SCALE8 && a.dbg == nullptr)
+      return pw2::launchPersistent<TR, 6, 12, 3, KMX_ACT_MISH_SCALE8, KMX_ACT_MISH_SCALE8>(a, numComputeUnits(), stream);
   }
   // the 4-wave shape: a wave of GEMM 1 owns C2/2 channels (WN1 doubles), of GEMM 2 C3/2 (WN2 as is)
 #define KMX_PW(K1_, WN1_, WN2_) \

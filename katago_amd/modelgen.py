@@ -130,9 +130,11 @@ def _nested(w, name, c, mid, gpool, with_gpool):
     w.conv(name + ".convq", 1, mid, c, gain=0.35)
 
 
-def write_model(path, arch, seed=20260921, version=15, activation="mish", name=None, stem_kernel=3, meta_encoder=None):
+def write_model(path, arch, seed=20260921, version=15, activation="mish", name=None, stem_kernel=3, meta_encoder=None, stem_gain=1.0):
     """Write a random-weight model file. `path` may end in .bin, .bin.gz, .txt or .txt.gz. Returns the architecture dict.
-    meta_encoder = internal channel count of an sgf-metadata encoder (export_model_pytorch.py:493-504; version >= 15), or None."""
+    meta_encoder = internal channel count of an sgf-metadata encoder (export_model_pytorch.py:493-504; version >= 15), or None.
+    stem_gain multiplies the stem's weights: the layers behind it preserve magnitudes, so every tensor of the net grows with it
+    (tests of the fp16 range transform use it to push activations past 65504)."""
     if meta_encoder and version < 15:
         raise ValueError("the sgf-metadata encoder needs model version >= 15")
     a = ARCHS[arch] if isinstance(arch, str) else arch
@@ -158,8 +160,8 @@ def write_model(path, arch, seed=20260921, version=15, activation="mish", name=N
         if version >= 15:
             for _ in range(6):
                 w.ln(0)
-        w.conv("model.conv_spatial", stem_kernel, 22, C)
-        w.matmul("model.linear_global", 19, C, gain=0.5)
+        w.conv("model.conv_spatial", stem_kernel, 22, C, gain=stem_gain)
+        w.matmul("model.linear_global", 19, C, gain=0.5 * stem_gain)
         if meta_encoder:
             e = "model.sgf_metadata_encoder"
             w.ln(e)

@@ -174,6 +174,16 @@ def main():
             out[case] = golden_case(ctx, name, rows=[int(r) for r in rows.split(",")] if rows else None)
         elif what == "torch_meta":
             out[case] = golden_case(ctx, what, with_meta=True)
+        elif what == "big_activations":
+            # Every tensor of this net is ~2e4 times the usual size (the stem is, the rest preserves magnitudes): trunk values pass
+            # 65504. With the fp16 range transform (the default) the device tracks the fp32 oracle; with the file's own values
+            # (KMX_FP16_SCALE8=0) fp16 overflows - which is what the transform is for (desc.cpp:2718-2736).
+            p = os.path.join(os.environ.get("TMPDIR", "/tmp"), "kmx_emu_big.bin")
+            modelgen.write_model(p, "b3c64nbt", seed=12, stem_gain=2.0e4)
+            out[case] = oracle_case(ctx, p, 2, [(19, 19), (9, 13)], 3)
+            os.environ["KMX_FP16_SCALE8"] = "0"
+            out[case]["finite_without_transform"] = oracle_case(ctx, p, 2, [(19, 19), (9, 13)], 3)["finite"]
+            del os.environ["KMX_FP16_SCALE8"]
         elif what.startswith("gen_"):  # gen_<arch>_v<version>
             _, arch, ver = what.split("_")
             p = os.path.join(os.environ.get("TMPDIR", "/tmp"), "kmx_emu_%s_%s.bin" % (arch, ver))

@@ -232,6 +232,20 @@ def test_convolutional_nets_emulated(emu_lib):
     check({k: v for k, v in res.items() if k.startswith("fp16")}, 0.03, 0.02)
 
 
+def test_fp16_range_transform_emulated(emu_lib):
+    """SURVEY 8 row a23(ii), model_desc.cpp scaledBy8: fp16 engines run the net at 1/8 of its values (the reference's
+    applyScale8ToReduceActivations, desc.cpp:2718-2736) with unchanged outputs. Nested bottleneck + gpool + pass MLP with mish
+    (v15), the metadata encoder, the v8 layout with relu - against the oracle / the PyTorch goldens, which know nothing of the
+    transform; then a net whose activations pass 65504: finite and right with the transform, overflowed without it."""
+    res = run_cases(emu_lib, ["fp16:gen_b3c64nbt_v15", "fp16:torch_meta", "fp16:gen_b10c128_v14"])
+    check(res, 0.03, 0.02)
+    big = run_cases(emu_lib, ["fp16:big_activations"])["fp16:big_activations"]
+    assert big["finite"] and not big["finite_without_transform"], big
+    for k in ("policy", "value", "score", "ownership"):
+        err, scale = big[k]
+        assert scale > 1.0e3 and err <= 0.02 * scale, (k, err, scale)  # logits of a net 2e4 times too big, relative to themselves
+
+
 def test_entry_point_variants_emulated(emu_lib):
     """kmx_eval_packed, the two-engine split of a batch, single rows: bit-identical to kmx_eval; counters add up."""
     res = run_cases(emu_lib, ["bf16:api_variants"])["bf16:api_variants"]

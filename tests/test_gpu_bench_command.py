@@ -43,6 +43,11 @@ def _check_line(d, steps, warmup):
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0.05 < r["frac"] < 1.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert abs(r["achieved"] - r["flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) / r["achieved"] < 0.01
+    assert r["traffic"] is None or "this run" in r["traffic"]["source"]  # measured by the run that prints it (--pmc), or absent
+    assert d["dtype"] == "fp16" and "1/8" in d["precision"]  # the backend default since round 3
+    q = d["roofline_seam"]
+    assert q["bound"] == "hbm" and q["unit"] == "GB/s" and q["peak"] == 8000.0 and 0.05 < q["frac"] < 1.0
+    assert abs(q["achieved"] - q["algorithmic_bytes_per_launch"] / (q["avg_launch_ms"] * 1e-3) / 1e9) / q["achieved"] < 0.01
 
 
 def test_driver_command_exits_zero_with_roofline_and_cpu_baseline():
@@ -51,6 +56,19 @@ def test_driver_command_exits_zero_with_roofline_and_cpu_baseline():
     _check_line(d, 20, 5)
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+    # the callers' side of the same box, outside the timed region
+    assert d["host_rows_through_batcher_per_s"] > 0.5 * d["value"]
+    if os.path.exists(os.path.join(REPO, "oracle", "_ref", "katago_hipx")):
+        assert d["reference_benchmark_nn_evals_per_s"] > 0.5 * d["value"], d
+
+
+def test_traffic_is_measured_by_the_run_that_prints_it():
+    """--pmc: two rocprofv3 counter passes inside the bench run; the line's traffic objects name this run as their source."""
+    d = _run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-callers", "--pmc"], timeout=900)
+    _check_line(d, 20, 5)
+    for r in (d["roofline"], d["roofline_seam"]):
+        t = r["traffic"]
+        assert t and "this run" in t["source"] and 0.9 < t["hbm_bytes_per_launch"] / r["algorithmic_bytes_per_launch"] < 2.0, t
 
 
 @pytest.mark.parametrize("rep", range(3))

@@ -8,7 +8,9 @@ counts exactly either: its fp16 golden (runSearchTestsV8FP16.txt) differs from t
 visits on the best move (mean 0.30 %), total-variation distance of the child visit distributions 0.46 % on average,
 root utility up to 1.8 c — with the same best move in all searches. That spread is the yardstick. Measured on the HIP
 backend in fp16: 2.8 % / 0.24 %, 0.45 %, 1.8 c, same best move in 136 of 139 searches — i.e. the reference's own fp16
-spread; the limits below are 2-3x it and are written out (bf16, the default for convolutional nets, is wider).
+spread; the limits below are 2-3x it and are written out. Round 3: the backend's DEFAULT precision ("auto") is fp16 with the
+reference's 1/8 range transform (model_desc.cpp scaledBy8) and is held to the same limits as explicit fp16; bf16, an opt-in
+since, keeps its wider ones.
 """
 import gzip
 import os
@@ -33,6 +35,7 @@ def _gold(name):
     # same best move | visit share of the best move: max, mean | child visit distribution TV: mean | root utility (c): max, mean
     # measured on MI355X (profiles/r02/search_fixed_seed_*.txt): fp16 0.978 | 0.028, 0.0024 | 0.0045 | 1.8, 0.076 - the spread of the
     # reference's own fp16 golden; bf16 0.976 | 0.89 (one search flips), 0.015 | 0.020 | 9.3, 0.52
+    ("auto", dict(searches=130, same_best=0.97, best_share_max=0.08, best_share_mean=0.01, tv_mean=0.015, root_util_max=4.0, root_util_mean=0.3)),
     ("fp16", dict(searches=130, same_best=0.97, best_share_max=0.08, best_share_mean=0.01, tv_mean=0.015, root_util_max=4.0, root_util_mean=0.3)),
     ("bf16", dict(searches=115, same_best=0.95, best_share_max=1.0, best_share_mean=0.04, tv_mean=0.06, root_util_max=15.0, root_util_mean=1.5)),
 ])
