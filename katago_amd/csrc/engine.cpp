@@ -882,7 +882,12 @@ std::vector<Engine::ProfileEntry> Engine::getProfile() {
   return out;
 }
 
-void Engine::sync() { hipCheck(hipStreamSynchronize(stream_), "stream synchronize"); }
+// (callable from any thread - the batcher's completion thread never made this engine's device current - and one process may
+// hold engines on several GPUs: nneval.cpp:399-407 runs one server thread per GPU)
+void Engine::sync() {
+  hipCheck(hipSetDevice(device_), "hipSetDevice");
+  hipCheck(hipStreamSynchronize(stream_), "stream synchronize");
+}
 
 // symmetry / optimism of the rows -> device. Pinned staging is double-buffered: the slot used two calls ago is free as
 // soon as ITS copies have run, so back-to-back asynchronous calls queue up without draining the stream in between.

@@ -16,6 +16,17 @@ REF_BIN_DIR = os.path.join(REPO, "oracle", "_ref")
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: takes more than ~30 s on CPU")
+    # The CPU suite (-m "not gpu") is dominated by emulated kernels and by the reference's own test commands run as subprocesses:
+    # independent files, spread over a few pytest-xdist workers when the plugin is there and the caller did not choose (-n / -p
+    # no:xdist / KMX_TEST_WORKERS=0). Never for -m gpu: those tests time the device and must have it to themselves.
+    opt = config.option
+    if (getattr(opt, "numprocesses", None) in (None, 0) and getattr(opt, "dist", None) == "no" and not hasattr(config, "workerinput")
+            and "not gpu" in (opt.markexpr or "") and os.environ.get("KMX_TEST_WORKERS", "") != "0" and not getattr(opt, "collectonly", False)):
+        n = min(int(os.environ.get("KMX_TEST_WORKERS", "4")), os.cpu_count() or 1)
+        if n > 1:
+            opt.numprocesses = n
+            opt.dist = "loadfile"
+            opt.tx = ["popen"] * n
 
 
 @pytest.fixture(scope="session", autouse=True)

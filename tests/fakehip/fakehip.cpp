@@ -20,11 +20,25 @@
 
 namespace {
 std::mutex g_mu;
-struct Alloc { size_t size; int ordinal; };
+struct Alloc { size_t size; int ordinal; int dev; };
 std::map<uintptr_t, Alloc> g_allocs;       // base -> info (device allocations only)
 std::map<const void*, std::string> g_names;  // host stub -> kernel name
 int g_nextOrdinal = 0;
 FILE* g_log = nullptr;
+// Several fake devices (KMX_FAKEHIP_DEVICES=N, default 1): every allocation, stream and event belongs to the device that was
+// current when it was created, and every later use is checked against the calling thread's current device - the rule the real
+// runtime enforces for launches, event records and stream waits. A mismatch is logged as a VIOLATION line; with one device
+// nothing below changes the log (tests/golden/schedule_md5.json).
+int numDevices() {
+  static const int n = [] {
+    const char* e = getenv("KMX_FAKEHIP_DEVICES");
+    const int v = e ? atoi(e) : 1;
+    return v < 1 ? 1 : v;
+  }();
+  return n;
+}
+thread_local int t_dev = 0;
+std::map<const void*, int> g_owner;  // stream / event -> device
 struct CallCfg { dim3 grid, block; size_t shmem; hipStream_t stream; };
 thread_local std::vector<CallCfg> g_cfg;
 
@@ -35,6 +49,19 @@ FILE* logFile() {
     if(!g_log) g_log = stderr;
   }
   return g_log;
+}
+void checkOwner(const char* what, const void* res) {
+  if(numDevices() == 1 || res == nullptr) return;
+  std::lock_guard<std::mutex> l(g_mu);
+  auto it = g_owner.find(res);
+  if(it != g_owner.end() && it->second != t_dev) {
+    fprintf(logFile(), "VIOLATION %s: resource of device %d used while device %d is current\n", what, it->second, t_dev);
+    fflush(logFile());
+  }
+}
+void own(const void* res) {
+  std::lock_guard<std::mutex> l(g_mu);
+  g_owner[res] = t_dev;
 }
 uint64_t fnv(const void* p, size_t n) {
   uint64_t h = 1469598103934665603ull;
@@ -77,9 +104,18 @@ bool describePtr(uint64_t v, char* out, size_t outLen, FILE* f) {
 
 extern "C" {
 
-hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
-hipError_t hipSetDevice(int) { return hipSuccess; }
-hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+hipError_t hipGetDeviceCount(int* n) { *n = numDevices(); return hipSuccess; }
+hipError_t hipSetDevice(int d) {
+  if(d < 0 || d >= numDevices()) return hipErrorInvalidDevice;
+  t_dev = d;
+  return hipSuccess;
+}
+hipError_t hipGetDevice(int* d) { *d = t_dev; return hipSuccess; }
+hipError_t hipGetDevicePropertiesR0600(hipDeviceProp_t* prop, int) {  // what hipGetDeviceProperties is a macro for
+  memset(prop, 0, sizeof(*prop));
+  prop->multiProcessorCount = 256;
+  return hipSuccess;
+}
 const char* hipGetErrorString(hipError_t) { return "fakehip"; }
 hipError_t hipGetLastError(void) { return hipSuccess; }
 hipError_t hipPeekAtLastError(void) { return hipSuccess; }
@@ -88,7 +124,7 @@ hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
 hipError_t hipMalloc(void** p, size_t n) {
   *p = calloc(1, n ? n : 1);
   std::lock_guard<std::mutex> l(g_mu);
-  g_allocs[(uintptr_t)*p] = Alloc{n, -1};
+  g_allocs[(uintptr_t)*p] = Alloc{n, -1, t_dev};
   return hipSuccess;
 }
 hipError_t hipFree(void* p) {
@@ -102,19 +138,19 @@ hipError_t hipFree(void* p) {
 hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
-hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t st) { checkOwner("hipMemcpyAsync", st); memcpy(d, s, n); return hipSuccess; }
 hipError_t hipHostMalloc(void** p, size_t n, unsigned int) { *p = calloc(1, n ? n : 1); return hipSuccess; }
 hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 
-hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned int) { *s = (hipStream_t)calloc(1, 8); return hipSuccess; }
-hipError_t hipStreamCreate(hipStream_t* s) { *s = (hipStream_t)calloc(1, 8); return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned int) { *s = (hipStream_t)calloc(1, 8); own(*s); return hipSuccess; }
+hipError_t hipStreamCreate(hipStream_t* s) { *s = (hipStream_t)calloc(1, 8); own(*s); return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { free((void*)s); return hipSuccess; }
-hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned int) { return hipSuccess; }
-hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned int) { *e = (hipEvent_t)calloc(1, 8); return hipSuccess; }
-hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)calloc(1, 8); return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t s) { checkOwner("hipStreamSynchronize", s); return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t, unsigned int) { checkOwner("hipStreamWaitEvent", s); return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned int) { *e = (hipEvent_t)calloc(1, 8); own(*e); return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)calloc(1, 8); own(*e); return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) { free((void*)e); return hipSuccess; }
-hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { checkOwner("hipEventRecord (event)", e); checkOwner("hipEventRecord (stream)", s); return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
@@ -148,7 +184,8 @@ hipError_t __hipPopCallConfiguration(dim3* grid, dim3* block, size_t* shmem, hip
   *grid = c.grid; *block = c.block; *shmem = c.shmem; *stream = c.stream;
   return hipSuccess;
 }
-hipError_t hipLaunchKernel(const void* func, dim3 grid, dim3 block, void** args, size_t shmem, hipStream_t) {
+hipError_t hipLaunchKernel(const void* func, dim3 grid, dim3 block, void** args, size_t shmem, hipStream_t stream) {
+  checkOwner("hipLaunchKernel", stream);
   std::lock_guard<std::mutex> l(g_mu);
   FILE* f = logFile();
   auto it = g_names.find(func);
@@ -166,6 +203,7 @@ hipError_t hipLaunchKernel(const void* func, dim3 grid, dim3 block, void** args,
       else { snprintf(tmp, sizeof(tmp), " %llx", (unsigned long long)v); line += tmp; }
     }
   }
+  if(numDevices() > 1) fprintf(f, "dev %d ", t_dev);
   fprintf(f, "launch %s grid %u,%u,%u block %u lds %zu args%s\n", name.c_str(), grid.x, grid.y, grid.z, block.x, shmem, line.c_str());
   fflush(f);
   return hipSuccess;

@@ -191,13 +191,22 @@ for (cin, cout, X, Y, n) in ((64, 192, 19, 19, 1), (96, 128, 13, 9, 1)):
     out["%%d_%%d" %% (cin, cout)] = [float(np.abs(got.reshape(want.shape) - want).max()), float(np.abs(want).max())]
 print("RESULT " + json.dumps(out))
 """ % (REPO,)
-    for bp2 in ("0", "1"):
-        env = dict(os.environ, KMX_MIN_WGS8="1", KMX_CONV_BP2=bp2)
-        p = subprocess.run([sys.executable, "-c", code, emu_full_lib], capture_output=True, text=True, timeout=1800, env=env)
-        assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
-        res = json.loads(p.stdout.split("RESULT ")[1])
+    runs = run_parallel([([sys.executable, "-c", code, emu_full_lib], dict(os.environ, KMX_MIN_WGS8="1", KMX_CONV_BP2=bp2)) for bp2 in ("0", "1")])
+    for bp2, (rc, so, se) in zip(("0", "1"), runs):
+        assert rc == 0, (so + se)[-3000:]
+        res = json.loads(so.split("RESULT ")[1])
         for k, v in res.items():
             assert v[0] <= 2.0 ** -7 * max(1.0, v[1]) * 1.5, (bp2, k, v)
+
+
+def run_parallel(cmds_envs, timeout=1800):
+    """The emulated kernels are slow (two thread barriers per emulated MFMA): independent variants run side by side."""
+    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for cmd, env in cmds_envs]
+    out = []
+    for p in procs:
+        o, e = p.communicate(timeout=timeout)
+        out.append((p.returncode, o, e))
+    return out
 
 
 def run_cases(emu_lib, cases, transformer=False, attention="valu"):
@@ -313,10 +322,11 @@ for dtype in ("bf16", "fp16"):
                   "off_board_zero": bool((fused[2][m != 1.0] == 0).all())}
 print("RESULT " + json.dumps(out))
 """ % (REPO, os.path.join(REPO, "tests"))
-    for waves in ("8", "4"):  # the product shape (8 waves x 128 cells) and the two-per-CU experiment (4 waves x 64 cells)
-        p = subprocess.run([sys.executable, "-c", code, emu_full_lib], capture_output=True, text=True, timeout=1800, env=dict(os.environ, KMX_PW_WAVES=waves))
-        assert p.returncode == 0 and "RESULT " in p.stdout, (p.stdout + p.stderr)[-3000:]
-        res = json.loads(p.stdout.split("RESULT ")[1])
+    variants = ("8", "4")  # the product shape (8 waves x 128 cells) and the two-per-CU experiment (4 waves x 64 cells)
+    runs = run_parallel([([sys.executable, "-c", code, emu_full_lib], dict(os.environ, KMX_PW_WAVES=w)) for w in variants])
+    for waves, (rc, so, se) in zip(variants, runs):
+        assert rc == 0 and "RESULT " in so, (so + se)[-3000:]
+        res = json.loads(so.split("RESULT ")[1])
         print(waves, res)
         for dtype, r in res.items():
             assert all(r["same"]) and r["off_board_zero"], (waves, dtype, r)
@@ -350,10 +360,11 @@ print("RESULT " + json.dumps({"same": [bool(np.array_equal(f, p)) for f, p in zi
                               "err": [float(np.abs(f - w).max()) for f, w in zip(fused, want)], "scale": [float(np.abs(w).max()) for w in want],
                               "off_board_zero": bool((fused[2][m != 1.0] == 0).all())}))
 """ % (REPO, os.path.join(REPO, "tests"))
-    for env in ({"KMX_PW_GRID": "1"}, {"KMX_PW_GRID": "2"}, {"KMX_PW_V2": "0"}):
-        p = subprocess.run([sys.executable, "-c", code, emu_full_lib], capture_output=True, text=True, timeout=1800, env=dict(os.environ, **env))
-        assert p.returncode == 0 and "RESULT " in p.stdout, (p.stdout + p.stderr)[-3000:]
-        r = json.loads(p.stdout.split("RESULT ")[1])
+    envs = ({"KMX_PW_GRID": "1"}, {"KMX_PW_GRID": "2"}, {"KMX_PW_V2": "0"})
+    runs = run_parallel([([sys.executable, "-c", code, emu_full_lib], dict(os.environ, **env)) for env in envs])
+    for env, (rc, so, se) in zip(envs, runs):
+        assert rc == 0 and "RESULT " in so, (so + se)[-3000:]
+        r = json.loads(so.split("RESULT ")[1])
         print(env, r)
         assert all(r["same"]) and r["off_board_zero"], (env, r)
         for e, sc, k in zip(r["err"], r["scale"], (1, 4, 4)):

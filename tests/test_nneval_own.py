@@ -26,8 +26,12 @@ def body(binary, *args, timeout=900, cwd=None):
 
 
 def same_output(*args, min_lines=1, **kw):
-    rc0, ref = body(ref_binary("katago_oracle"), *args, **kw)
-    rc1, own = body(ref_binary("katago_oraclex"), *args, **kw)
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(2) as ex:  # the two binaries side by side
+        f0 = ex.submit(body, ref_binary("katago_oracle"), *args, **kw)
+        f1 = ex.submit(body, ref_binary("katago_oraclex"), *args, **kw)
+        (rc0, ref), (rc1, own) = f0.result(), f1.result()
     assert rc0 == 0 and rc1 == 0, (rc0, rc1, ref[-5:], own[-5:])
     assert len(ref) >= min_lines, ref[-5:]
     assert len(own) == len(ref)

@@ -147,3 +147,23 @@ if __name__ == "__main__":
         out = {"generated_with": lib, "md5": {c: generate(c, tmp, so, lib=lib)[0] for c in sorted(CASES)}}
         json.dump(out, open(GOLDEN, "w"), indent=1, sort_keys=True)
         print(json.dumps(out, indent=1))
+
+
+def test_two_devices_in_one_process(fake_so, tmp_path):
+    """The reference's in-process multi-GPU mode (one NNEvaluator server thread per GPU, nneval.cpp:399-407; config keys
+    INTEGRATION.md section 2) without an 8-GPU node: two fake devices, two server threads, a plain handle and a leaf batcher per
+    device (tests/fakehip/run_two_devices.py). Every stream, event and launch of device k must be touched with device k current -
+    including by the batcher's own dispatcher / completion threads, which no caller ever bound to a device."""
+    from katago_amd import modelgen
+
+    model = str(tmp_path / "b2.bin")
+    modelgen.write_model(model, "b2c32nbt", seed=3, version=16)
+    log_path = str(tmp_path / "two.log")
+    env = dict(os.environ, LD_PRELOAD=fake_so, KMX_FAKEHIP_LOG=log_path, KMX_FAKEHIP_DEVICES="2")
+    p = subprocess.run([sys.executable, os.path.join(FAKE_DIR, "run_two_devices.py"), LIB, model], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and "done" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+    log = open(log_path).read().splitlines()
+    violations = [l for l in log if l.startswith("VIOLATION")]
+    assert not violations, violations[:10]
+    per_dev = {d: sum(1 for l in log if l.startswith("dev %d launch" % d)) for d in (0, 1)}
+    assert per_dev[0] > 100 and per_dev[1] > 100, per_dev  # (how the batchers cut their rows into batches depends on timing)
