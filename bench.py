@@ -184,6 +184,39 @@ def caller_rates(model_path, tmp):
             out["reference_benchmark_nn_evals_per_s"] = float(m[-1][1])
             out["reference_benchmark"] = ("katago benchmark -v 8000 -t 1024 -boardsize 19 (4 positions), unmodified reference search on fibers "
                                           "(16 per OS thread), this repo's NNEvaluator + leaf batcher: %s visits/s, avg device batch %s rows" % (m[-1][0], m[-1][2]))
+    cfg_sp = os.path.join(REPO, "tests", "configs", "selfplay_tiny.cfg")
+    if os.path.exists(hipx) and os.path.exists(cfg_sp):
+        # BASELINE configs[2]: `selfplay`, 8 parallel games on this GPU, the visit counts of cpp/configs/training/selfplay8mainb18.cfg
+        # (2000 / 350 cheap), every game's 8 search threads as fibers on the game's own OS thread (8 leaves in flight per game).
+        # A full-length game costs ~190 k NN rows (250 moves x ~760 visits): the games here are cut after 6 moves so that the run
+        # takes seconds - NN rows/s is the measured, transferable number; games/hour for full-length games is DERIVED from it.
+        import shutil
+        import tempfile
+
+        d = tempfile.mkdtemp(prefix="kmx_bench_selfplay_", dir=tmp)
+        try:
+            os.makedirs(os.path.join(d, "models"))
+            shutil.copy(model_path, os.path.join(d, "models", "b18c384nbt-s1-d1.bin"))
+            moves_cap = 6
+            over = ("numGameThreads=8,numSearchThreads=8,nnMaxBatchSize=64,dataBoardLen=19,bSizes=19,bSizeRelProbs=1,maxMovesPerGame=%d,maxVisits=2000,"
+                    "cheapSearchVisits=350,cheapSearchProb=0.75,reducedVisitsMin=350,maxRowsPerTrainFile=20000,maxDataQueueSize=2000,"
+                    "nnCacheSizePowerOfTwo=18,nnMutexPoolSizePowerOfTwo=14,logGamesEvery=1000,numNNServerThreadsPerModel=2" % moves_cap)
+            env = dict(os.environ, KATAMX_LEAVES_PER_THREAD="8")
+            r = subprocess.run([hipx, "selfplay", "-config", cfg_sp, "-models-dir", os.path.join(d, "models"), "-output-dir", os.path.join(d, "out"),
+                                "-max-games-total", "8", "-override-config", over], capture_output=True, text=True, timeout=300, cwd=d, env=env)
+            log = r.stdout + r.stderr
+            if r.returncode == 0 and "Total selfplay runtime (seconds): " in log:
+                games = int(log.split("Total games: ")[1].split()[0])
+                secs = float(log.split("Total selfplay runtime (seconds): ")[1].split()[0])
+                rows = int(log.split("Final NN rows: ")[1].split()[0])
+                out["selfplay_nn_rows_per_s"] = round(rows / secs, 1)
+                rows_per_move = rows / float(games * moves_cap)
+                out["selfplay_games_per_hour_250_move_games_derived"] = round(rows / secs * 3600.0 / (rows_per_move * 250.0), 1)
+                out["selfplay"] = ("katago selfplay (command/selfplay.cpp:388-389), b18c384nbt 19x19 random weights, 8 game threads x 8 search threads on "
+                                   "fibers, maxVisits 2000 / cheap 350 (selfplay8mainb18.cfg), games cut after %d moves: %d games, %d NN rows in %.1f s "
+                                   "(%.0f rows per move); games/hour is derived for 250-move games from the measured rows/s" % (moves_cap, games, rows, secs, rows_per_move))
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
     return out
 
 

@@ -256,6 +256,11 @@ class Batcher {
       }
       catch(const Error& e) { err = e.code; msg = e.what(); }
       catch(const std::exception& e) { err = KMX_ERR_INTERNAL; msg = e.what(); }
+      if(err != KMX_OK) {
+        // a launch that failed half-way may have copies or kernels queued on this set's stream: nothing may reuse its pinned
+        // staging before they have drained (best effort - the stream itself may be what failed)
+        try { s.eng->sync(); } catch(...) {}
+      }
       l.lock();
       s.error = err;
       s.errorMsg = msg;

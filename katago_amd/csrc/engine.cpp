@@ -544,7 +544,11 @@ void Engine::buildStack(const std::vector<BlockDesc>& blocks, const Stream& s, c
       const bool seam = fuseSeams_ && nx != nullptr && nx->kind == BlockKind::Nested && nextBN != nullptr && !nx->inner.empty() &&
                         !nx->inner[0].isTransformer() && b.finalConv.ky == 1 && b.finalConv.kx == 1 && nx->regularConv.ky == 1 &&
                         nx->regularConv.kx == 1 && nx->regularConv.inC == b.finalConv.outC &&
-                        pointwisePairSupported(b.finalConv.inC, b.finalConv.outC, nx->regularConv.outC);
+                        pointwisePairSupported(b.finalConv.inC, b.finalConv.outC, nx->regularConv.outC) &&
+                        // the fused kernel runs IN PLACE: its input (this block's activated mid image) and its mid outputs (the
+                        // next block's) are the same buffers, which is race-free only while both have the same row stride - a
+                        // work-group then overwrites exactly the rows it has fetched itself. Other shapes take the two launches.
+                        roundUp(nx->regularConv.outC, 32) == mid.stride;
       if(seam) {
         Stream nmid = mid;  // the next block's mid stream lives in the same buffers (same nesting depth)
         nmid.stride = roundUp(nx->regularConv.outC, 32);

@@ -63,6 +63,8 @@ bool convCfgInstantiated(int ks, int cfg);  // is there a kernel for this (kerne
 // (+ residual), block i+1's preBN + activation, block i+1's opening 1x1 convolution and the first inner block's
 // preBN + activation. The activated trunk image only exists in LDS. Cells are the flat N*S index.
 struct PwPairArgs {
+  // ALIASING CONTRACT: `in` may be the same buffer as actOut2 / rawOut2 only if inC == midC (a work-group then writes only rows
+  // it has already fetched: 128 consecutive cells, all channels); the engine fuses a seam under that condition only.
   const void* in;        // T [cells][inC]: activated mid image of block i
   int inC;
   const void* w1;        // T [C1/32][C2][32], rows slot-swizzled (the FusedConv layout)

@@ -60,6 +60,7 @@ def test_driver_command_exits_zero_with_roofline_and_cpu_baseline():
     assert d["host_rows_through_batcher_per_s"] > 0.5 * d["value"]
     if os.path.exists(os.path.join(REPO, "oracle", "_ref", "katago_hipx")):
         assert d["reference_benchmark_nn_evals_per_s"] > 0.5 * d["value"], d
+        assert d["selfplay_nn_rows_per_s"] > 1000 and d["selfplay_games_per_hour_250_move_games_derived"] > 0 and "cut after" in d["selfplay"], d
 
 
 def test_traffic_is_measured_by_the_run_that_prints_it():
