@@ -162,12 +162,13 @@ def test_oracle_agrees_with_reference_opencl_backend(tmp_path):
         print("katago_opencl testgpuerror exit code %d (its own fp16-vs-fp32 check); margins %s" % (r.returncode, margins))
 
 
-@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+@pytest.mark.parametrize("prec", ["auto", "fp16", "bf16"])
 def test_reference_gpuerror_acceptance_on_hip(tmp_path, prec):
     """The reference's cross-backend acceptance test `testgpuerror` (command/gputest.cpp; thresholds
     tests/testnnevalcanary.cpp:787-788 fp32, :806-807 reduced precision) on the katamx backend: real net (g170-b6c96), the
     reference's own 9x9 positions, reference values written by the oracle in the role of the Eigen build. The test also
     builds an "fp32" evaluator; katamx has none, so katamxPrecision pins both evaluators to the mode under test.
+      auto: the backend default = fp16 with the 1/8 range transform (round 3): at most a quarter of the reduced-precision limits;
       fp16: passes outright — even the strict fp32-vs-fp32 limits (exit code 0);
       bf16: within the reduced-precision limits ("current cfg error vs reference"); only the strict fp32 rows exceed."""
     if not os.path.exists(G170):
@@ -185,5 +186,11 @@ def test_reference_gpuerror_acceptance_on_hip(tmp_path, prec):
     margins = {k: float(v) for k, v in re.findall(r": ((?:batched )?(?:fp32|current cfg)) error vs reference closest margin:\s+([\d.eE+-]+)x of limit", out)}
     assert len(margins) == 4, out[-3000:]
     assert margins["current cfg"] < 1.0 and margins["batched current cfg"] < 1.0, margins
-    if prec == "fp16":
+    if prec in ("fp16", "auto"):
         assert r.returncode == 0 and margins["fp32"] < 1.0, (margins, out[-1500:])
+    if prec == "auto":
+        assert margins["current cfg"] <= 0.25 and margins["batched current cfg"] <= 0.25, margins
+    keep = os.path.join(REPO, "gpurun_out")
+    if os.path.isdir(keep):
+        with open(os.path.join(keep, "testgpuerror_g170_%s.txt" % prec), "w") as f:
+            f.write("katago_hip testgpuerror -quick on g170-b6c96 9x9, katamxPrecision=%s: margins (x of the reference's limits) %s\n" % (prec, margins))
