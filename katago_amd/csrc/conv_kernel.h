@@ -63,6 +63,8 @@ enum { ABL_NO_EPILOGUE = 1, ABL_NO_COMPUTE = 2, ABL_NO_DMA = 4, ABL_NO_LDS_READ 
        ABL_EPI_NOACT = 512, ABL_EPI_NOSTORE = 1024,
        ABL_TIMING = 2048 /* s_memtime stamps between the segments of a step, summed per wave into ConvArgs::dbg */,
        ABL_TWOLOADERS = 16384 /* the previous division of the DMA work in the 8-wave 3x3 / 5x5 shapes: weights by waves 0-3, board image by waves 4-7 */,
+       ABL_NT_EPI = 32768 /* EXPERIMENT: the epilogue's stores and residual loads carry the non-temporal hint (streaming data: written once, read once by a later launch) */,
+       ABL_NT_DMA = 65536 /* EXPERIMENT: the board image's LDS-DMA requests carry the non-temporal hint (aux = 2): each CU reads its board once */,
        ABL_PRIO = 8192 /* EXPERIMENT: waves 4-7 (the younger wave of each SIMD, which loses the issue arbitration) run the main loop at s_setprio 1 */,
        ABL_BP2 = 4096 /* EXPERIMENT, not an ablation: work-group barrier on even taps only (Geom::BP = 2). Carried in this
                          parameter so that the product kernels (ABL = 0) keep their symbols and their code. */ };
@@ -184,6 +186,10 @@ __device__ __forceinline__ void waitVmSel(int n) {
 __device__ __forceinline__ void dma16(const void* gsrc, unsigned ldsWaveBase) {
   __builtin_amdgcn_global_load_lds(
     (const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)(size_t)ldsWaveBase, 16, 0, 0);
+}
+__device__ __forceinline__ void dma16nt(const void* gsrc, unsigned ldsWaveBase) {  // aux = 2: non-temporal
+  __builtin_amdgcn_global_load_lds(
+    (const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)(size_t)ldsWaveBase, 16, 0, 2);
 }
 __device__ __forceinline__ void dma4(const void* gsrc, unsigned ldsWaveBase) {
   __builtin_amdgcn_global_load_lds(
@@ -307,7 +313,8 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
     const bool live = j >= 0 && chunk < nChunks && pbase * 16 < G::ACT_BYTES;
     const unsigned off = srcOff[jj];
     const char* src = (off & 0x80000000u) ? zero + (off & 0x7fffffffu) : inBoard + off;
-    dma16(src, live ? bufA + (chunk % G::NSA) * G::ACT_BYTES + pbase * 16 : mySlack);
+    if(ABL & ABL_NT_DMA) dma16nt(src, live ? bufA + (chunk % G::NSA) * G::ACT_BYTES + pbase * 16 : mySlack);
+    else dma16(src, live ? bufA + (chunk % G::NSA) * G::ACT_BYTES + pbase * 16 : mySlack);
     if(j >= 0) srcOff[jj] = off + KCHUNK * sizeof(T);
   };
 
@@ -642,7 +649,7 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
     for(int j = 0; j < 2; j++) {
       const int c = cout0 + wn * (32 * WN) + ct * 32 + 16 * j + 8 * khalf;
       const T* src = (c >= a.rawBegin && c < a.rawEnd) ? rrow + c : (const T*)zero;
-      dst[j] = *(const u32x4*)src;
+      dst[j] = (ABL & ABL_NT_EPI) ? __builtin_nontemporal_load((const u32x4*)src) : *(const u32x4*)src;
     }
   };
   if(RESID) loadResid(0, 0, rq[0]);
@@ -722,6 +729,7 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
           const int c = cout0 + chTile + 16 * j + 8 * khalf;
           T* const dst = (live && c >= a.rawBegin && c < a.rawEnd) ? rawRow + c : trash;
           if(ABL & ABL_EPI_NOSTORE) asm volatile("" ::"v"(rawQ[j]));
+          else if(ABL & ABL_NT_EPI) __builtin_nontemporal_store(rawQ[j], (u32x4*)dst);
           else *(u32x4*)dst = rawQ[j];
         }
       }
@@ -733,6 +741,7 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
           const int c = cout0 + chTile + 16 * j + 8 * khalf;
           T* const dst = (live && c >= a.actBegin && c < a.actEnd) ? actRow + c : trash;
           if(ABL & ABL_EPI_NOSTORE) asm volatile("" ::"v"(actQ[j]));
+          else if(ABL & ABL_NT_EPI) __builtin_nontemporal_store(actQ[j], (u32x4*)dst);
           else *(u32x4*)dst = actQ[j];
         }
       }
