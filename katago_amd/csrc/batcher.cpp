@@ -61,6 +61,7 @@ class Batcher {
     for(int i = 0; i < numSlots; i++) slots_.emplace_back();
     for(Slot& s : slots_) {
       s.eng.reset(new Engine(model, nnXLen, nnYLen, maxBatch, dtype, device));
+      s.eng->setSharesDevice(maxInFlight > 1);
       s.sym.resize(maxBatch);
       s.opt.resize(maxBatch);
       s.rows.resize(maxBatch);

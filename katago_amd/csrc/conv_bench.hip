@@ -253,6 +253,7 @@ double benchSeam(int batch, int iters, int timing) {
   pa.scale2 = f2.scale.as<float>(); pa.bias2 = f2.bias.as<float>(); pa.actKind2 = KMX_ACT_MISH;
   pa.mask = mask.as<float>(); pa.cells = (long long)cells; pa.zeroPage = zero.get();
   pa.dbg = timing ? dbg.as<unsigned long long>() : nullptr;
+  pa.alone = 1;
   hipStream_t st = nullptr;
   auto launch = [&]() { hipCheck(launchPointwisePair(dtype, C1, C2, C3, pa, st), "bench seam launch"); };
   for(int i = 0; i < 3; i++) launch();

@@ -336,6 +336,7 @@ void Engine::addSeam(const ConvDesc& post, const void* in, int inStride, const S
     if(n >= fuseMinRows_) {
       PwPairArgs x = pa;
       x.cells = (long long)n * S;
+      x.alone = cfgScale_ <= 1 && !sharesDevice_;
       hipCheck(launchPointwisePair(dtype_, C1, C2, C3, x, st), "pointwise pair launch");
     }
     else {
@@ -1242,6 +1243,7 @@ void testPointwisePair(int dtype, int batch, int X, int Y, int c1, int c2, int c
     pa.w2 = f2.w.get(); pa.rawOut2 = midRaw.get(); pa.actOut2 = midAct.get(); pa.midC = midStride;
     pa.scale2 = f2.scale.as<float>(); pa.bias2 = f2.bias.as<float>(); pa.actKind2 = act2;
     pa.mask = h.mask.as<float>(); pa.cells = (long long)cells; pa.zeroPage = h.zero.get();
+    pa.alone = 1;  // the unit hook tests the persistent kernel where it exists (KMX_PW_V2=0: the one-tile-per-group kernel)
     hipCheck(launchPointwisePair(dtype, c1, c2, c3, pa, h.st), "pointwise pair launch");
   }
   else {

@@ -119,6 +119,9 @@ class Engine {
   // The convolution work-group shape is chosen for `rows * scale` boards: a handle that runs two engines side by side
   // on two streams sets 2, so that each half still uses the 8-wave shape (the other half fills the rest of the chip).
   void setConcurrency(int scale) { cfgScale_ = scale < 1 ? 1 : scale; }
+  // Other engines' passes run on the same device at the same time (the batcher's batches in flight): kernels that exist in a
+  // "chip to itself" and a "side by side" form (the seam, kernels.h PwPairArgs::alone) take the latter.
+  void setSharesDevice(bool shares) { sharesDevice_ = shares; }
   // Record `ev` on this engine's stream after the first `afterOps` launches of the next pass (0: at entry, before the
   // row parameters are staged); null clears it. A second engine's stream waits for it (kmx_api.cpp, split handle).
   void setForkPoint(int afterOps, hipEvent_t ev) { forkOps_ = afterOps < 0 ? 0 : afterOps; forkEv_ = ev; }
@@ -200,6 +203,7 @@ class Engine {
   int stagingSlot_ = 0;
   bool hostAnyOwner_ = false;
   int cfgScale_ = 1;
+  bool sharesDevice_ = false;
   bool fuseSeams_ = true;   // KMX_FUSE_SEAMS=0: always the two convolution launches
   bool packInputs_ = false;  // KMX_PACK_INPUTS=1: kmx_eval bit-packs 0/1 planes while staging. Off: measured on MI355X (b18c384nbt, batch 256,
                             // synchronous host entry) 32.9 k evals/s with it against 39.2 k without - the caller's thread packs while the GPU idles,

@@ -86,6 +86,14 @@ struct PwPairArgs {
   long long cells;       // N * S
   const void* zeroPage;  // >= 64 readable zero bytes
   unsigned long long* dbg;  // instrumentation only (conv_bench.hip benchSeam): per-wave cycle sums of the persistent kernel's phases
+  // 1: the launch has the chip to itself. The persistent, software-pipelined kernel (one work-group per CU for the whole launch) is
+  // taken when the launch is alone (39.6 k against 37.9 k evals/s at batch 256 on one stream, 28.6 k against 28.1 k at batch 128) or
+  // has at least two tiles per CU whatever runs beside it (two streams of 256 boards: 40.5 k against 39.1 k; the batcher's 256-row
+  // batches, two in flight: 39.6 k against 37.4 k rows/s). A launch of fewer tiles beside other streams' kernels - the two 128-board
+  // halves of a split batch: 361 tiles each - takes the one-tile-per-work-group kernel: short work-groups free their CU tile by tile
+  // and let the other stream's kernels in (41.5 k against 40.5-40.9 k on one box, equal within noise on another;
+  // profiles/r03_steps/seam_two_streams*.txt).
+  int alone;
 };
 hipError_t launchPointwisePair(int dtype, int c1, int c2, int c3, const PwPairArgs& a, hipStream_t stream);
 bool pointwisePairSupported(int c1, int c2, int c3);  // is there a kernel for these channel counts?

@@ -35,6 +35,13 @@ bool persistentWanted() {
   }();
   return on;
 }
+bool persistentForced() {  // KMX_PW_V2=2: the persistent kernel whatever runs beside it (A/B)
+  static const bool on = [] {
+    const char* e = getenv("KMX_PW_V2");
+    return e != nullptr && atoi(e) == 2;
+  }();
+  return on;
+}
 int numComputeUnits() {  // per device: one persistent work-group per CU (KMX_PW_GRID overrides: tests walk several tiles per group)
   static const int forced = [] {
     const char* e = getenv("KMX_PW_GRID");
@@ -56,7 +63,9 @@ int numComputeUnits() {  // per device: one persistent work-group per CU (KMX_PW
 
 template <class TR>
 hipError_t launchT(int c1, int c2, int c3, const PwPairArgs& a, hipStream_t stream) {
-  if(c1 == 192 && c2 == 384 && c3 == 192 && a.actOut == nullptr && a.actKind1 == a.actKind2 && pwWaves() == 8 && persistentWanted()) {
+  if(c1 == 192 && c2 == 384 && c3 == 192 && a.actOut == nullptr && a.actKind1 == a.actKind2 && pwWaves() == 8 && persistentWanted() &&
+     (a.alone != 0 || (a.cells + pw2::TM - 1) / pw2::TM >= 2LL * numComputeUnits() || persistentForced()))
+  {
     if(a.actKind1 == KMX_ACT_MISH) {
       if(a.dbg != nullptr) return pw2::launchPersistent<TR, 6, 12, 3, KMX_ACT_MISH, KMX_ACT_MISH, true>(a, numComputeUnits(), stream);
       return pw2::launchPersistent<TR, 6, 12, 3, KMX_ACT_MISH, KMX_ACT_MISH>(a, numComputeUnits(), stream);

@@ -29,6 +29,7 @@
 #define KMX_POINTWISE2_KERNEL_H_
 
 #include <atomic>
+#include <cstdlib>
 
 #include "device_common.h"
 
@@ -447,7 +448,18 @@ hipError_t launchPersistent(const PwPairArgs& a, int maxGrid, hipStream_t stream
   }
   if(a.cells <= 0 || a.actOut != nullptr) return hipErrorInvalidValue;
   const long long tiles = (a.cells + TM - 1) / TM;
-  const long long grid = tiles < maxGrid ? tiles : maxGrid;
+  // Balanced grid: with k = ceil(tiles / CUs) tiles per work-group, ceil(tiles / k) work-groups finish in the same k rounds as one
+  // per CU would and leave the other CUs to whatever else is runnable - the other half-batch stream's kernel (361 tiles of a
+  // 128-board half: 181 work-groups of two tiles instead of 256 of which 151 would walk a single tile). KMX_PW_BALANCE=0: one per CU.
+  static const bool balance = [] {
+    const char* e = getenv("KMX_PW_BALANCE");
+    return e == nullptr || atoi(e) != 0;
+  }();
+  long long grid = tiles < maxGrid ? tiles : maxGrid;
+  if(balance && tiles > maxGrid) {
+    const long long perGroup = (tiles + maxGrid - 1) / maxGrid;
+    grid = (tiles + perGroup - 1) / perGroup;
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), G::LDS_BYTES, stream, a);
   return hipGetLastError();
 }
