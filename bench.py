@@ -114,7 +114,10 @@ def measured_traffic(args):
                            capture_output=True, text=True, timeout=600, env=env, cwd=os.environ.get("TMPDIR", "/tmp"))
         if r.returncode != 0:
             return {"error": "rocprofv3 --pmc %s failed: %s" % (c, (r.stdout + r.stderr)[-300:])}
-    rocpd_summary.main(d, os.path.join(d, "summary"))
+    import contextlib
+
+    with contextlib.redirect_stdout(sys.stderr):  # the summariser reports what it wrote; stdout carries ONE line, the JSON
+        rocpd_summary.main(d, os.path.join(d, "summary"))
 
     def per_dispatch(counter, key):
         tot = disp = 0.0
