@@ -181,7 +181,7 @@ def caller_rates(model_path, tmp):
             f.write(CALLER_CFG % os.path.join(tmp, "kmx_bench_gtp_logs"))
         env = dict(os.environ, KATAMX_LEAVES_PER_THREAD="16")
         r = subprocess.run([hipx, "benchmark", "-model", model_path, "-config", cfg, "-v", "8000", "-t", "1024", "-boardsize", "19", "-n", "4"],
-                           capture_output=True, text=True, timeout=300, env=env, cwd=tmp)
+                           capture_output=True, text=True, timeout=120, env=env, cwd=tmp)
         m = re.findall(r"visits/s = ([\d.]+) nnEvals/s = ([\d.]+).*avgBatchSize = ([\d.]+)", (r.stdout + r.stderr).replace("\r", "\n"))
         if r.returncode == 0 and m:
             out["reference_benchmark_nn_evals_per_s"] = float(m[-1][1])
@@ -206,7 +206,7 @@ def caller_rates(model_path, tmp):
                     "nnCacheSizePowerOfTwo=18,nnMutexPoolSizePowerOfTwo=14,logGamesEvery=1000,numNNServerThreadsPerModel=2" % moves_cap)
             env = dict(os.environ, KATAMX_LEAVES_PER_THREAD="8")
             r = subprocess.run([hipx, "selfplay", "-config", cfg_sp, "-models-dir", os.path.join(d, "models"), "-output-dir", os.path.join(d, "out"),
-                                "-max-games-total", "8", "-override-config", over], capture_output=True, text=True, timeout=300, cwd=d, env=env)
+                                "-max-games-total", "8", "-override-config", over], capture_output=True, text=True, timeout=120, cwd=d, env=env)
             log = r.stdout + r.stderr
             if r.returncode == 0 and "Total selfplay runtime (seconds): " in log:
                 games = int(log.split("Total games: ")[1].split()[0])
@@ -403,7 +403,10 @@ def main():
     callers = None
     if rank == 0 and world == 1 and not args.no_callers:
         handle.sync()
-        callers = caller_rates(model_path, tmp)
+        try:  # informative extras: whatever goes wrong here (a missing binary, a hung child) must not cost the bench line
+            callers = caller_rates(model_path, tmp)
+        except Exception as e:  # noqa: BLE001
+            callers = {"callers_error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
     if rank == 0:
         value = total_rows / elapsed
