@@ -32,7 +32,7 @@
 
 namespace {
 
-constexpr size_t STACK_BYTES = 1u << 20;  // the descent is recursive (one frame per ply, search.cpp:1440); pages are committed on touch
+constexpr size_t STACK_BYTES = 2u << 20;  // the descent is recursive (one frame per ply, search.cpp:1440); pages are committed on touch
 constexpr size_t GUARD_BYTES = 1u << 12;
 
 std::atomic<uint64_t> gFibersRun{0}, gParks{0}, gBlockingWaits{0};

@@ -8,7 +8,7 @@
 //
 // Here a "search thread" of the reference (one invocation of the task that Search::performTaskWithThreads fans out,
 // cpp/search/searchmultithreadhelpers.cpp:77-92, with its own SearchThread state, search.cpp:567-620) runs on a FIBER: a
-// user-level context with its own stack. K fibers share an OS thread. When a fiber's leaf has been handed to the device
+// user-level context with its own stack (2 MB of address space, committed on touch). K fibers share an OS thread. When a fiber's leaf has been handed to the device
 // (KatamxNNEval::begin returned with the leaf in flight), this repo's NNEvaluator::evaluate parks the fiber instead of
 // blocking; the OS thread continues with its next fiber - which descends again, sees the virtual losses of the parked
 // descents and submits another leaf - and only when all of its fibers are parked does it block, on the OLDEST ticket.
