@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 3, call 14: the full -m gpu suite at HEAD + smoke + split-ways scan
+# round 3: the full -m gpu suite at HEAD + smoke + split-ways scan
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-OUT=gpurun_out/r3c14
+OUT=gpurun_out/full_suite_r03
 rm -rf $OUT; mkdir -p $OUT
 timeout 1800 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=12 2>&1 | tail -40 > $OUT/pytest_gpu.log
 cat $OUT/pytest_gpu.log
