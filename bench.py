@@ -71,8 +71,9 @@ def cpu_baseline(model_path, batch_rows, min_seconds=10.0, max_seconds=30.0):
 
     om = oracle.loadModelFile(model_path)
     sp, gl = synthetic_rows(batch_rows, 4242)
-    # the GPU box reports 256 logical CPUs; the oracle's OpenMP loops (batch x channel tiles) do not scale that far
-    # (0.26 evals/s with 256 threads), so at most 32 threads are used and that is the number reported as `cores`.
+    # the GPU box reports 256 logical CPUs but does not deliver them: one OpenMP team of 256 threads measures 0.26 evals/s, eight
+    # pinned 32-thread processes together 4.9 (round 3, profiles/r03_steps/cpu_baseline_256_threads.txt) against ~20 for ONE team of
+    # 32 - the container's CPU share, not the oracle's loops, is the limit. 32 threads are used and reported as `cores`.
     cores = oracle.usable_cores(32)
     rows = 0
     t0 = time.time()

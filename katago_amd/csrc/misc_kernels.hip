@@ -265,7 +265,7 @@ __global__ __launch_bounds__(GV_THREADS) void gpoolApplyVecKernel(const GPoolArg
       const int kg = idx / R, r = idx - kg * R;
       const int k0 = kg * K / KG, k1 = (kg + 1) * K / KG;
       float acc = 0.0f;
-#pragma unroll 8
+#pragma unroll 16
       for(int k = k0; k < k1; k++) acc += feat[k] * a.w[(size_t)k * R + r];
       partial[idx] = acc;
     }
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(GV_THREADS) void gpoolApplyVecKernel(const GPoolArg
   }
   __syncthreads();
   const int RV = R / 8;
-  constexpr int UN = 4;  // loads of UN iterations in flight before the first is consumed
+  constexpr int UN = 12;  // loads of UN iterations in flight before the first is consumed: a 19x19 board of 128 channels is ONE burst per thread
   if(GV_THREADS % RV == 0) {
     // every thread keeps ONE group of 8 channels for all its cells: bias, BN scale and BN bias live in registers
     const int rv = tid % RV, pStep = GV_THREADS / RV;
