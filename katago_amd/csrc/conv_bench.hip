@@ -26,6 +26,7 @@ hipError_t launchVariant(int ks, int cfg, int variant, const ConvArgs& a, hipStr
   V(3, 2, 3, 3, 1) V(3, 2, 3, 3, 2) V(3, 2, 3, 3, 4) V(3, 2, 3, 3, 5) V(3, 2, 3, 3, 512) V(3, 2, 3, 3, 1024)
   V(3, 2, 3, 2, 0) V(3, 2, 3, 4, 0) V(3, 2, 3, 4, 2048)
   V(3, 2, 3, 3, 16384 + 2048)  // ABL_TWOLOADERS
+  V(3, 2, 3, 3, 131072) V(1, 2, 3, 3, 131072) V(3, 1, 3, 2, 131072)  // ABL_BATCHED: the round-2 form of a step, for A/B
   V(3, 2, 3, 3, 0) V(3, 2, 3, 3, 32768) V(3, 2, 3, 3, 65536) V(3, 2, 3, 3, 32768 + 65536)  // product shape again / ABL_NT_EPI / ABL_NT_DMA / both
 #undef V
   return hipErrorInvalidValue;

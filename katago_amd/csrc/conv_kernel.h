@@ -65,6 +65,7 @@ enum { ABL_NO_EPILOGUE = 1, ABL_NO_COMPUTE = 2, ABL_NO_DMA = 4, ABL_NO_LDS_READ 
        ABL_TWOLOADERS = 16384 /* the previous division of the DMA work in the 8-wave 3x3 / 5x5 shapes: weights by waves 0-3, board image by waves 4-7 */,
        ABL_NT_EPI = 32768 /* EXPERIMENT: the epilogue's stores and residual loads carry the non-temporal hint (streaming data: written once, read once by a later launch) */,
        ABL_NT_DMA = 65536 /* EXPERIMENT: the board image's LDS-DMA requests carry the non-temporal hint (aux = 2): each CU reads its board once */,
+       ABL_BATCHED = 131072 /* the round-2 form of a step (A/B): the six fragment reads of a half-step as one batch behind its first MFMA, the step's LDS-DMA requests as one batch between the halves */,
        ABL_PRIO = 8192 /* EXPERIMENT: waves 4-7 (the younger wave of each SIMD, which loses the issue arbitration) run the main loop at s_setprio 1 */,
        ABL_BP2 = 4096 /* EXPERIMENT, not an ablation: work-group barrier on even taps only (Geom::BP = 2). Carried in this
                          parameter so that the product kernels (ABL = 0) keep their symbols and their code. */ };
@@ -261,6 +262,10 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   // the younger waves only multiply. (tools/conv_timing.py; ABL_TWOLOADERS restores the previous division for comparison.)
   // (possible when the image pieces have all been requested before the slab that is waited for at the last tap: LS <= NT + 1 - D)
   constexpr bool ONE = ROLES && SPREAD && BP == 1 && G::LS <= NT + 1 - D && !(ABL & ABL_TWOLOADERS);
+  // the step's fragment reads (and, in the ONE division, its DMA requests) spread over its MFMAs: needs a slot per read in each half
+  constexpr bool SPREAD_STEP = WN * MT >= WN + MT && !(ABL & (ABL_BATCHED | ABL_TIMING));
+  constexpr int SLOTS = WN * MT - (WN + MT);                           // MFMAs of a half-step that carry no fragment read
+  constexpr bool SPREAD_DMA = SPREAD_STEP && ONE && 2 * SLOTS >= 1 + NPW;  // the image piece(s) of the tap + the slab's instructions
   const bool wLoader = !ROLES || wave < 4;        // wave-uniform
   const bool aLoader = !ROLES || (ONE ? wave < 4 : wave >= 4);
   const int lw = wave;                            // index among the weight-loading waves
@@ -512,6 +517,27 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
       for(int j = 0; j < NPA; j++) issueA(chunk + D, j);
     }
   };
+  // (SPREAD_DMA) the k-th request of a step in the ONE division: k = 0 the image piece of this tap (if any), k = 1 .. NPW the
+  // slab's instructions - the same requests in the same order as issueStep, one call each
+  auto issueOneDma = [&](int chunk, int t, int step, int k) {
+    if(!ONE || !wLoader) return;
+    if(ABL & (ABL_NO_DMA)) return;
+    if(k == 0) {
+#pragma unroll
+      for(int i = 0; i < G::PPS; i++)
+        if(t * G::PPS + i < NPA) issueA(chunk + 1, t * G::PPS + i);
+      return;
+    }
+    const int j = k - 1;
+    if(j >= NPW) return;
+    const int stepW = step + D;
+    const bool live = stepW < nSteps;
+    const char* slab = wBase + (size_t)(live ? stepW : 0) * wSlabStride;
+    const unsigned dst = bufW + (stepW % G::NSW) * G::W_BYTES;
+    const int pbase = (j * G::NLW + (lw % G::NLW)) * 64;
+    const bool inRange = live && pbase < G::WPIECES;
+    dma16(slab + wOff[j], inRange ? dst + pbase * 16 : mySlack);
+  };
   // top-of-step wait of this wave's own requests: everything the barrier is about to publish
   auto waitStep = [&](int t) {
     if(ABL & (ABL_NO_DMA | ABL_NO_VMWAIT | ABL_NO_W_DMA | ABL_NO_A_DMA)) return;
@@ -574,6 +600,51 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
       // The compiler's own s_waitcnt before an MFMA drains ALL outstanding LDS reads (lgkmcnt(0)), so each batch of
       // reads is issued right AFTER the first MFMA of the other fragment set: the wait it causes then only covers
       // reads that had eight MFMAs to land.
+      if constexpr(SPREAD_STEP) {
+        // Round 3: the WN + MT fragment reads of a half-step ride behind its first MFMAs ONE BY ONE, and (8-wave 3x3 / 5x5 shapes) so
+        // do the step's LDS-DMA requests behind the later ones. As batches - six ds_read_b128 behind the first MFMA, three or four
+        // DMA instructions between the halves - they held the wave's issue stage while its matrix core ran dry: a DMA instruction
+        // costs its wave 100-150 cycles of issue, and all eight waves hit the LDS with their batches right after the barrier.
+        // 3x3 192->192, batch 256, same box: 64.3 -> 61.8 us (act only), 76.7 -> 73.1 us (residual); profiles/r03_steps/conv_spread_step.txt.
+        // Same MFMAs in the same order: results are bit-identical to the batched form (ABL_BATCHED; the cycle stamps use it too).
+        const unsigned wb1 = wLane[1] + (unsigned)(step % G::NSW) * G::W_BYTES;
+#pragma unroll
+        for(int idx = 0; idx < WN * MT; idx++) {
+          mfmaPart(0, idx, idx + 1, acc);
+          __builtin_amdgcn_sched_barrier(0);
+          if(idx < WN) wf[1][idx] = ldsV8(wb1 + idx * 32 * ROWB);
+          else if(idx < WN + MT) af[1][idx - WN] = ldsV8(aAddr[idx - WN] ^ 0x20u);
+          if constexpr(SPREAD_DMA) {
+            if(idx >= WN + MT) issueOneDma(chunk, t, step, idx - (WN + MT));  // requests 0 .. WN*MT - WN - MT - 1
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr(!SPREAD_DMA) issueStep(chunk, t, step);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned wb0 = wLane[0] + (unsigned)((step + 1) % G::NSW) * G::W_BYTES;
+        {
+          const int tn = t + 1 < NT ? t + 1 : 0;
+          unsigned sTap = (unsigned)(((tn / KS - HALO) * W2 + (tn % KS - HALO)) * 4) + ((ldsBase + (t + 1 < NT ? curA : nextA)) >> 4);
+          asm volatile("" : "+s"(sTap));
+#pragma unroll
+          for(int pt = 0; pt < MT; pt++) {
+            const unsigned q4 = aRow4[pt] + sTap;
+            aAddr[pt] = (q4 << 4) | ((q4 ^ c40) & 0x30u);
+          }
+        }
+#pragma unroll
+        for(int idx = 0; idx < WN * MT; idx++) {
+          mfmaPart(1, idx, idx + 1, acc);
+          __builtin_amdgcn_sched_barrier(0);
+          if(idx < WN) wf[0][idx] = ldsV8(wb0 + idx * 32 * ROWB);
+          else if(idx < WN + MT) af[0][idx - WN] = ldsV8(aAddr[idx - WN]);
+          if constexpr(SPREAD_DMA) {
+            if(idx >= WN + MT) issueOneDma(chunk, t, step, SLOTS + idx - (WN + MT));  // the rest
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        continue;
+      }
       mfmaPart(0, 0, 1, acc);
       __builtin_amdgcn_sched_barrier(0);
       readW(1, step);

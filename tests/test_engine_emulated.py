@@ -50,7 +50,7 @@ def emu_lib(tmp_path_factory):
 # show is anything about asynchronous completion (the s_waitcnt / ring-depth logic): the copies are immediate here.
 CONV_REWRITES = [
     (r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\(N\) : "memory"\);', ";", 1),
-    (r'asm volatile\("" : "\+s"\(sTap\)\);', ";", 1),
+    (r'asm volatile\("" : "\+s"\(sTap\)\);', ";", 2),
     (r'asm volatile\("" ::"v"\((rawQ|actQ)\[j\]\)\);', ";", 2),
     (r'asm volatile\("" : "\+v"\(pOff\)\);', ";", 1),
     (r'extern __shared__ __attribute__\(\(aligned\(256\)\)\) char smem\[\];', "char* const smem = (char*)emu::dynLds();", 1),

@@ -1,16 +1,18 @@
 #!/bin/bash
-# parity of the layers / whole nets and one driver-style bench line (scratch: a quick check after a small kernel change)
+# parity of the layers / whole nets and driver-style bench lines (a quick check after a kernel change)
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/quick
 rm -rf $OUT; mkdir -p $OUT
-timeout 600 python -m pytest tests/test_gpu_layers.py tests/test_gpu_model.py tests/test_gpu_fuzz.py -m gpu -x -q -p no:cacheprovider 2>&1 | tail -3 | tee $OUT/parity.log
-timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
-python - <<'P'
-import json
-d=json.loads([l for l in open('gpurun_out/quick/bench.json') if l.startswith('{')][0])
-print(d['value'], d['roofline']['frac'], d['roofline_seam']['frac'], d['roofline']['kernel_avg_launch_us'], d['box'])
-print(d['cpu_baseline'])
-print({k: d.get(k) for k in ('host_rows_through_batcher_per_s','reference_benchmark_nn_evals_per_s','selfplay_nn_rows_per_s','callers_error')})
-P
+timeout 900 python -m pytest tests/test_gpu_layers.py tests/test_gpu_model.py tests/test_gpu_fuzz.py tests/test_gpu_pointwise.py tests/test_gpu_transformer.py -m gpu -x -q -p no:cacheprovider 2>&1 | tail -3 | tee $OUT/parity.log
+for rep in 1 2 3; do
+for mode in 0 1; do
+for var in 0 134072; do
+  timeout 60 python tools/conv_one.py 3 23 $var 192 192 $mode 40 2>/dev/null | tee -a $OUT/conv_spread_step.txt
+done; done; done
+for c in "1 23 0 384 192 1" "1 23 134072 384 192 1" "3 13 0 192 192 1" "3 13 134072 192 192 1"; do timeout 60 python tools/conv_one.py $c 40 2>/dev/null | tee -a $OUT/conv_spread_step.txt; done
+for rep in 1 2; do
+timeout 200 python bench.py --no-cpu-baseline --no-callers --steps 60 --warmup 5 2>> $OUT/bench.err | grep -o '"value": [0-9.]*\|"frac": [0-9.]*' | tr '\n' ' ' | tee -a $OUT/bench.txt; echo | tee -a $OUT/bench.txt
+timeout 200 python bench.py --no-cpu-baseline --no-callers --steps 60 --warmup 5 --dtype bf16 2>> $OUT/bench.err | grep -o '"value": [0-9.]*\|"frac": [0-9.]*' | tr '\n' ' ' | tee -a $OUT/bench.txt; echo " (bf16)" | tee -a $OUT/bench.txt
+done
