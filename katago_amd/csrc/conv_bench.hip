@@ -353,13 +353,81 @@ __global__ __launch_bounds__(512) void mfmaPeakKernel(int steps, int barEvery, u
   }
 }
 
+// ---- what it costs a wave to ISSUE its operand traffic in the small-batch step shape (6 MFMAs per step, one wave per SIMD) ----
+// VARIANT 0: MFMAs only; 1: + two LDS-DMA instructions (global_load_lds, 1 KiB each) per step; 2: + two plain global_load_dwordx4
+// into registers, written to LDS with ds_write_b128 a step later (register staging). Sources are 2 KiB per wave of an L2-resident
+// buffer; at most the requests of two steps are in flight. (kmx_bench_mfma, mode = 256 + VARIANT; tools/issue_cost.py.)
+template <int VARIANT>
+__global__ __launch_bounds__(256) void issueCostKernel(int steps, const char* src, unsigned long long* clocks, float* sink) {
+  extern __shared__ __attribute__((aligned(256))) char smemIc[];
+  typedef TraitsBF16 TR;
+  typedef TR::V8 V8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smemIc;
+  f32x16 acc[3];
+#pragma unroll
+  for(int i = 0; i < 3; i++)
+#pragma unroll
+    for(int r = 0; r < 16; r++) acc[i][r] = 0.0f;
+  V8 wf, af[3];
+#pragma unroll
+  for(int i = 0; i < 8; i++) {
+    wf[i] = (TR::T)(0.001f * (float)lane);
+    af[0][i] = af[1][i] = af[2][i] = (TR::T)(0.002f * (float)(lane + i));
+  }
+  const char* mine = src + ((size_t)blockIdx.x % 64) * 8192 + wave * 2048 + lane * 16;
+  u32x4 stage[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  const unsigned long long c0 = clock64(), w0 = wall_clock64();
+  for(int s = 0; s < steps; s++) {
+    const unsigned slot = ldsBase + (unsigned)(wave * 4 + (s & 1) * 2) * 1024u;
+    if(VARIANT == 1) {
+      dma16(mine, slot);
+      dma16(mine + 1024, slot + 1024);
+    }
+    if(VARIANT == 2) {
+      *(__attribute__((address_space(3))) u32x4*)(size_t)(slot + lane * 16) = stage[0];
+      *(__attribute__((address_space(3))) u32x4*)(size_t)(slot + 1024 + lane * 16) = stage[1];
+      stage[0] = *(const u32x4*)mine;
+      stage[1] = *(const u32x4*)(mine + 1024);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for(int kk = 0; kk < 2; kk++)
+#pragma unroll
+      for(int pt = 0; pt < 3; pt++) acc[pt] = TR::mfma(wf, af[pt], acc[pt]);
+    __builtin_amdgcn_sched_barrier(0);
+    if(VARIANT == 1) waitVm<2>();
+  }
+  waitVm<0>();
+  const unsigned long long c1 = clock64(), w1 = wall_clock64();
+  float t = (float)(stage[0][0] + stage[1][3]);
+#pragma unroll
+  for(int i = 0; i < 3; i++)
+#pragma unroll
+    for(int r = 0; r < 16; r++) t += acc[i][r];
+  if(t == 12345.678f) sink[lane] = t;
+  if(blockIdx.x == 0 && threadIdx.x == 0) {
+    clocks[0] = c1 - c0;
+    clocks[1] = w1 - w0;
+  }
+}
+
 // returns avg ms per launch; *tflops = achieved rate; *coreMhz = shader clock during the kernel (clock64 vs the 100 MHz wall clock)
 double benchMfma(int wavesPerWg, int wgs, int mode, int steps, int iters, double* tflops, double* coreMhz) {
   DevBuf clk(16), sink(1024);
   hipStream_t st = nullptr;
   const int barEvery = (mode >> 4) > 0 ? (mode >> 4) : 1;
+  DevBuf icSrc(64 * 8192 + 4096);
   auto launch = [&]() {
     dim3 g(wgs), b(wavesPerWg * 64);
+    if(mode >= 256) {  // issue-cost microbenchmark: 4 waves per work-group; *tflops then returns shader cycles per step
+      const char* srcp = (const char*)icSrc.get();
+      if(mode == 256) hipLaunchKernelGGL(issueCostKernel<0>, g, dim3(256), 65536, st, steps, srcp, clk.as<unsigned long long>(), sink.as<float>());
+      else if(mode == 257) hipLaunchKernelGGL(issueCostKernel<1>, g, dim3(256), 65536, st, steps, srcp, clk.as<unsigned long long>(), sink.as<float>());
+      else hipLaunchKernelGGL(issueCostKernel<2>, g, dim3(256), 65536, st, steps, srcp, clk.as<unsigned long long>(), sink.as<float>());
+      hipCheck(hipGetLastError(), "issue-cost bench launch");
+      return;
+    }
 #define KMX_PEAK(M_) \
   case M_: hipLaunchKernelGGL(mfmaPeakKernel<M_>, g, b, 65536, st, steps, barEvery, clk.as<unsigned long long>(), sink.as<float>()); break;
     switch(mode & 7) {
@@ -386,6 +454,7 @@ double benchMfma(int wavesPerWg, int wgs, int mode, int steps, int iters, double
   const double avg = (double)ms / iters;
   if(tflops) *tflops = 18.0 * 32768.0 * steps * wavesPerWg * (double)wgs / (avg * 1e-3) / 1e12;
   if(coreMhz) *coreMhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
+  if(mode >= 256 && tflops) *tflops = (double)h[0] / steps;  // shader cycles per step of wave 0 of work-group 0, last launch
   return avg;
 }
 
