@@ -277,8 +277,19 @@ class Batcher {
       // a batch the dispatcher has counted (running_) but not yet handed over is still coming
       cvComplete_.wait(l, [&] { return !inflight_.empty() || (closing_ && running_ == 0); });
       if(inflight_.empty()) return;
-      const int si = inflight_.front();
-      inflight_.pop_front();
+      // Batches finish in launch order when they are large (each fills the device); small ones side by side (SMALL_ROWS) need not:
+      // a batch behind the oldest that has already finished is delivered first instead of waiting for its elder.
+      size_t pick = 0;
+      if(inflight_.size() > 1) {
+        for(size_t i = 0; i < inflight_.size(); i++) {
+          Slot& c = slots_[inflight_[i]];
+          bool done = false;
+          try { done = c.error == KMX_OK && c.eng->idle(); } catch(...) { done = false; }
+          if(done) { pick = i; break; }
+        }
+      }
+      const int si = inflight_[pick];
+      inflight_.erase(inflight_.begin() + (long)pick);
       Slot& s = slots_[si];
       l.unlock();
       int err = s.error;

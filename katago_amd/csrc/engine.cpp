@@ -893,6 +893,14 @@ void Engine::sync() {
   hipCheck(hipSetDevice(device_), "hipSetDevice");
   hipCheck(hipStreamSynchronize(stream_), "stream synchronize");
 }
+bool Engine::idle() {
+  hipCheck(hipSetDevice(device_), "hipSetDevice");
+  const hipError_t e = hipStreamQuery(stream_);
+  if(e == hipSuccess) return true;
+  if(e == hipErrorNotReady) return false;
+  hipCheck(e, "hipStreamQuery");
+  return false;
+}
 
 // symmetry / optimism of the rows -> device. Pinned staging is double-buffered: the slot used two calls ago is free as
 // soon as ITS copies have run, so back-to-back asynchronous calls queue up without draining the stream in between.

@@ -100,6 +100,7 @@ class Engine {
                   const float* policyOptimism, float* dPolicy, float* dValue, float* dScore, float* dOwnership, bool sync);
   int numInputMetaChannels() const { return min_; }
   void sync();
+  bool idle();  // has everything queued on this engine's stream completed? (never blocks)
   // Staged entry (the batcher, batcher.cpp): rows are written by their submitters straight into this engine's pinned staging
   // - bit-packed planes, globals, metadata - then ONE call enqueues H2D, the pass and D2H without waiting; after sync() the
   // results sit in pinned memory. The engine must be idle when rows are staged (the batcher's slot state machine sees to it).

@@ -20,7 +20,7 @@ struct dim3 {
   dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorInvalidDevice = 101 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorInvalidDevice = 101, hipErrorNotReady = 600 };
 typedef void* hipStream_t;
 typedef void* hipEvent_t;
 typedef void* hipGraph_t;
@@ -64,6 +64,7 @@ inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = mall
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = malloc(8); return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = malloc(8); return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = malloc(8); return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }

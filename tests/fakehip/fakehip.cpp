@@ -146,6 +146,7 @@ hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned int) { *s = (hipStr
 hipError_t hipStreamCreate(hipStream_t* s) { *s = (hipStream_t)calloc(1, 8); own(*s); return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { free((void*)s); return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t s) { checkOwner("hipStreamSynchronize", s); return hipSuccess; }
+hipError_t hipStreamQuery(hipStream_t s) { checkOwner("hipStreamQuery", s); return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t, unsigned int) { checkOwner("hipStreamWaitEvent", s); return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned int) { *e = (hipEvent_t)calloc(1, 8); own(*e); return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)calloc(1, 8); own(*e); return hipSuccess; }
