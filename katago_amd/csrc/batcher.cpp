@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -57,6 +58,7 @@ class Batcher {
         q = hipGetDeviceProperties(&prop, device < 0 ? 0 : device) == hipSuccess ? prop.multiProcessorCount : 0;
       }
       sealAt_ = q > 0 && q < maxBatch ? q : maxBatch;
+      if(const char* e = getenv("KMX_BATCH_LINGER_US")) lingerUs_ = atoi(e) < 0 ? 0 : atoi(e);
     }
     for(int i = 0; i < numSlots; i++) slots_.emplace_back();
     for(Slot& s : slots_) {
@@ -221,6 +223,22 @@ class Batcher {
         if(filling_ < 0 || slots_[filling_].count == 0) return false;
         return running_ == 0 || (running_ < maxInFlight_ && rowsOnDevice_ + slots_[filling_].count <= SMALL_ROWS);
       });
+      // A short linger before a PARTIAL batch goes: the rows of the batch that has just been delivered come back one by one within a
+      // few hundred microseconds (each waiter wakes, post-processes, descends again, featurises), and greedy sealing on the first of
+      // them cuts what would be one batch into several small ones that then share the device - a pass costs ~2.5-3 ms whatever it
+      // holds up to ~64 rows, so rows per pass is what counts (64 leaves in flight: 15.3 k rows/s with at most two batches in flight,
+      // 11.9 k with eight). While fewer rows wait than the last delivered batch held, the dispatcher waits up to lingerUs_ more
+      // (KMX_BATCH_LINGER_US, default 150; 0 = the reference's pure greedy rule, threadsafequeue.h:173-189) - at most once per batch,
+      // 5 % of a pass.
+      if(!closing_ && sealed_.empty() && filling_ >= 0 && lingerUs_ > 0 && slots_[filling_].count < lastBatchRows_ &&
+         slots_[filling_].count < sealAt_)
+      {
+        const int f = filling_;
+        cvWork_.wait_for(l, std::chrono::microseconds(lingerUs_), [&] {
+          return closing_ || !sealed_.empty() || filling_ != f || slots_[f].count >= lastBatchRows_ || slots_[f].count >= sealAt_;
+        });
+        if(!closing_ && sealed_.empty() && filling_ < 0) continue;  // (cannot happen: only this thread seals a partial batch)
+      }
       if(closing_) {
         // rows that were never launched: fail their waiters
         auto fail = [&](int i) { finishSlot(slots_[i], KMX_ERR_INTERNAL, "the batcher shut down before this row was evaluated"); };
@@ -312,6 +330,7 @@ class Batcher {
       l.lock();
       if(err == KMX_OK) {
         rows_ += (uint64_t)s.count;
+        lastBatchRows_ = s.count;
         batches_ += 1;
       }
       rowsOnDevice_ -= s.count;
@@ -328,6 +347,8 @@ class Batcher {
   std::deque<int> sealed_, inflight_;
   int filling_ = -1, running_ = 0;
   int rowsOnDevice_ = 0;                    // rows of the batches between launch and completion
+  int lastBatchRows_ = 0;                   // rows of the batch delivered last: what a partial batch is expected to grow to
+  int lingerUs_ = 150;
   static constexpr int SMALL_ROWS = 96;     // partial batches may run side by side while the device holds at most this many rows
   bool closing_ = false;
   uint64_t nextTicket_ = 1;

@@ -1,16 +1,10 @@
 #!/bin/bash
-# parity of the layers / whole nets and a small-batch scan with and without the loader-wave shape
+# the tests that go through the leaf batcher (after a change to it), with their recorded rates
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/quick
 rm -rf $OUT; mkdir -p $OUT
-timeout 900 python -m pytest tests/test_gpu_layers.py tests/test_gpu_model.py tests/test_gpu_fuzz.py -m gpu -x -q -p no:cacheprovider 2>&1 | tail -3 | tee $OUT/parity.log
-timeout 100 python tools/small_batch_timing.py 2>&1 | grep -A1 "product\|4 waves x 32" | grep -v "^\[timing\]\|^--" | paste - - | tee $OUT/small_kernel.txt
-b() { local name=$1; shift; local envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
-  local v=$(env "${envs[@]}" timeout 150 python3 bench.py --no-cpu-baseline --no-callers --no-profile --steps 60 --warmup 5 "$@" 2>>"$OUT/err.txt" | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' | tr '\n' ' ')
-  echo "$name | $v" | tee -a "$OUT/small_batch_scan.txt"; }
-for n in 1 8 16 32 42; do
-b "batch $n loader waves" KMX_CONV_LW=1 -- --batch $n
-b "batch $n plain 4-wave shape" KMX_CONV_LW=0 -- --batch $n
-done
+timeout 1200 python -m pytest tests/test_gpu_batcher.py tests/test_gpu_leaf_pump.py tests/test_gpu_leaf_search.py tests/test_gpu_selfplay.py tests/test_gpu_analysis_engine.py "tests/test_gpu_bench_command.py::test_driver_command_exits_zero_with_roofline_and_cpu_baseline" -m gpu -q -p no:cacheprovider 2>&1 | tail -4 | tee $OUT/parity.log
+for f in search_driven_rate.txt selfplay_rate_b18.txt selfplay_rate_b18_own_evaluator.txt analysis_engine_b28.txt leaf_pump_b18.txt; do cp gpurun_out/$f $OUT/ 2>/dev/null; done
+cat $OUT/search_driven_rate.txt $OUT/selfplay_rate_b18_own_evaluator.txt $OUT/analysis_engine_b28.txt | cut -c1-250
