@@ -36,8 +36,9 @@ extern "C" {
  * 4: + kmx_handle_set_graphs / kmx_handle_graph_stats (hipGraph replay of the launch schedule); kmx_handle_set_split_min
  *    accepts a negative value (restore the creation value); the handle stream orders both halves of a split batch.
  *    + kmx_test_pointwise_pair (unit hook of the fused 1x1 -> 1x1 seam kernel); + kmx_batcher_* (persistent leaf
- *    batcher). Additive over 3. */
-#define KMX_ABI_VERSION 4
+ *    batcher). Additive over 3.
+ * 5: + kmx_batcher_submit_packed (a row that was featurised as bit planes is handed over as such). Additive over 4. */
+#define KMX_ABI_VERSION 5
 
 typedef enum kmx_status {
   KMX_OK = 0,
@@ -217,6 +218,13 @@ void kmx_batcher_free(kmx_batcher* batcher); /* fails rows not yet launched, com
 int kmx_batcher_submit(kmx_batcher* batcher, const float* row_spatial, const float* row_global, const float* row_meta,
                        int symmetry, float policy_optimism, float* out_policy, float* out_value, float* out_score,
                        float* out_ownership, uint64_t* ticket);
+/* The same with the spatial planes already bit-packed (layout of kmx_eval_packed: num_input_channels * ceil(nn_x*nn_y/8) bytes,
+ * plane by plane, most significant bit first) - for a caller that featurises straight into bits (integration/katamx_features.h
+ * does, in place of the fp32 row of NNInputs::fillRowV7, nninputs.cpp:2288-2731): 1012 bytes copied into the staging instead of
+ * 31768 read and packed. Padding bits of a plane's last byte must be zero. */
+int kmx_batcher_submit_packed(kmx_batcher* batcher, const uint8_t* row_packed, const float* row_global, const float* row_meta,
+                              int symmetry, float policy_optimism, float* out_policy, float* out_value, float* out_score,
+                              float* out_ownership, uint64_t* ticket);
 int kmx_batcher_wait(kmx_batcher* batcher, uint64_t ticket);
 int kmx_batcher_stats(kmx_batcher* batcher, uint64_t* rows, uint64_t* batches);
 int kmx_batcher_precision(const kmx_batcher* batcher); /* KMX_PREC_FP16 or KMX_PREC_BF16: what its engines compute in (isUsingFP16, nninterface.h:108) */

@@ -31,6 +31,11 @@ bool isUsingFP16(const Port* port);  // isUsingFP16 of nninterface.h:108 for thi
 uint64_t submit(
   Port* port, const float* rowSpatial, const float* rowGlobal, const float* rowMeta, int symmetry, float policyOptimism,
   float* outPolicy, float* outValue, float* outScore, float* outOwnership);
+// The same for a row that was featurised as bit planes (integration/katamx_features.h; layout of kmx_eval_packed): numPlanes *
+// ceil(nnX*nnY / 8) bytes, copied before the call returns.
+uint64_t submitPacked(
+  Port* port, const uint8_t* rowPacked, int numPlanes, const float* rowGlobal, const float* rowMeta, int symmetry, float policyOptimism,
+  float* outPolicy, float* outValue, float* outScore, float* outOwnership);
 void wait(Port* port, uint64_t ticket);  // blocks until the row's outputs are written; each ticket exactly once
 void stats(Port* port, uint64_t& rows, uint64_t& batches);  // meaning of nneval.cpp:712-713
 

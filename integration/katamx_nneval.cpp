@@ -10,7 +10,8 @@
 // of two, no second wake-up, and the split begin()/finish() (katamx_nneval.h) lets a caller keep several leaves in flight.
 //
 // What is identical to the reference, and pinned by running its own tests on this evaluator (tests/test_nneval_own.py):
-// the values. Same hash (NNInputs::getHash), same feature rows (NNInputs::fillRowV*), same symmetry rule, and the same
+// the values. Same hash (NNInputs::getHash), the same feature rows (inputs version 7 from this repository's featuriser,
+// integration/katamx_features.cpp, held bit for bit to NNInputs::fillRowV7; older versions from NNInputs::fillRowV3-6), same symmetry rule, and the same
 // post-processing arithmetic in the same precision (nneval.cpp:960-1254): policy logits -> masked softmax (passing hack,
 // dagger ban), value logits -> softmax in double, score / lead / variance-time / short-term-error transforms per model
 // version, ownership tanh; the no-neural-net debugging mode draws its random outputs in the order nneval.cpp:612-673 does.
@@ -18,12 +19,15 @@
 
 #include <array>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <numeric>
 #include <set>
 #include <shared_mutex>
 #include <unordered_map>
 
 #include "core/test.h"
+#include "katamx_features.h"
 #include "katamx_fibers.h"
 #include "katamx_leaf.h"
 #include "neuralnet/modelversion.h"
@@ -376,17 +380,39 @@ void fillRandomOutput(EvalState& st, NNResultBuf& buf, int boardXSize, int board
   st.nnlessRows.fetch_add(1, std::memory_order_relaxed);
 }
 
-void featurise(EvalState& st, const Board& board, const BoardHistory& history, Player pla, const SGFMetadata* sgfMeta, const MiscNNInputParams& params,
-               NNResultBuf& buf) {
-  const size_t spatialLen = (size_t)NNModelVersion::getNumSpatialFeatures(st.modelVersion) * st.nnXLen * st.nnYLen;
-  const size_t globalLen = (size_t)NNModelVersion::getNumGlobalFeatures(st.modelVersion);
-  if(buf.rowSpatialBuf.size() < spatialLen) buf.rowSpatialBuf.resize(spatialLen);
-  if(buf.rowGlobalBuf.size() < globalLen) buf.rowGlobalBuf.resize(globalLen);
+// Featurisation (row a2). Inputs version 7 - every net since model version 8 - is written straight into the boundary's
+// bit-plane row by this repository's featuriser (katamx_features.h: 1 012 bytes per 19x19 row instead of the 31 768-byte fp32 row
+// of NNInputs::fillRowV7, ladder planes of the parent positions looked up instead of read again); older input versions keep the
+// reference's functions and cross the boundary as fp32 rows. KATAMX_FEATURES = own (default) | reference (fillRowV7 + fp32 rows,
+// for A/B) | check (both, any difference is fatal: tests/test_nneval_own.py runs the reference's commands in this mode).
+enum FeatureMode { FEATURES_OWN = 0, FEATURES_REFERENCE = 1, FEATURES_CHECK = 2 };
+FeatureMode featureMode() {
+  static const FeatureMode mode = [] {
+    const char* env = getenv("KATAMX_FEATURES");
+    if(env == NULL || strcmp(env, "own") == 0) return FEATURES_OWN;
+    if(strcmp(env, "reference") == 0) return FEATURES_REFERENCE;
+    if(strcmp(env, "check") == 0) return FEATURES_CHECK;
+    throw StringError("KATAMX_FEATURES must be own, reference or check");
+  }();
+  return mode;
+}
+
+void metadataRow(EvalState& st, const Board& board, Player pla, const SGFMetadata* sgfMeta, NNResultBuf& buf) {
   if(buf.rowMetaBuf.size() < (size_t)st.numInputMetaChannels) buf.rowMetaBuf.resize(st.numInputMetaChannels);
+  buf.hasRowMeta = st.numInputMetaChannels > 0;
+  if(buf.hasRowMeta) {
+    if(sgfMeta == NULL)
+      Global::fatalError("SGFMetadata is required for " + st.modelName + " but was not provided");
+    if(!sgfMeta->initialized)
+      Global::fatalError("SGFMetadata is required for " + st.modelName + " but was not initialized. Did you specify humanSLProfile=... in katago's config or via overrides?");
+    SGFMetadata::fillMetadataRow(sgfMeta, buf.rowMetaBuf.data(), pla, board.x_size * board.y_size);
+  }
+}
+
+// The reference's featurisers: fp32 planes into buf.rowSpatialBuf, globals into buf.rowGlobalBuf.
+void referenceRow(EvalState& st, const Board& board, const BoardHistory& history, Player pla, const MiscNNInputParams& params, float* sp, float* gl) {
   // rows cross the boundary channels-last whatever the evaluator was constructed with (katamx.h conventions)
   const bool nhwc = true;
-  float* sp = buf.rowSpatialBuf.data();
-  float* gl = buf.rowGlobalBuf.data();
   static_assert(NNModelVersion::latestInputsVersionImplemented == 7, "a new inputs version needs a case here");
   switch(st.inputsVersion) {
     case 3: NNInputs::fillRowV3(board, history, pla, params, st.nnXLen, st.nnYLen, nhwc, sp, gl); break;
@@ -396,14 +422,34 @@ void featurise(EvalState& st, const Board& board, const BoardHistory& history, P
     case 7: NNInputs::fillRowV7(board, history, pla, params, st.nnXLen, st.nnYLen, nhwc, sp, gl); break;
     default: ASSERT_UNREACHABLE;
   }
-  buf.hasRowMeta = st.numInputMetaChannels > 0;
-  if(buf.hasRowMeta) {
-    if(sgfMeta == NULL)
-      Global::fatalError("SGFMetadata is required for " + st.modelName + " but was not provided");
-    if(!sgfMeta->initialized)
-      Global::fatalError("SGFMetadata is required for " + st.modelName + " but was not initialized. Did you specify humanSLProfile=... in katago's config or via overrides?");
-    SGFMetadata::fillMetadataRow(sgfMeta, buf.rowMetaBuf.data(), pla, board.x_size * board.y_size);
+}
+
+// Fills buf's global (and metadata) row and EITHER `packed` (returns true; KatamxFeatures::MAX_PACKED_ROW_BYTES) OR
+// buf.rowSpatialBuf (returns false).
+bool featurise(EvalState& st, const Board& board, const BoardHistory& history, Player pla, const SGFMetadata* sgfMeta, const MiscNNInputParams& params,
+               NNResultBuf& buf, uint8_t* packed) {
+  const int numPlanes = NNModelVersion::getNumSpatialFeatures(st.modelVersion);
+  const size_t spatialLen = (size_t)numPlanes * st.nnXLen * st.nnYLen;
+  const size_t globalLen = (size_t)NNModelVersion::getNumGlobalFeatures(st.modelVersion);
+  if(buf.rowGlobalBuf.size() < globalLen) buf.rowGlobalBuf.resize(globalLen);
+  metadataRow(st, board, pla, sgfMeta, buf);
+  const FeatureMode mode = featureMode();
+  const bool own = st.inputsVersion == 7 && mode != FEATURES_REFERENCE && packed != NULL;
+  if(own)
+    KatamxFeatures::fillPackedV7(board, history, pla, params, st.nnXLen, st.nnYLen, packed, buf.rowGlobalBuf.data());
+  if(!own || mode == FEATURES_CHECK) {
+    if(buf.rowSpatialBuf.size() < spatialLen) buf.rowSpatialBuf.resize(spatialLen);
+    std::vector<float> refGlobal(own ? globalLen : 0);
+    referenceRow(st, board, history, pla, params, buf.rowSpatialBuf.data(), own ? refGlobal.data() : buf.rowGlobalBuf.data());
+    if(own) {
+      std::vector<float> mine(spatialLen);
+      KatamxFeatures::unpackToNHWC(packed, st.nnXLen, st.nnYLen, numPlanes, mine.data());
+      if(memcmp(mine.data(), buf.rowSpatialBuf.data(), spatialLen * sizeof(float)) != 0 ||
+         memcmp(refGlobal.data(), buf.rowGlobalBuf.data(), globalLen * sizeof(float)) != 0)
+        Global::fatalError("KATAMX_FEATURES=check: KatamxFeatures::fillPackedV7 and NNInputs::fillRowV7 differ on\n" + Board::toStringSimple(board, '\n'));
+    }
   }
+  return own;
 }
 
 }  // namespace
@@ -478,7 +524,8 @@ void KatamxNNEval::begin(
     return;
   }
   try {
-    featurise(st, board, history, nextPlayer, sgfMeta, params, buf);
+    uint8_t packedRow[KatamxFeatures::MAX_PACKED_ROW_BYTES];
+    const bool rowIsPacked = featurise(st, board, history, nextPlayer, sgfMeta, params, buf, packedRow);
     if(st.ports.empty())
       throw StringError("NNEvaluator::evaluate called before spawnServerThreads");
     PortSlot& slot = *st.ports[st.nextPort.fetch_add(1, std::memory_order_relaxed) % st.ports.size()];
@@ -493,9 +540,15 @@ void KatamxNNEval::begin(
       }
     }
     leaf.port = slot.port;
-    leaf.ticket = KatamxLeaf::submit(
-      slot.port, buf.rowSpatialBuf.data(), buf.rowGlobalBuf.data(), buf.hasRowMeta ? buf.rowMetaBuf.data() : NULL, buf.symmetry,
-      (float)buf.policyOptimism, out->policyProbs, leaf.value, leaf.score, out->whiteOwnerMap);
+    const float* rowMeta = buf.hasRowMeta ? buf.rowMetaBuf.data() : NULL;
+    if(rowIsPacked)
+      leaf.ticket = KatamxLeaf::submitPacked(
+        slot.port, packedRow, KatamxFeatures::NUM_PLANES_V7, buf.rowGlobalBuf.data(), rowMeta, buf.symmetry, (float)buf.policyOptimism,
+        out->policyProbs, leaf.value, leaf.score, out->whiteOwnerMap);
+    else
+      leaf.ticket = KatamxLeaf::submit(
+        slot.port, buf.rowSpatialBuf.data(), buf.rowGlobalBuf.data(), rowMeta, buf.symmetry, (float)buf.policyOptimism, out->policyProbs,
+        leaf.value, leaf.score, out->whiteOwnerMap);
     leaf.inFlight = true;
   }
   catch(...) {
@@ -749,7 +802,14 @@ void NNEvaluator::fillRowBufs(
   const Board& board, const BoardHistory& history, Player nextPlayer, const SGFMetadata* sgfMeta, const MiscNNInputParams& nnInputParams,
   NNResultBuf& buf
 ) const {
-  featurise(*stateOf(this), board, history, nextPlayer, sgfMeta, nnInputParams, buf);
+  // the declared contract of this method is the fp32 row in buf.rowSpatialBuf: expand this repository's bit planes into it
+  EvalState& st = *stateOf(this);
+  uint8_t packedRow[KatamxFeatures::MAX_PACKED_ROW_BYTES];
+  if(featurise(st, board, history, nextPlayer, sgfMeta, nnInputParams, buf, packedRow)) {
+    const int numPlanes = NNModelVersion::getNumSpatialFeatures(st.modelVersion);
+    buf.rowSpatialBuf.resize((size_t)numPlanes * st.nnXLen * st.nnYLen);
+    KatamxFeatures::unpackToNHWC(packedRow, st.nnXLen, st.nnYLen, numPlanes, buf.rowSpatialBuf.data());
+  }
 }
 
 void NNEvaluator::evaluate(

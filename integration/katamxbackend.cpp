@@ -526,6 +526,28 @@ uint64_t KatamxLeaf::submit(
   return ticket;
 #endif
 }
+uint64_t KatamxLeaf::submitPacked(
+  Port* port, const uint8_t* rowPacked, int numPlanes, const float* rowGlobal, const float* rowMeta, int symmetry, float policyOptimism,
+  float* outPolicy, float* outValue, float* outScore, float* outOwnership
+) {
+  testAssert((rowMeta != NULL) == (port->numInputMetaChannels > 0));
+  testAssert(numPlanes == port->loadedModel->modelDesc.numInputChannels);
+#ifdef KMX_USE_ORACLE
+  // the oracle knows fp32 rows only: expand the bits (what the device's input stage does, misc_kernels.hip inputExpand)
+  const int cells = port->context->nnXLen * port->context->nnYLen, planeBytes = (cells + 7) / 8;
+  std::vector<float> row((size_t)cells * numPlanes);
+  for(int pos = 0; pos < cells; pos++)
+    for(int p = 0; p < numPlanes; p++)
+      row[(size_t)pos * numPlanes + p] = (float)((rowPacked[(size_t)p * planeBytes + (pos >> 3)] >> (7 - (pos & 7))) & 1);
+  return submit(port, row.data(), rowGlobal, rowMeta, symmetry, policyOptimism, outPolicy, outValue, outScore, outOwnership);
+#else
+  uint64_t ticket = 0;
+  check(
+    kmx_batcher_submit_packed(port->batcher, rowPacked, rowGlobal, rowMeta, symmetry, policyOptimism, outPolicy, outValue, outScore, outOwnership, &ticket),
+    "submitting a leaf");
+  return ticket;
+#endif
+}
 void KatamxLeaf::wait(Port* port, uint64_t ticket) {
 #ifdef KMX_USE_ORACLE
   (void)port;

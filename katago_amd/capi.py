@@ -110,6 +110,7 @@ SIGNATURES = {
     "kmx_batcher_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "kmx_batcher_free": (None, [ctypes.c_void_p]),
     "kmx_batcher_submit": (ctypes.c_int, [ctypes.c_void_p, _FP, _FP, _FP, ctypes.c_int, ctypes.c_float, _FP, _FP, _FP, _FP, ctypes.POINTER(ctypes.c_uint64)]),
+    "kmx_batcher_submit_packed": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _FP, _FP, ctypes.c_int, ctypes.c_float, _FP, _FP, _FP, _FP, ctypes.POINTER(ctypes.c_uint64)]),
     "kmx_batcher_wait": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64]),
     "kmx_batcher_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "kmx_batcher_precision": (ctypes.c_int, [ctypes.c_void_p]),

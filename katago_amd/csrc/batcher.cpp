@@ -87,9 +87,10 @@ class Batcher {
     if(completer_.joinable()) completer_.join();
   }
 
-  uint64_t submit(const float* rowSpatial, const float* rowGlobal, const float* rowMeta, int symmetry, float optimism, float* outPolicy,
-                  float* outValue, float* outScore, float* outOwnership) {
-    if(!rowSpatial || !rowGlobal) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_submit: null row");
+  // exactly one of rowSpatial (fp32 NHWC planes, bit-packed here) and rowPacked (already in the staging layout) is given
+  uint64_t submit(const float* rowSpatial, const unsigned char* rowPacked, const float* rowGlobal, const float* rowMeta, int symmetry, float optimism,
+                  float* outPolicy, float* outValue, float* outScore, float* outOwnership) {
+    if((!rowSpatial && !rowPacked) || !rowGlobal) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_submit: null row");
     if(!outPolicy || !outValue || !outScore) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_submit: null output");
     if(symmetry < 0 || symmetry > 7) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_submit: symmetry must be in 0..7");
     if((min_ > 0) != (rowMeta != nullptr))
@@ -137,7 +138,9 @@ class Batcher {
     cvWork_.notify_one();
     // stage the row outside the lock: the dispatcher launches only once every reserved row has been copied
     Slot& s = slots_[si];
-    const bool binary = packRowNHWC(rowSpatial, S_, cin_, s.eng->stagedPackedRow(r));
+    bool binary = true;
+    if(rowPacked) memcpy(s.eng->stagedPackedRow(r), rowPacked, (size_t)s.eng->packedRowBytes());
+    else binary = packRowNHWC(rowSpatial, S_, cin_, s.eng->stagedPackedRow(r));
     memcpy(s.eng->stagedGlobalRow(r), rowGlobal, (size_t)gin_ * sizeof(float));
     if(min_ > 0) memcpy(s.eng->stagedMetaRow(r), rowMeta, (size_t)min_ * sizeof(float));
     if(!binary) s.nonBinary.store(true, std::memory_order_relaxed);
@@ -405,7 +408,16 @@ int kmx_batcher_submit(kmx_batcher* b, const float* row_spatial, const float* ro
                        float policy_optimism, float* out_policy, float* out_value, float* out_score, float* out_ownership, uint64_t* ticket) {
   return apiGuarded([&] {
     if(!b || !ticket) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_submit: null argument");
-    *ticket = b->b->submit(row_spatial, row_global, row_meta, symmetry, policy_optimism, out_policy, out_value, out_score, out_ownership);
+    if(!row_spatial) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_submit: null row");
+    *ticket = b->b->submit(row_spatial, nullptr, row_global, row_meta, symmetry, policy_optimism, out_policy, out_value, out_score, out_ownership);
+  });
+}
+int kmx_batcher_submit_packed(kmx_batcher* b, const uint8_t* row_packed, const float* row_global, const float* row_meta, int symmetry,
+                              float policy_optimism, float* out_policy, float* out_value, float* out_score, float* out_ownership, uint64_t* ticket) {
+  return apiGuarded([&] {
+    if(!b || !ticket) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_submit_packed: null argument");
+    if(!row_packed) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_submit_packed: null row");
+    *ticket = b->b->submit(nullptr, row_packed, row_global, row_meta, symmetry, policy_optimism, out_policy, out_value, out_score, out_ownership);
   });
 }
 int kmx_batcher_wait(kmx_batcher* b, uint64_t ticket) {

@@ -285,6 +285,7 @@ class Batcher:
         self._p = ctypes.c_void_p()
         capi.check(self._lib.kmx_batcher_create(context._p, model._p, maxBatchSize, maxInFlight, gpuIdx, ctypes.byref(self._p)), self._lib)
         self.S = context.nnXLen * context.nnYLen
+        self.numInputChannels = model.info.num_input_channels
         self._out = {}
         self._lock = threading.Lock()
 
@@ -299,17 +300,23 @@ class Batcher:
         except Exception:
             pass
 
-    def submit(self, rowSpatial, rowGlobal, symmetry=0, policyOptimism=0.0, wantOwnership=True, rowMeta=None):
-        """Returns a ticket. The row's output arrays are allocated here (the library writes into them) and handed out by wait()."""
-        sp = np.ascontiguousarray(rowSpatial, dtype=np.float32)
+    def submit(self, rowSpatial, rowGlobal, symmetry=0, policyOptimism=0.0, wantOwnership=True, rowMeta=None, packed=False):
+        """Returns a ticket. The row's output arrays are allocated here (the library writes into them) and handed out by wait().
+        packed=True: rowSpatial is one row of packRows() (uint8 bit planes) and goes through kmx_batcher_submit_packed."""
+        if packed:
+            sp = np.ascontiguousarray(rowSpatial, dtype=np.uint8).reshape(-1)
+            assert sp.size == self.numInputChannels * ((self.S + 7) // 8)
+        else:
+            sp = np.ascontiguousarray(rowSpatial, dtype=np.float32)
         gl = np.ascontiguousarray(rowGlobal, dtype=np.float32)
         mt = None if rowMeta is None else np.ascontiguousarray(rowMeta, dtype=np.float32)
         out = {"policy": np.empty(self.S + 1, np.float32), "value": np.empty(3, np.float32), "score": np.empty(6, np.float32),
                "ownership": np.empty(self.S, np.float32) if wantOwnership else None}
         t = ctypes.c_uint64()
-        capi.check(self._lib.kmx_batcher_submit(self._p, _fp(sp), _fp(gl), None if mt is None else _fp(mt), int(symmetry), float(policyOptimism),
-                                                _fp(out["policy"]), _fp(out["value"]), _fp(out["score"]),
-                                                None if out["ownership"] is None else _fp(out["ownership"]), ctypes.byref(t)), self._lib)
+        entry = self._lib.kmx_batcher_submit_packed if packed else self._lib.kmx_batcher_submit
+        capi.check(entry(self._p, sp.ctypes.data_as(ctypes.c_void_p) if packed else _fp(sp), _fp(gl), None if mt is None else _fp(mt), int(symmetry),
+                         float(policyOptimism), _fp(out["policy"]), _fp(out["value"]), _fp(out["score"]),
+                         None if out["ownership"] is None else _fp(out["ownership"]), ctypes.byref(t)), self._lib)
         with self._lock:
             self._out[t.value] = out
         return t.value

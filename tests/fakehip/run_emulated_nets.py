@@ -110,9 +110,11 @@ def batcher_case(ctx):
     b = nn.Batcher(ctx, model, 4, maxInFlight=2)
     got = [None] * n
 
+    packed = nn.packRows(sp, 19, 19)  # odd rows go in as bit planes (kmx_batcher_submit_packed), even ones as fp32 rows
+
     def worker(i0):
         for i in range(i0, n, 3):
-            t = b.submit(sp[i], gl[i], sym[i], opt[i], True)
+            t = b.submit(packed[i], gl[i], sym[i], opt[i], True, packed=True) if i % 2 else b.submit(sp[i], gl[i], sym[i], opt[i], True)
             got[i] = b.wait(t)
 
     th = [threading.Thread(target=worker, args=(k,)) for k in range(3)]

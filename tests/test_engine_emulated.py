@@ -263,7 +263,8 @@ def test_entry_point_variants_emulated(emu_lib):
 
 
 def test_leaf_batcher_emulated(emu_lib):
-    """kmx_batcher_*: three submitter threads, batches of at most 4 rows, two in flight - every row bit-identical to kmx_eval;
+    """kmx_batcher_*: three submitter threads, batches of at most 4 rows, two in flight, rows handed over as fp32 planes and as
+    bit planes (kmx_batcher_submit_packed) side by side - every row bit-identical to kmx_eval;
     rows/batches counters; a non-binary feature plane fails that batch only."""
     res = run_cases(emu_lib, ["bf16:batcher"])["bf16:batcher"]
     assert res["equal"] and res["after_error_equal"], res

@@ -35,13 +35,17 @@ def test_batcher_rows_are_bit_identical_to_kmx_eval(tmp_path, dtype):
     b = nn.Batcher(ctx, model, 48, maxInFlight=3)
     got = [None] * n
     errors = []
+    packed = nn.packRows(sp, 19, 19)  # every fifth row is handed over as bit planes (kmx_batcher_submit_packed)
 
     def worker(k, nthreads):
         try:
             # a few rows in flight per thread, as a search thread with several pending leaves would have
             pending = []
             for i in range(k, n, nthreads):
-                pending.append((i, b.submit(sp[i], gl[i], sym[i], opt[i], i % 3 != 0)))
+                if i % 5 == 1:
+                    pending.append((i, b.submit(packed[i], gl[i], sym[i], opt[i], i % 3 != 0, packed=True)))
+                else:
+                    pending.append((i, b.submit(sp[i], gl[i], sym[i], opt[i], i % 3 != 0)))
                 if len(pending) >= 4:
                     j, t = pending.pop(0)
                     got[j] = b.wait(t)

@@ -7,7 +7,11 @@ oracle) and differ in exactly one translation unit: neuralnet/nneval.cpp against
 reference command prints through one must therefore be printed, character for character, through the other: policies and
 values after post-processing, ownership maps, the batching test's cache behaviour, whole searches (visit counts, principal
 variations), and the random outputs of the no-neural-net mode. Only backend log lines (start with ':') may differ - the
-reference's server thread logs "GPU 0 finishing" when it exits, and there is no such thread here."""
+reference's server thread logs "GPU 0 finishing" when it exits, and there is no such thread here.
+
+Since round 3 this evaluator also featurises (row a2): inputs version 7 comes from integration/katamx_features.cpp as bit planes,
+not from NNInputs::fillRowV7 as an fp32 row. The small commands run it as shipped; the large ones run it in its checking mode,
+where every row is additionally compared with the reference's featuriser (tests/test_features_own.py is the direct test)."""
 import os
 import re
 import subprocess
@@ -19,18 +23,22 @@ from conftest import REPO, ref_binary
 G170 = os.path.join(REPO, "oracle", "_ref", "models", "g170-b6c96-s175395328-d26788732.bin.gz")
 
 
-def body(binary, *args, timeout=900, cwd=None):
-    r = subprocess.run([binary] + list(args), capture_output=True, text=True, timeout=timeout, cwd=cwd or os.path.dirname(binary))
+def body(binary, *args, timeout=900, cwd=None, env=None):
+    r = subprocess.run([binary] + list(args), capture_output=True, text=True, timeout=timeout, cwd=cwd or os.path.dirname(binary),
+                       env=dict(os.environ, **(env or {})))
     text = re.sub(r": GPU \d+ finishing, processed \d+ rows \d+ batches", "", r.stdout + r.stderr)
     return r.returncode, [l for l in text.splitlines() if l.strip() and not l.startswith(":")]
 
 
-def same_output(*args, min_lines=1, **kw):
+def same_output(*args, min_lines=1, features="own", **kw):
+    """features: KATAMX_FEATURES of this repo's evaluator - "own" = the product default (inputs featurised as bit planes by
+    integration/katamx_features.cpp), "check" = the same rows submitted, and every one of them also compared, plane by plane and
+    global by global, with NNInputs::fillRowV7 (a difference aborts the command)."""
     from concurrent.futures import ThreadPoolExecutor
 
     with ThreadPoolExecutor(2) as ex:  # the two binaries side by side
         f0 = ex.submit(body, ref_binary("katago_oracle"), *args, **kw)
-        f1 = ex.submit(body, ref_binary("katago_oraclex"), *args, **kw)
+        f1 = ex.submit(body, ref_binary("katago_oraclex"), *args, env={"KATAMX_FEATURES": features}, **kw)
         (rc0, ref), (rc1, own) = f0.result(), f1.result()
     assert rc0 == 0 and rc1 == 0, (rc0, rc1, ref[-5:], own[-5:])
     assert len(ref) >= min_lines, ref[-5:]
@@ -58,13 +66,13 @@ def test_tiny_nets_end_to_end(tmp_path):
 
 def test_many_positions_identical():
     """runnnonmanyposestest: 92 000 lines of post-processed outputs over the positions of tests/testnnevalcanary.cpp, symmetry 5."""
-    same_output("runnnonmanyposestest", G170, "false", "false", "5", "false", min_lines=90000)
+    same_output("runnnonmanyposestest", G170, "false", "false", "5", "false", min_lines=90000, features="check")
 
 
 @pytest.mark.slow
 def test_batching_cache_and_threads_identical():
     """runnnbatchingtest: many threads, cache on, results independent of batch composition (cpp/tests/results/runNNBatchingTest*.txt)."""
-    out = same_output("runnnbatchingtest", G170, "true", "true", "false")
+    out = same_output("runnnbatchingtest", G170, "true", "true", "false", features="check")
     ref = os.path.join(os.environ.get("KATAGO_REFERENCE", "/root/reference"), "cpp", "tests", "results", "runNNBatchingTestNHWC.txt")
     if os.path.exists(ref):
         assert "\n".join(out).strip() == open(ref).read().strip()
@@ -74,4 +82,4 @@ def test_batching_cache_and_threads_identical():
 def test_whole_searches_identical():
     """runsearchtests on the real g170 net: visit counts, values and principal variations of every search of
     cpp/tests/testsearch.cpp (fixed seeds, one search thread) - the same through both evaluators (2 x 80 s on the CPU)."""
-    same_output("runsearchtests", G170, "false", "false", "0", "false", min_lines=1400, timeout=1500)
+    same_output("runsearchtests", G170, "false", "false", "0", "false", min_lines=1400, timeout=1500, features="check")
