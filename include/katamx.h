@@ -198,14 +198,15 @@ int kmx_handle_sync(kmx_handle* handle);
  * synchronously (nneval.cpp:562-752, core/threadsafequeue.h:173-189) — for callers that submit rows themselves:
  *   kmx_batcher_submit  thread-safe, called by the thread that owns the leaf (a search thread, or a server thread of the
  *                       reference's NNEvaluator with the rows it popped): reserves a row of the batch that is filling and
- *                       bit-packs the fp32 NHWC feature planes (all V7 planes are 0/1; any other value fails the batch with
- *                       KMX_ERR_INVALID_ARG) straight into that batch's pinned staging, outside the lock. The out_* buffers
+ *                       bit-packs the fp32 NHWC feature planes (all V7 planes are 0/1; any other value fails THIS call with
+ *                       KMX_ERR_INVALID_ARG, no row is reserved) into that batch's pinned staging, outside the lock. The out_* buffers
  *                       (layout as kmx_eval: policy nn_x*nn_y+1, value 3, score 6, ownership nn_x*nn_y or NULL = not
  *                       wanted) receive the row's results and must stay valid until kmx_batcher_wait returns. Blocks only
  *                       while every staging set is filling or on the DEVICE - never on results that have not been
  *                       collected, so a thread may hold any number of tickets. Returns a ticket.
  *   kmx_batcher_wait    blocks until the ticket's row has been written to its out_* buffers (or its batch failed: the
- *                       status and kmx_last_error say why). Each ticket is waited for exactly once.
+ *                       status and kmx_last_error say why). Each ticket is waited for exactly once; a ticket that is never
+ *                       waited for keeps its (small) completion record until kmx_batcher_free.
  * Batching is greedy like the reference's when the device is idle (a waiting row never waits for more rows); while a
  * batch is on the device the next one accumulates, and FULL batches are launched behind it, up to max_in_flight
  * (default 2 when <= 0) between H2D and D2H at once on their own engines and streams, so that copies and kernels of

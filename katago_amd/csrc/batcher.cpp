@@ -3,9 +3,10 @@
 // Replaces, for callers that adopt it, the server half of the reference's NNEvaluator (cpp/neuralnet/nneval.cpp:562-752:
 // serve() popping up to maxBatch NNResultBuf* from a ThreadsafeQueue, cpp/core/threadsafequeue.h:173-189, and calling
 // NeuralNet::getOutput synchronously) and the row copies of the backend's getOutput:
-//   * kmx_batcher_submit is called by the SEARCH thread that owns the leaf. It reserves a row in the batch that is filling and
-//     bit-packs the row's feature planes straight into that batch's PINNED staging (1012 instead of 31768 bytes per 19x19 row;
-//     the reference's binaryInputNCHWPacked layout) — in parallel with the other submitters, outside the lock.
+//   * kmx_batcher_submit is called by the SEARCH thread that owns the leaf. It bit-packs the row's feature planes (1012 instead
+//     of 31768 bytes per 19x19 row; the reference's binaryInputNCHWPacked layout; kmx_batcher_submit_packed takes
+//     them already packed from a caller that featurises into bits), reserves a row in the batch that is filling and copies
+//     the bits into that batch's PINNED staging - in parallel with the other submitters, outside the lock.
 //   * a dispatcher thread seals the filling batch when the device is idle (greedy like waitPopUpToN: it never waits for more
 //     rows once one is waiting and the device has nothing to do) or when it is full (then up to `max_in_flight` batches are
 //     between H2D and D2H, each on its own engine and stream, so that H2D of batch k+1, the kernels of batch k and D2H of
@@ -96,6 +97,21 @@ class Batcher {
     if((min_ > 0) != (rowMeta != nullptr))
       throw Error(KMX_ERR_INVALID_ARG, min_ > 0 ? "this net has an sgf-metadata encoder: rows need the metadata input"
                                                 : "this net has no sgf-metadata encoder: the metadata input must be NULL");
+    // fp32 planes are bit-packed BEFORE a row is reserved: a plane with a value other than 0 / 1 fails this call only, not the
+    // batch its row would have shared with other callers' rows
+    const size_t packedBytes = (size_t)slots_[0].eng->packedRowBytes();
+    unsigned char localPacked[32 * 128];
+    std::vector<unsigned char> bigPacked;
+    unsigned char* packedHere = localPacked;
+    if(!rowPacked) {
+      if(packedBytes > sizeof(localPacked)) {
+        bigPacked.resize(packedBytes);
+        packedHere = bigPacked.data();
+      }
+      if(!packRowNHWC(rowSpatial, S_, cin_, packedHere))
+        throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_submit: spatial features must be 0 or 1 (bit-packed staging); use kmx_eval for other inputs");
+      rowPacked = packedHere;
+    }
     int si, r;
     uint64_t ticket;
     {
@@ -138,12 +154,9 @@ class Batcher {
     cvWork_.notify_one();
     // stage the row outside the lock: the dispatcher launches only once every reserved row has been copied
     Slot& s = slots_[si];
-    bool binary = true;
-    if(rowPacked) memcpy(s.eng->stagedPackedRow(r), rowPacked, (size_t)s.eng->packedRowBytes());
-    else binary = packRowNHWC(rowSpatial, S_, cin_, s.eng->stagedPackedRow(r));
+    memcpy(s.eng->stagedPackedRow(r), rowPacked, packedBytes);
     memcpy(s.eng->stagedGlobalRow(r), rowGlobal, (size_t)gin_ * sizeof(float));
     if(min_ > 0) memcpy(s.eng->stagedMetaRow(r), rowMeta, (size_t)min_ * sizeof(float));
-    if(!binary) s.nonBinary.store(true, std::memory_order_relaxed);
     s.copied.fetch_add(1, std::memory_order_release);
     return ticket;
   }
@@ -181,7 +194,6 @@ class Batcher {
     State state = FREE;
     int count = 0;                 // rows reserved
     std::atomic<int> copied{0};    // rows staged
-    std::atomic<bool> nonBinary{false};
     bool anyOwner = false;
     std::vector<int> sym;
     std::vector<float> opt;
@@ -273,7 +285,6 @@ class Batcher {
       int err = KMX_OK;
       std::string msg;
       try {
-        if(s.nonBinary.exchange(false)) throw Error(KMX_ERR_INVALID_ARG, "kmx_batcher_submit: spatial features must be 0 or 1 (bit-packed staging); use kmx_eval for other inputs");
         s.eng->launchStagedPacked(n, s.sym.data(), s.opt.data(), anyOwner);
       }
       catch(const Error& e) { err = e.code; msg = e.what(); }

@@ -123,8 +123,8 @@ class Engine {
   // Other engines' passes run on the same device at the same time (the batcher's batches in flight): kernels that exist in a
   // "chip to itself" and a "side by side" form (the seam, kernels.h PwPairArgs::alone) take the latter.
   void setSharesDevice(bool shares) { sharesDevice_ = shares; }
-  // Record `ev` on this engine's stream after the first `afterOps` launches of the next pass (0: at entry, before the
-  // row parameters are staged); null clears it. A second engine's stream waits for it (kmx_api.cpp, split handle).
+  // Record `ev` on this engine's stream after the first `afterOps` launches of the next pass (0: at the top of runSchedule, i.e.
+  // after the row parameters were staged and before the first launch); null clears it. A second engine's stream waits for it (kmx_api.cpp, split handle).
   void setForkPoint(int afterOps, hipEvent_t ev) { forkOps_ = afterOps < 0 ? 0 : afterOps; forkEv_ = ev; }
   // hipGraph replay of the launch schedule: a pass with the same row count, work-group shapes and buffer
   // pointers as an earlier one is captured once (on its second occurrence: the first runs directly and sets the kernels'
@@ -148,6 +148,12 @@ class Engine {
     int cls;               // index into opClasses_
     double flopsPerRow;    // algorithmic flops per evaluated position
     double bytesPerRow;    // algorithmic HBM bytes per evaluated position
+    // an op that takes another form below a batch size (the seam: two plain convolution launches below fuseMinRows_) is accounted
+    // as that form there: its own class, its own byte model, its number of launches
+    int smallBelow = 0;    // rows; 0 = one form only
+    int clsSmall = -1;
+    double bytesPerRowSmall = 0.0;
+    int launchesSmall = 1;
   };
   void construct(const ModelDesc& model);  // the body of the constructor
   bool scale8_ = false;  // the net runs at 1/8 of its values (fp16 range transform)
@@ -253,7 +259,7 @@ class Engine {
   bool profiling_ = false;
   std::vector<std::string> opClasses_;
   std::vector<ProfileEntry> profile_;
-  struct Pending { hipEvent_t a, b; int cls; double flops, bytes; };
+  struct Pending { hipEvent_t a, b; int cls; int launches; double flops, bytes; };
   std::vector<Pending> pending_;
   std::vector<hipEvent_t> eventPool_;
 };

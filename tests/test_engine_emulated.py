@@ -265,7 +265,7 @@ def test_entry_point_variants_emulated(emu_lib):
 def test_leaf_batcher_emulated(emu_lib):
     """kmx_batcher_*: three submitter threads, batches of at most 4 rows, two in flight, rows handed over as fp32 planes and as
     bit planes (kmx_batcher_submit_packed) side by side - every row bit-identical to kmx_eval;
-    rows/batches counters; a non-binary feature plane fails that batch only."""
+    rows/batches counters; a non-binary feature plane is refused by its own submit call."""
     res = run_cases(emu_lib, ["bf16:batcher"])["bf16:batcher"]
     assert res["equal"] and res["after_error_equal"], res
     assert res["many_tickets_equal"], res  # threads that hold more tickets than the staging sets have rows must not dead-lock
