@@ -173,10 +173,44 @@ namespace emu {
 // epilogue in tests/test_engine_emulated.py).
 inline void waveSync() { cur->waves[tIdx.x >> 6].bar->arrive_and_wait(); }
 // global_load_lds: every lane copies `size` bytes from its own global address to (wave-uniform LDS base) + lane * size.
-// Immediate here; on the hardware it completes asynchronously (s_waitcnt vmcnt), which emulation therefore cannot check.
+// On the hardware the copy completes asynchronously: a wave's vector-memory requests retire IN ORDER, and s_waitcnt vmcnt(N) returns
+// when at most N of them are outstanding. The emulation runs the two legal extremes:
+//   * immediate (default): the copy happens at issue - the earliest the hardware could complete it (a slot that is overwritten while
+//     another wave still reads it shows up, thread interleaving permitting; tools/emulated_tsan.sh);
+//   * KMX_EMU_LATE_DMA=1: the copy happens only when an s_waitcnt of the issuing wave forces it - the LATEST the hardware may complete
+//     it. A count that is too generous (vmcnt(N) with N one too large, a ring one slot too shallow for the requests in flight, a
+//     barrier that publishes a slab its requester has not waited for) leaves the destination stale and the results wrong.
+// Requests that are not LDS-DMA (plain global loads and stores count in vmcnt on gfx9 too) are entered with vmNote() where a
+// kernel's counts rely on them.
+struct VmOp { const void* src; void* dst; int size; };
+struct VmQueue {
+  std::vector<VmOp> ops;
+  size_t head = 0;  // ops[head ..) are outstanding, oldest first
+};
+extern thread_local VmQueue vmQueue;  // per lane (a lane is an OS thread here; all lanes of a wave issue and wait alike)
+bool lateDma();
+inline void vmRetireTo(size_t outstanding) {
+  VmQueue& q = vmQueue;
+  while(q.ops.size() - q.head > outstanding) {
+    const VmOp& op = q.ops[q.head++];
+    if(op.dst != nullptr) memcpy(op.dst, op.src, (size_t)op.size);
+  }
+  if(q.head == q.ops.size()) {
+    q.ops.clear();
+    q.head = 0;
+  }
+}
+inline void waitVm(int n) {
+  if(lateDma()) vmRetireTo((size_t)n);
+}
+inline void vmNote() {  // a vector-memory request that is not an LDS-DMA copy: it only takes its place in the in-order queue
+  if(lateDma()) vmQueue.ops.push_back(VmOp{nullptr, nullptr, 0});
+}
 template <class G, class L>
 inline void globalLoadLds(G gsrc, L ldsBase, int size, int, int) {
-  memcpy((char*)(uintptr_t)ldsBase + (tIdx.x & 63) * size, (const void*)(uintptr_t)gsrc, (size_t)size);
+  void* const dst = (char*)(uintptr_t)ldsBase + (tIdx.x & 63) * size;
+  if(lateDma()) vmQueue.ops.push_back(VmOp{(const void*)(uintptr_t)gsrc, dst, size});
+  else memcpy(dst, (const void*)(uintptr_t)gsrc, (size_t)size);
 }
 }  // namespace emu
 // v_permlane32_swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second; returns {new first, new second}

@@ -45,11 +45,11 @@ def emu_lib(tmp_path_factory):
 # ---- the "real convolution" build: conv_mfma.hip / conv_kernel.h themselves, emulated -----------------------------------
 # The kernel source is used as it is except for the statements that only exist on the GPU, which are rewritten at test time
 # (the product file is not touched): s_waitcnt / register-class asm statements are dropped, the dynamic LDS declaration
-# becomes the emulator's buffer, global_load_lds becomes an immediate per-lane copy. v_mfma_f32_32x32x16 and
-# v_permlane32_swap run as wave-collectives in the hardware's register layout. What this cannot
-# show is anything about asynchronous completion (the s_waitcnt / ring-depth logic): the copies are immediate here.
+# becomes the emulator's buffer, global_load_lds becomes a per-lane copy that happens at once or (KMX_EMU_LATE_DMA=1) as late as
+# the wave's s_waitcnt vmcnt(N) statements - which become emu::waitVm(N) - allow. v_mfma_f32_32x32x16 and
+# v_permlane32_swap run as wave-collectives in the hardware's register layout.
 CONV_REWRITES = [
-    (r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\(N\) : "memory"\);', ";", 1),
+    (r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\(N\) : "memory"\);', "emu::waitVm(N);", 1),
     (r'asm volatile\("" : "\+s"\(sTap\)\);', ";", 2),
     (r'asm volatile\("" ::"v"\((rawQ|actQ)\[j\]\)\);', ";", 2),
     (r'asm volatile\("" : "\+v"\(pOff\)\);', ";", 1),
@@ -60,8 +60,17 @@ CONV_REWRITES = [
 
 
 # pointwise_kernel.h (the fused seam of two 1x1 convolutions) gets the same treatment
+# Plain global loads and stores take their place in the wave's in-order request queue (emu::vmNote): the seam kernels' counts include
+# them ("in flight at most this part's residual loads and stores").
 PW_REWRITES = [
-    (r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\(N\) : "memory"\);', ";", 1),
+    (r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\(N\) : "memory"\);', "emu::waitVm(N);", 1),
+    (r'for\(int j = 0; j < 2; j\+\+\) rq\[pt\]\[ct\]\[j\] = \*\(const u32x4\*\)\(live \? rrow \+ ct \* 32 \+ 16 \* j : rrow\);',
+     "for(int j = 0; j < 2; j++) { rq[pt][ct][j] = *(const u32x4*)(live ? rrow + ct * 32 + 16 * j : rrow); emu::vmNote(); }", 1),
+    (r'\*\(u32x4\*\)\(live \? rawRow \+ c : trash\) = rawQ\[j\];', "*(u32x4*)(live ? rawRow + c : trash) = rawQ[j]; emu::vmNote();", 1),
+    (r'if\(hasActOut\) \*\(u32x4\*\)\(live \? actRow \+ c : trash\) = oq\[j\];',
+     "if(hasActOut) { *(u32x4*)(live ? actRow + c : trash) = oq[j]; emu::vmNote(); }", 1),
+    (r'\*\(u32x4\*\)\(rawRow \+ c\) = rq\[j\];', "*(u32x4*)(rawRow + c) = rq[j]; emu::vmNote();", 1),
+    (r'\*\(u32x4\*\)\(actRow \+ c\) = oq\[j\];', "*(u32x4*)(actRow + c) = oq[j]; emu::vmNote();", 1),
     (r'asm volatile\("s_waitcnt lgkmcnt\(0\)" ::: "memory"\);', ";", 1),
     (r'extern __shared__ __attribute__\(\(aligned\(256\)\)\) char smemPw\[\];', "char* const smemPw = (char*)emu::dynLds();", 1),
     (r'__builtin_amdgcn_global_load_lds\(', "emu::globalLoadLds(", 1),
@@ -71,7 +80,13 @@ PW_REWRITES = [
 
 # pointwise2_kernel.h (the persistent, software-pipelined seam kernel)
 PW2_REWRITES = [
-    (r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\(N\) : "memory"\);', ";", 1),
+    (r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\(N\) : "memory"\);', "emu::waitVm(N);", 1),
+    (r'for\(int j = 0; j < 2; j\+\+\) dst\[j\] = \*\(const GLOBAL u32x4\*\)\(rrow \+ 64 \* q \+ 16 \* j\);',
+     "for(int j = 0; j < 2; j++) { dst[j] = *(const GLOBAL u32x4*)(rrow + 64 * q + 16 * j); emu::vmNote(); }", 1),
+    (r'for\(int j = 0; j < 2; j\+\+\) \*\(GLOBAL u32x4\*\)\(rawRow \+ 64 \* q \+ 16 \* j\) = rawQ\[j\];',
+     "for(int j = 0; j < 2; j++) { *(GLOBAL u32x4*)(rawRow + 64 * q + 16 * j) = rawQ[j]; emu::vmNote(); }", 1),
+    (r'\*\(GLOBAL u32x4\*\)\(rawRow2 \+ ct \* 32 \+ 16 \* j\) = rawQ\[j\];', "*(GLOBAL u32x4*)(rawRow2 + ct * 32 + 16 * j) = rawQ[j]; emu::vmNote();", 1),
+    (r'\*\(GLOBAL u32x4\*\)\(actRow2 \+ ct \* 32 \+ 16 \* j\) = oq\[j\];', "*(GLOBAL u32x4*)(actRow2 + ct * 32 + 16 * j) = oq[j]; emu::vmNote();", 1),
     (r'asm volatile\("s_waitcnt lgkmcnt\(0\)" ::: "memory"\);', ";", 1),
     (r'asm volatile\("" : "\+s"\((w1|w2)\)\);', ";", 2),
     (r'extern __shared__ __attribute__\(\(aligned\(256\)\)\) char smemPw2\[\];', "char* const smemPw2 = (char*)emu::dynLds();", 1),
@@ -80,14 +95,14 @@ PW2_REWRITES = [
 ]
 
 
-@pytest.fixture(scope="module")
-def emu_full_lib(tmp_path_factory):
+def build_emu_full(d, conv_mutations=(), pw2_mutations=()):
+    """conv_mutations: further (pattern, replacement, count) rewrites of conv_kernel.h - deliberate defects for the tests of the
+    emulator's own teeth."""
     import re
     import shutil
 
-    d = str(tmp_path_factory.mktemp("emufull"))
     src = open(os.path.join(CSRC, "conv_kernel.h")).read()
-    for pat, rep, count in CONV_REWRITES:
+    for pat, rep, count in list(CONV_REWRITES) + list(conv_mutations):
         src, k = re.subn(pat, rep, src)
         assert k == count, "conv_kernel.h changed: %r matched %d times, expected %d" % (pat, k, count)
     open(os.path.join(d, "conv_kernel.h"), "w").write(src)
@@ -98,7 +113,7 @@ def emu_full_lib(tmp_path_factory):
         assert k == count, "pointwise_kernel.h changed: %r matched %d times, expected %d" % (pat, k, count)
     open(os.path.join(d, "pointwise_kernel.h"), "w").write(src)
     src = open(os.path.join(CSRC, "pointwise2_kernel.h")).read()
-    for pat, rep, count in PW2_REWRITES:
+    for pat, rep, count in list(PW2_REWRITES) + list(pw2_mutations):
         src, k = re.subn(pat, rep, src)
         assert k == count, "pointwise2_kernel.h changed: %r matched %d times, expected %d" % (pat, k, count)
     open(os.path.join(d, "pointwise2_kernel.h"), "w").write(src)
@@ -117,6 +132,39 @@ def emu_full_lib(tmp_path_factory):
     r = subprocess.run(["/opt/rocm/lib/llvm/bin/clang++", "-shared", "-fPIC", "-pthread", "-o", so] + objs + ["-lz"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     return so
+
+
+@pytest.fixture(scope="module")
+def emu_full_lib(tmp_path_factory):
+    return build_emu_full(str(tmp_path_factory.mktemp("emufull")))
+
+
+CONV_ONLY = r"""
+import sys, json
+sys.path.insert(0, %r)
+import numpy as np, torch
+from katago_amd import capi
+capi._lib = capi.load_library(path=sys.argv[1])
+from katago_amd import nninterface as nn
+rng = np.random.default_rng(2)
+out = {}
+for (ks, cin, cout, X, Y, n) in json.loads(sys.argv[2]):
+    w = (rng.normal(size=(cout, cin, ks, ks)) * 0.1).astype(np.float32)
+    x = rng.normal(size=(n, Y * X, cin)).astype(np.float32)
+    got = np.asarray(nn.testEvaluateConv(w, n, X, Y, True, x))
+    xt = torch.from_numpy(x.reshape(n, Y, X, cin).transpose(0, 3, 1, 2)).to(torch.bfloat16).float()
+    wt = torch.from_numpy(w).to(torch.bfloat16).float()
+    want = torch.nn.functional.conv2d(xt, wt, padding=ks // 2).numpy().transpose(0, 2, 3, 1).reshape(n, Y * X, cout)
+    out["conv%%d_%%d_%%d" %% (ks, cin, cout)] = [float(np.abs(got.reshape(want.shape) - want).max()), float(np.abs(want).max())]
+print("RESULT " + json.dumps(out))
+""" % (REPO,)
+# 3x3 on the 4-wave x 32-channel shape (every wave issues weights and image pieces, padded to a constant count), 1x1 (whole images
+# ride the ring), 5x5, and 3x3 96 -> 192 which KMX_MIN_WGS8=1 sends to the 8-wave shape whose waves 0-3 issue all requests
+LATE_DMA_SHAPES = [(3, 64, 32, 9, 9, 1), (1, 96, 64, 13, 13, 1), (5, 32, 64, 9, 9, 1), (3, 96, 192, 19, 19, 1)]
+
+
+def conv_only(lib, env):
+    return [sys.executable, "-c", CONV_ONLY, lib, json.dumps(LATE_DMA_SHAPES)], dict(os.environ, KMX_MIN_WGS8="1", **env)
 
 
 def test_real_convolution_kernel_emulated(emu_full_lib):
@@ -323,8 +371,11 @@ for dtype in ("bf16", "fp16"):
                   "off_board_zero": bool((fused[2][m != 1.0] == 0).all())}
 print("RESULT " + json.dumps(out))
 """ % (REPO, os.path.join(REPO, "tests"))
-    variants = ("8", "4")  # the product shape (8 waves x 128 cells) and the two-per-CU experiment (4 waves x 64 cells)
-    runs = run_parallel([([sys.executable, "-c", code, emu_full_lib], dict(os.environ, KMX_PW_WAVES=w)) for w in variants])
+    # the product shape (8 waves x 128 cells) and the two-per-CU experiment (4 waves x 64 cells); each with immediate LDS-DMA
+    # copies and with the latest completion its s_waitcnt counts allow (KMX_EMU_LATE_DMA=1, tests/fakehip/emul/hip/hip_runtime.h)
+    variants = (("8", "0"), ("4", "0"), ("8", "1"), ("4", "1"))
+    runs = run_parallel([([sys.executable, "-c", code, emu_full_lib], dict(os.environ, KMX_PW_WAVES=w, KMX_PW_V2="0", KMX_EMU_LATE_DMA=late))
+                         for w, late in variants])
     for waves, (rc, so, se) in zip(variants, runs):
         assert rc == 0 and "RESULT " in so, (so + se)[-3000:]
         res = json.loads(so.split("RESULT ")[1])
@@ -336,13 +387,7 @@ print("RESULT " + json.dumps(out))
                 assert e <= 2 * ulp * max(s, 1.0) * k, (waves, dtype, r)
 
 
-def test_persistent_seam_kernel_emulated(emu_full_lib):
-    """pointwise2_kernel.h on the CPU: a work-group that walks three tiles (two full, one tail of 82 cells; KMX_PW_GRID=1) and two
-    work-groups that share them (KMX_PW_GRID=2) - the ring-slot reuse, the part order and the prefetch of the next tile's X are
-    all exercised with IMMEDIATE copies (a request into a slot some wave still reads would show as a wrong answer); bit for bit
-    against the one-tile-per-group kernel (KMX_PW_V2=0) and the two emulated convolution launches. The s_waitcnt counts are not
-    exercised here: that is tests/test_gpu_pointwise.py on the MI355X."""
-    code = r"""
+PW2_CODE = r"""
 import sys, json
 sys.path.insert(0, %r); sys.path.insert(0, %r)
 import numpy as np
@@ -361,7 +406,17 @@ print("RESULT " + json.dumps({"same": [bool(np.array_equal(f, p)) for f, p in zi
                               "err": [float(np.abs(f - w).max()) for f, w in zip(fused, want)], "scale": [float(np.abs(w).max()) for w in want],
                               "off_board_zero": bool((fused[2][m != 1.0] == 0).all())}))
 """ % (REPO, os.path.join(REPO, "tests"))
-    envs = ({"KMX_PW_GRID": "1"}, {"KMX_PW_GRID": "2"}, {"KMX_PW_V2": "0"})
+
+
+def test_persistent_seam_kernel_emulated(emu_full_lib):
+    """pointwise2_kernel.h on the CPU: a work-group that walks three tiles (two full, one tail of 82 cells; KMX_PW_GRID=1) and two
+    work-groups that share them (KMX_PW_GRID=2) - the ring-slot reuse, the part order and the prefetch of the next tile's X are
+    all exercised with IMMEDIATE copies (a request into a slot some wave still reads would show as a wrong answer) and with the
+    LATEST completion the kernel's s_waitcnt counts allow (a count that is too generous leaves a slab or an X tile stale); bit for
+    bit against the one-tile-per-group kernel (KMX_PW_V2=0) and the two emulated convolution launches."""
+    code = PW2_CODE
+    envs = ({"KMX_PW_GRID": "1"}, {"KMX_PW_GRID": "2"}, {"KMX_PW_V2": "0"},
+            {"KMX_PW_GRID": "1", "KMX_EMU_LATE_DMA": "1"}, {"KMX_PW_GRID": "2", "KMX_EMU_LATE_DMA": "1"})  # ... and with the latest legal completion
     runs = run_parallel([([sys.executable, "-c", code, emu_full_lib], dict(os.environ, **env)) for env in envs])
     for env, (rc, so, se) in zip(envs, runs):
         assert rc == 0 and "RESULT " in so, (so + se)[-3000:]

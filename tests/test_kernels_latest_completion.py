@@ -1,0 +1,52 @@
+"""The kernels' asynchronous-completion logic on the CPU (tests/fakehip/README.md, "Asynchronous completion"): conv_kernel.h and
+the seam kernels emulated with every LDS-DMA copy landing as LATE as the issuing wave's s_waitcnt vmcnt(N) statements allow
+(KMX_EMU_LATE_DMA=1; requests retire in order). Compile-time request counts, ring depths and barrier placement must be right for
+the answers to be - and the second test shows that they are not when a count is one too generous. (A file of its own so that the
+CPU suite's workers share the emulated builds' time; helpers and rewrite rules live in test_engine_emulated.py.)"""
+import json
+import os
+import sys
+
+from test_engine_emulated import PW2_CODE, build_emu_full, conv_only, emu_full_lib, run_parallel  # noqa: F401  (emu_full_lib is a fixture)
+
+
+def test_convolution_waitcnt_logic_with_latest_completion(emu_full_lib):
+    """KMX_EMU_LATE_DMA=1: an LDS-DMA copy lands only when an s_waitcnt vmcnt(N) of its wave forces it (requests retire in order) -
+    the latest the hardware may complete it. The convolution's compile-time counts, ring depths and barrier placement must be
+    right for the answers to be: 4-wave and 8-wave shapes, 1x1 / 3x3 / 5x5, with the product's barrier on every tap and with the
+    even-tap variant."""
+    runs = run_parallel([conv_only(emu_full_lib, {"KMX_EMU_LATE_DMA": "1", "KMX_CONV_BP2": bp2}) for bp2 in ("0", "1")])
+    for bp2, (rc, so, se) in zip(("0", "1"), runs):
+        assert rc == 0 and "RESULT " in so, (so + se)[-3000:]
+        for k, v in json.loads(so.split("RESULT ")[1]).items():
+            assert v[0] <= 2.0 ** -7 * max(1.0, v[1]) * 1.5, (bp2, k, v)
+
+
+def test_latest_completion_catches_a_wrong_count(tmp_path):
+    """The emulator's teeth: the same kernels with every top-of-step wait ONE request too generous (the padded shapes' VMCNT
+    constant, the loader waves' computed count). With immediate copies nothing shows; with the latest legal completion the slab a
+    step needs has not landed and the answers are wrong."""
+    lib = build_emu_full(str(tmp_path), conv_mutations=[
+        (r"static constexpr int VMCNT = SPREAD \? PPS \+ \(D - 2\) \* \(NPW \+ PPS\) : \(D - 2\) \* \(NPW \+ NPA\);",
+         "static constexpr int VMCNT = 1 + (SPREAD ? PPS + (D - 2) * (NPW + PPS) : (D - 2) * (NPW + NPA));", 1),
+        (r"        waitVmSel\(n\);\n      \}\n      return;", "        waitVmSel(n + 1);\n      }\n      return;", 1),
+    ], pw2_mutations=[
+        # the persistent seam kernel: phase 2 of a part lets one request more stay in flight than its loads and stores account for
+        (r"waitVmSel\(G::nR\(q\) \+ 2\);", "waitVmSel(G::nR(q) + 2 + 1);", 1),
+    ])
+    runs = run_parallel([conv_only(lib, {"KMX_EMU_LATE_DMA": late}) for late in ("0", "1")])
+    (rc0, so0, se0), (rc1, so1, se1) = runs
+    assert rc0 == 0 and rc1 == 0, (so0 + se0 + so1 + se1)[-3000:]
+    early, late = json.loads(so0.split("RESULT ")[1]), json.loads(so1.split("RESULT ")[1])
+    for k, v in early.items():
+        assert v[0] <= 2.0 ** -7 * max(1.0, v[1]) * 1.5, ("immediate copies hide the defect", k, v)
+    wrong = [k for k, v in late.items() if not v[0] <= 2.0 ** -7 * max(1.0, v[1]) * 1.5]
+    print("late completion, one request too generous:", late)
+    assert "conv3_64_32" in wrong and "conv3_96_192" in wrong, late  # the padded 4-wave shape and the 8-wave loader shape
+    # the seam kernel with its defect: right with immediate copies, wrong when a W2 slab may land as late as the count allows
+    runs = run_parallel([([sys.executable, "-c", PW2_CODE, lib], dict(os.environ, KMX_PW_GRID="1", KMX_EMU_LATE_DMA=late_)) for late_ in ("0", "1")])
+    (rc0, so0, se0), (rc1, so1, se1) = runs
+    assert rc0 == 0 and rc1 == 0, (so0 + se0 + so1 + se1)[-3000:]
+    r0, r1 = json.loads(so0.split("RESULT ")[1]), json.loads(so1.split("RESULT ")[1])
+    print("seam, one request too generous: immediate", r0["same"], "latest", r1["same"])
+    assert all(r0["same"]) and not all(r1["same"]), (r0, r1)
