@@ -74,9 +74,13 @@ enum { ABL_NO_EPILOGUE = 1, ABL_NO_COMPUTE = 2, ABL_NO_DMA = 4, ABL_NO_LDS_READ 
 // A slab is then overwritten two steps after its last read with possibly no barrier in between, so the ring holds one
 // slot more (D + 2), and at a barrier the slabs of the next TWO steps must have landed (one when the next step has a
 // barrier of its own, i.e. at the last tap of a chunk).
-template <int KS, int WN, int WNW, int D, int BP = 1>
+// CW = waves along the CELL dimension: 4 (each owns 3 tiles of 32 cells; every product shape of rounds 1-3) or 12 (each owns ONE
+// tile: the small-batch shape, see conv_mfma.hip) - CW * MTW * 32 = 384 >= 361 cells either way.
+template <int KS, int WN, int WNW, int D, int BP = 1, int CW = 4>
 struct Geom {
-  static constexpr int NWAVES = 4 * WNW;
+  static_assert(CW == 4 || (CW == 12 && WN == 1 && WNW == 1 && BP == 1), "12 cell waves exist for the 32-channel work-group only");
+  static constexpr int MTW = 12 / CW;  // 32-cell tiles per wave
+  static constexpr int NWAVES = CW * WNW;
   static constexpr int NTHREADS = NWAVES * 64;
   static constexpr int HALO = KS / 2;
   static constexpr int NT = KS * KS;
@@ -85,9 +89,11 @@ struct Geom {
   // first and which otherwise idles at the barrier; tools/conv_timing.py) fetch the weight slabs, waves 4-7 the board image.
   // No dummy requests, per-role s_waitcnt constants, and a weight wave never waits behind an HBM-latency image piece.
   // 4-wave work-groups: every wave does both, padded with dummies to a constant per-step count.
-  static constexpr bool ROLES = WNW == 2;
-  static constexpr int NLW = ROLES ? 4 : NWAVES;  // waves that fetch weights
-  static constexpr int NLA = ROLES ? 4 : NWAVES;  // waves that fetch the image
+  // 12-wave work-groups split by role too: a 32-channel slab is 2 KB = the requests of two waves (waves 0-1), the other ten share the
+  // board image - one request per wave and step at most, none of them padding.
+  static constexpr bool ROLES = WNW == 2 || CW == 12;
+  static constexpr int NLW = !ROLES ? NWAVES : CW == 12 ? (32 * WN * WNW * 4 + 63) / 64 : 4;  // waves that fetch weights
+  static constexpr int NLA = !ROLES ? NWAVES : CW == 12 ? NWAVES - NLW : 4;                    // waves that fetch the image
   static constexpr int NPA = (HPMAX * 4 + NLA * 64 - 1) / (NLA * 64);   // DMA instructions per image-loading wave per board image
   static constexpr int ACT_BYTES = (HPMAX * ROWB + 1023) / 1024 * 1024;  // instructions wholly past it go to the slack
   static constexpr int NTILE = 32 * WN * WNW;
@@ -107,7 +113,7 @@ struct Geom {
   static constexpr int LS = (NPA + PPS - 1) / PPS;
   static constexpr int NSA = SPREAD ? 2 : D + 1;
   static constexpr int NSW = D + BP;
-  static_assert(BP == 1 || (BP == 2 && WNW == 2 && KS * KS > 1 && (KS * KS) % 2 == 1 && D >= 3),
+  static_assert(BP == 1 || (BP == 2 && WNW == 2 && CW == 4 && KS * KS > 1 && (KS * KS) % 2 == 1 && D >= 3),
                 "the even-tap barrier variant exists for the 8-wave 3x3 / 5x5 shapes with a ring of at least 3 requests");
   static constexpr int SLACK_BYTES = 1024;  // destination of padding / past-the-end DMA instructions (never read; shared by all waves)
   static constexpr int NPM = (384 + NTHREADS - 1) / NTHREADS;          // 4-byte DMA instructions per wave for the mask
@@ -197,13 +203,14 @@ __device__ __forceinline__ void dma4(const void* gsrc, unsigned ldsWaveBase) {
     (const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)(size_t)ldsWaveBase, 4, 0, 0);
 }
 
-template <class TR, int KS, int WN, int WNW, int D, int ABL>
-__global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2))) void convMfmaKernel(const ConvArgs a) {
+template <class TR, int KS, int WN, int WNW, int D, int ABL, int CW = 4>
+__global__ __launch_bounds__(64 * CW * WNW) __attribute__((amdgpu_waves_per_eu(CW / 4 + 1, CW / 4 + 1))) void convMfmaKernel(const ConvArgs a) {
   typedef typename TR::T T;
   typedef typename TR::V8 V8;
   typedef typename TR::V4 V4;
   constexpr int BP = (ABL & ABL_BP2) ? 2 : 1;
-  typedef Geom<KS, WN, WNW, D, BP> G;
+  typedef Geom<KS, WN, WNW, D, BP, CW> G;
+  constexpr int MT = G::MTW;  // (shadows convk::MT, the value of the 4-cell-wave shapes)
   constexpr int HALO = G::HALO, NT = G::NT, NPA = G::NPA, NPW = G::NPW, NWAVES = G::NWAVES;
   constexpr bool SPREAD = G::SPREAD;
 
@@ -261,15 +268,16 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   // (an LDS-DMA instruction costs its wave 100-200 cycles of issue). With every request on the waves that have the slack,
   // the younger waves only multiply. (tools/conv_timing.py; ABL_TWOLOADERS restores the previous division for comparison.)
   // (possible when the image pieces have all been requested before the slab that is waited for at the last tap: LS <= NT + 1 - D)
-  constexpr bool ONE = ROLES && SPREAD && BP == 1 && G::LS <= NT + 1 - D && !(ABL & ABL_TWOLOADERS);
+  constexpr bool ONE = ROLES && CW == 4 && SPREAD && BP == 1 && G::LS <= NT + 1 - D && !(ABL & ABL_TWOLOADERS);
   // the step's fragment reads (and, in the ONE division, its DMA requests) spread over its MFMAs: needs a slot per read in each half
   constexpr bool SPREAD_STEP = WN * MT >= WN + MT && !(ABL & (ABL_BATCHED | ABL_TIMING));
   constexpr int SLOTS = WN * MT - (WN + MT);                           // MFMAs of a half-step that carry no fragment read
   constexpr bool SPREAD_DMA = SPREAD_STEP && ONE && 2 * SLOTS >= 1 + NPW;  // the image piece(s) of the tap + the slab's instructions
-  const bool wLoader = !ROLES || wave < 4;        // wave-uniform
-  const bool aLoader = !ROLES || (ONE ? wave < 4 : wave >= 4);
+  constexpr bool TAPSLOT = CW == 12 && NT % G::NSW == 0;  // ring slot of a step = ring slot of its tap
+  const bool wLoader = !ROLES || wave < G::NLW;   // wave-uniform
+  const bool aLoader = !ROLES || (ONE ? wave < 4 : wave >= G::NLW);
   const int lw = wave;                            // index among the weight-loading waves
-  const int la = ROLES ? (wave & 3) : wave;       // index among the image-loading waves
+  const int la = !ROLES ? wave : CW == 12 ? (wave >= G::NLW ? wave - G::NLW : 0) : (wave & 3);  // index among the image-loading waves
   unsigned srcOff[NPA];  // byte offset from this board's tensor, or (bit 31 set) into the zero page; +64 per chunk
 #pragma unroll
   for(int j = 0; j < NPA; j++) {
@@ -297,11 +305,13 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   }
 
   // Every call issues exactly NPW instructions (into the slack area when `step` is past the end).
-  auto issueW = [&](int step) {
+  // (slot: the ring slot when the caller knows it at compile time - the 12-wave shape, whose ring of 3 divides the 9 taps of a
+  // chunk, so that step % 3 = tap % 3 and the scalar division by 3 leaves the loop; -1: computed from the step)
+  auto issueW = [&](int step, int slot = -1) {
     if(ABL & (ABL_NO_DMA | ABL_NO_W_DMA)) return;
     const bool live = step < nSteps;
     const char* slab = wBase + (size_t)(live ? step : 0) * wSlabStride;
-    const unsigned dst = bufW + (step % G::NSW) * G::W_BYTES;
+    const unsigned dst = bufW + (slot >= 0 ? slot : step % G::NSW) * G::W_BYTES;
 #pragma unroll
     for(int j = 0; j < NPW; j++) {
       const int pbase = (j * G::NLW + (lw % G::NLW)) * 64;
@@ -350,9 +360,9 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   V8 af[2][MT];
   unsigned aAddr[MT];  // kk=0 addresses of the tap last prepared; the kk=1 fragments sit 32 bytes away (slot ^ 2)
   auto ldsV8 = [&](unsigned addr) { return *(const __attribute__((address_space(3))) V8*)addr; };
-  auto readW = [&](int kk, int stepIdx) {
+  auto readW = [&](int kk, int stepIdx, int slot = -1) {
     if(ABL & (ABL_NO_LDS_READ | ABL_NO_COMPUTE)) return;
-    const unsigned base = wLane[kk] + (unsigned)(stepIdx % G::NSW) * G::W_BYTES;
+    const unsigned base = wLane[kk] + (unsigned)(slot >= 0 ? slot : stepIdx % G::NSW) * G::W_BYTES;
 #pragma unroll
     for(int ct = 0; ct < WN; ct++) wf[kk][ct] = ldsV8(base + ct * 32 * ROWB);
   };
@@ -492,7 +502,7 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
       return;
     }
     if(ROLES) {
-      if(wLoader) issueW(step + D);
+      if(wLoader) issueW(step + D, TAPSLOT ? (t + D) % G::NSW : -1);
       else if(SPREAD) {
         // real pieces only; nothing after the image is complete (this wave waits with vmcnt(0) once per chunk)
         if(t * G::PPS < NPA && chunk + 1 < nChunks) {
@@ -582,7 +592,7 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
     seg[which] += now - tPrev;
     tPrev = now;
   };
-  if((ABL & ABL_PRIO) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+  if((ABL & ABL_PRIO) && CW == 4 && wave >= 4) __builtin_amdgcn_s_setprio(1);
   if(ABL & ABL_TIMING) tPrev = __builtin_readcyclecounter();
   const unsigned long long tLoop0 = tPrev;
   int step = 0;
@@ -647,7 +657,7 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
       }
       mfmaPart(0, 0, 1, acc);
       __builtin_amdgcn_sched_barrier(0);
-      readW(1, step);
+      readW(1, step, TAPSLOT ? t % G::NSW : -1);
       readA1();
       __builtin_amdgcn_sched_barrier(0);
       mfmaPart(0, 1, WN * MT, acc);
@@ -658,7 +668,7 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
       stamp(2);
       mfmaPart(1, 0, 1, acc);
       __builtin_amdgcn_sched_barrier(0);
-      readW(0, step + 1);
+      readW(0, step + 1, TAPSLOT ? (t + 1) % G::NSW : -1);
       readA0(t + 1 < NT ? curA : nextA, t + 1 < NT ? t + 1 : 0);
       __builtin_amdgcn_sched_barrier(0);
       mfmaPart(1, 1, WN * MT, acc);
@@ -838,13 +848,13 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   }
 }
 
-template <class TR, int KS, int WN, int WNW, int D, int ABL>
+template <class TR, int KS, int WN, int WNW, int D, int ABL, int CW = 4>
 hipError_t launchOne(const ConvArgs& a, hipStream_t stream) {
-  typedef Geom<KS, WN, WNW, D, (ABL & ABL_BP2) ? 2 : 1> G;
+  typedef Geom<KS, WN, WNW, D, (ABL & ABL_BP2) ? 2 : 1, CW> G;
   constexpr int ldsBytes = G::LDS_BYTES;
   static_assert(ldsBytes <= 160 * 1024, "LDS budget exceeded");
   static_assert(!G::SPREAD || G::LS + (G::ROLES ? 1 : D) <= G::NT, "image pieces must land within their chunk");
-  auto kern = convMfmaKernel<TR, KS, WN, WNW, D, ABL>;
+  auto kern = convMfmaKernel<TR, KS, WN, WNW, D, ABL, CW>;
   // The opt-in to more than 64 KiB of dynamic LDS is a property of the function ON ONE DEVICE, and one process may hold
   // handles on several GPUs (the reference runs one server thread per GPU in a single process): one flag per
   // instantiation and device. The call is idempotent, so a race between two handles' first launches is harmless.

@@ -22,6 +22,23 @@ using namespace convk;
 // (no 5x5 4-wave x 64-channel shape: it spills 50 registers to scratch - found in round 3 with -Rpass-analysis=kernel-resource-usage,
 // the same cause as the two "unexplained" 2x cliffs of round 2, ring depth 4 and the even-tap barrier variant)
 
+// The small-batch 3x3 shape, cfg 111 = 12 cell waves x 32 channels (conv_kernel.h, Geom<.., CW = 12>): a work-group still owns a board
+// and 32 output channels, but twelve waves of ONE 32-cell tile each instead of four waves of three. While the chip is not full a
+// layer takes as long as ONE work-group does (they all run side by side on idle CUs), and a 4-wave work-group's step is 6 MFMAs plus
+// two LDS-DMA requests per wave (a third of them padding) at ~160 cycles of issue each: 697 cycles per step, 320 of them requests
+// (profiles/r03_steps/small_batch_conv_timing.txt). With twelve waves a step is 2 MFMAs per wave and at most ONE request (two
+// waves fetch the 2 KB slab, ten share the board image, none padded). Same MFMAs per output in the same K order: bit-identical
+// results. KMX_CONV_CW12=0 / 1 overrides the default.
+constexpr bool kCw12Default = false;
+bool cw12Enabled() {
+  static const bool on = [] {
+    const char* e = getenv("KMX_CONV_CW12");
+    return e != nullptr ? e[0] == '1' : kCw12Default;
+  }();
+  return on;
+}
+constexpr int CFG_CW12 = 111;
+
 // EXPERIMENT (off unless KMX_CONV_BP2=1): the 8-wave 3x3 shapes with a work-group barrier on even
 // taps only and a ring of D + 2 slabs. Not yet run on hardware.
 bool evenTapBarriers() {
@@ -38,6 +55,7 @@ hipError_t launchT(int ks, int cfg, const ConvArgs& a, hipStream_t stream) {
     if(cfg == 22) return launchOne<TR, 3, 2, 2, 3, ABL_BP2>(a, stream);
     return launchOne<TR, 3, 3, 2, 3, ABL_BP2>(a, stream);
   }
+  if(ks == 3 && cfg == CFG_CW12) return launchOne<TR, 3, 1, 1, 2, 0, 12>(a, stream);
 #define KMX_CFG(KS_, WNW_, WN_, D_) \
   if(ks == KS_ && cfg == 10 * WNW_ + WN_) return launchOne<TR, KS_, WN_, WNW_, D_, 0>(a, stream);
   KMX_CFG_LIST(KMX_CFG)
@@ -56,6 +74,7 @@ hipError_t launchConv(int dtype, int ks, int cfg, const ConvArgs& a, hipStream_t
 }
 
 bool convCfgInstantiated(int ks, int cfg) {
+  if(ks == 3 && cfg == CFG_CW12) return true;
 #define KMX_CFG(KS_, WNW_, WN_, D_) \
   if(ks == KS_ && cfg == 10 * WNW_ + WN_) return true;
   KMX_CFG_LIST(KMX_CFG)
@@ -82,6 +101,8 @@ int chooseConvCfg(int ks, int coutPad, int batch) {
   auto wgs = [&](int cfg) { return batch * (tiles / ((cfg / 10) * (cfg % 10))); };
   const int widest8 = fits(23) ? 23 : fits(22) ? 22 : 0;
   if(widest8 && wgs(widest8) >= minWgs8) return widest8;
+  // twelve waves per 32-channel work-group while that is at most one work-group per CU (it is the only one on its CU)
+  if(ks == 3 && cw12Enabled() && batch * tiles <= 256) return CFG_CW12;
   // 3x3/5x5 narrow shapes keep two work-groups per CU (LDS), 1x1 shapes one
   const int round = ks == 1 ? 200 : 420;
   if(fits(11) && wgs(11) <= round) return 11;

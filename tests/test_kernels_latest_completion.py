@@ -50,3 +50,43 @@ def test_latest_completion_catches_a_wrong_count(tmp_path):
     r0, r1 = json.loads(so0.split("RESULT ")[1]), json.loads(so1.split("RESULT ")[1])
     print("seam, one request too generous: immediate", r0["same"], "latest", r1["same"])
     assert all(r0["same"]) and not all(r1["same"]), (r0, r1)
+
+
+CW12_CODE = r"""
+import sys, json, hashlib
+sys.path.insert(0, %r)
+import numpy as np, torch
+from katago_amd import capi
+capi._lib = capi.load_library(path=sys.argv[1])
+from katago_amd import nninterface as nn
+rng = np.random.default_rng(7)
+out = {}
+for (cin, cout, X, Y, n) in ((64, 32, 9, 9, 1), (96, 192, 19, 19, 2), (40, 200, 19, 19, 1), (64, 64, 13, 9, 1), (32, 96, 7, 11, 3)):
+    w = (rng.normal(size=(cout, cin, 3, 3)) * 0.1).astype(np.float32)
+    x = rng.normal(size=(n, Y * X, cin)).astype(np.float32)
+    got = np.asarray(nn.testEvaluateConv(w, n, X, Y, True, x))
+    xt = torch.from_numpy(x.reshape(n, Y, X, cin).transpose(0, 3, 1, 2)).to(torch.bfloat16).float()
+    wt = torch.from_numpy(w).to(torch.bfloat16).float()
+    want = torch.nn.functional.conv2d(xt, wt, padding=1).numpy().transpose(0, 2, 3, 1).reshape(n, Y * X, cout)
+    out["%%d_%%d_%%dx%%d_n%%d" %% (cin, cout, X, Y, n)] = [float(np.abs(got.reshape(want.shape) - want).max()), float(np.abs(want).max()),
+                                                   hashlib.sha1(np.ascontiguousarray(got).tobytes()).hexdigest()]
+print("RESULT " + json.dumps(out))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+
+
+def test_twelve_wave_small_batch_shape(emu_full_lib):
+    """cfg 111 (conv_mfma.hip: 12 cell waves x 32 channels, two waves fetch the slabs, ten the board image): against conv2d with
+    immediate and with the latest legal completion of its LDS-DMA requests, and BIT-IDENTICAL to the 4-wave shapes the same layers
+    take without it (same MFMAs per output in the same K order) - square, rectangular and several boards, channel counts that are
+    not multiples of the tile."""
+    runs = run_parallel([([sys.executable, "-c", CW12_CODE, emu_full_lib], dict(os.environ, KMX_CONV_CW12=cw, KMX_EMU_LATE_DMA=late))
+                         for cw, late in (("0", "0"), ("1", "0"), ("1", "1"))])
+    res = []
+    for rc, so, se in runs:
+        assert rc == 0 and "RESULT " in so, (so + se)[-3000:]
+        res.append(json.loads(so.split("RESULT ")[1]))
+    for r in res:
+        for k, v in r.items():
+            assert v[0] <= 2.0 ** -7 * max(1.0, v[1]) * 1.5, (k, v)
+    for k in res[0]:
+        assert res[0][k][2] == res[1][k][2] == res[2][k][2], ("not bit-identical across shapes", k, [r[k] for r in res])
