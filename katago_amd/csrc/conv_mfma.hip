@@ -28,8 +28,13 @@ using namespace convk;
 // two LDS-DMA requests per wave (a third of them padding) at ~160 cycles of issue each: 697 cycles per step, 320 of them requests
 // (profiles/r03_steps/small_batch_conv_timing.txt). With twelve waves a step is 2 MFMAs per wave and at most ONE request (two
 // waves fetch the 2 KB slab, ten share the board image, none padded). Same MFMAs per output in the same K order: bit-identical
-// results. KMX_CONV_CW12=0 / 1 overrides the default.
-constexpr bool kCw12Default = false;
+// results (on the MI355X: the digest of 64 rows' outputs is the same with either shape and at every batch size,
+// profiles/r03_steps/small_batch_cw12/). Measured there, b18c384nbt through kmx_eval: 26.9 -> 23.4 us per 3x3 launch at batch 1,
+// 28.1 -> 23.8 at batch 8; a pass 2.59 -> 2.35 ms (batch 1), 2.94 -> 2.60 (8), 3.36 -> 3.10 (32), 3.58 -> 3.30 (42). Less than the
+// request count suggests: with two MFMAs per wave and step nothing hides the LDS read latency of the fragments any more, and a
+// launch costs ~14 us whatever it does (the 1x1 layers and the small kernels of the same pass take 14-37 us each).
+// KMX_CONV_CW12=0 / 1 overrides the default (on).
+constexpr bool kCw12Default = true;
 bool cw12Enabled() {
   static const bool on = [] {
     const char* e = getenv("KMX_CONV_CW12");
