@@ -117,10 +117,11 @@ def test_transformer_schedule_is_consistent(name, C, H, KVH, QD, VD, F, blocks, 
     # every convolution tiles its padded channels with the chosen shape
     for (kname, grid, block, lds, args), k in zip(launches, kinds):
         if k == "conv":
-            m = re.search(r"ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi0EEE", kname)
-            ks, wn, wnw = int(m.group(1)), int(m.group(2)), int(m.group(3))
+            m = re.search(r"ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi0ELi(\d+)EEE", kname)  # kernel size, WN, WNW, ring depth, ablations, cell waves
+            ks, wn, wnw, cw = int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(5))
             cout_pad = int(args[4], 16) & 0xFFFFFFFF
-            assert grid == (cout_pad // (32 * wn * wnw), n, 1) and block == 256 * wnw and lds <= 160 * 1024
+            assert cw in (4, 12) and (cw == 4 or (ks, wn, wnw) == (3, 1, 1))
+            assert grid == (cout_pad // (32 * wn * wnw), n, 1) and block == 64 * cw * wnw and lds <= 160 * 1024
 
 
 def test_reference_transformer_nets_build_a_schedule(fake_so, tmp_path):

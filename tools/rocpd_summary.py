@@ -12,12 +12,13 @@ import sys
 
 
 def short(name):
-    m = re.search(r"convMfmaKernel<kmx::(Traits\w+), (\d+), (\d+), (\d+), (\d+), (\d+)>", name)
+    # template arguments: traits, kernel size, WN, WNW, ring depth, ablation mask and (since round 3) the number of cell waves
+    m = re.search(r"convMfmaKernel<kmx::(Traits\w+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?>", name)
+    if not m:
+        m = re.search(r"convMfmaKernelINS_\d+(Traits\w+?)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E(?:Li(\d+)E)?", name)  # mangled form
     if m:
-        return "convMfmaKernel<%s,KS=%s,WN=%s,WNW=%s,D=%s,ABL=%s>" % m.groups()
-    m = re.search(r"convMfmaKernelINS_\d+(Traits\w+?)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)  # mangled form
-    if m:
-        return "convMfmaKernel<%s,KS=%s,WN=%s,WNW=%s,D=%s,ABL=%s>" % m.groups()
+        g = m.groups()
+        return "convMfmaKernel<%s,KS=%s,WN=%s,WNW=%s,D=%s,ABL=%s%s>" % (g[:6] + ("" if g[6] in (None, "4") else ",CW=" + g[6],))
     return re.sub(r"\(.*", "", name)[:80]
 
 
