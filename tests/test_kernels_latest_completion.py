@@ -30,6 +30,8 @@ def test_latest_completion_catches_a_wrong_count(tmp_path):
         (r"static constexpr int VMCNT = SPREAD \? PPS \+ \(D - 2\) \* \(NPW \+ PPS\) : \(D - 2\) \* \(NPW \+ NPA\);",
          "static constexpr int VMCNT = 1 + (SPREAD ? PPS + (D - 2) * (NPW + PPS) : (D - 2) * (NPW + NPA));", 1),
         (r"        waitVmSel\(n\);\n      \}\n      return;", "        waitVmSel(n + 1);\n      }\n      return;", 1),
+        # the weight waves of the role-split shapes (the twelve-wave small-batch shape among them)
+        (r"static constexpr int VMCNT_W = \(D - 2\) \* NPW,", "static constexpr int VMCNT_W = 1 + (D - 2) * NPW,", 1),
     ], pw2_mutations=[
         # the persistent seam kernel: phase 2 of a part lets one request more stay in flight than its loads and stores account for
         (r"waitVmSel\(G::nR\(q\) \+ 2\);", "waitVmSel(G::nR(q) + 2 + 1);", 1),
@@ -43,6 +45,14 @@ def test_latest_completion_catches_a_wrong_count(tmp_path):
     wrong = [k for k, v in late.items() if not v[0] <= 2.0 ** -7 * max(1.0, v[1]) * 1.5]
     print("late completion, one request too generous:", late)
     assert "conv3_64_32" in wrong and "conv3_96_192" in wrong, late  # the padded 4-wave shape and the 8-wave loader shape
+    # the twelve-wave shape with its weight waves' wait one request too generous
+    runs = run_parallel([([sys.executable, "-c", CW12_CODE, lib], dict(os.environ, KMX_CONV_CW12="1", KMX_EMU_LATE_DMA=late_)) for late_ in ("0", "1")])
+    (rc0, so0, se0), (rc1, so1, se1) = runs
+    assert rc0 == 0 and rc1 == 0, (so0 + se0 + so1 + se1)[-3000:]
+    c0, c1 = json.loads(so0.split("RESULT ")[1]), json.loads(so1.split("RESULT ")[1])
+    ok = lambda v: v[0] <= 2.0 ** -7 * max(1.0, v[1]) * 1.5  # noqa: E731
+    print("twelve-wave shape, one request too generous: latest completion", {k: v[:2] for k, v in c1.items()})
+    assert all(ok(v) for v in c0.values()) and not any(ok(v) for v in c1.values()), (c0, c1)
     # the seam kernel with its defect: right with immediate copies, wrong when a W2 slab may land as late as the count allows
     runs = run_parallel([([sys.executable, "-c", PW2_CODE, lib], dict(os.environ, KMX_PW_GRID="1", KMX_EMU_LATE_DMA=late_)) for late_ in ("0", "1")])
     (rc0, so0, se0), (rc1, so1, se1) = runs
