@@ -28,6 +28,8 @@ Rank 0 prints ONE JSON line, including
                  host rows through the persistent leaf batcher (katago_amd/leaf_pump, this repo's C++ consumer of the C ABI)
                  and, when oracle/_ref/katago_hipx was built, the reference's own `benchmark` (nnEvals/s as
                  cpp/program/playutils.cpp:843,991-1000 defines it) from its unmodified search on 1024 fibers;
+  small_batches: (N = 1, outside the timed region, < 1 s) ms per pass and rows/s of the same net at batch 1 / 8 / 32 from host rows
+                 through kmx_eval - the latency-bound regime of a few games per GPU (BASELINE configs[2]; DESIGN.md 4.12);
   cpu_baseline : the CPU oracle (a port of the reference's Eigen path; Eigen itself is not buildable offline)
                  timed on this host's cores on a bounded sample of the same workload. Reported, not optimised against.
 """
@@ -409,6 +411,29 @@ def main():
         except Exception as e:  # noqa: BLE001
             callers = {"callers_error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
+    # Small batches of the same net on this box (outside the timed region, host rows through kmx_eval - H2D, pass, D2H, synchronous):
+    # what BASELINE configs[2]'s regime (a few games per GPU) sees of the device. Informative: a failure here must not cost the bench line.
+    small = None
+    if rank == 0 and world == 1 and not args.no_callers:
+        try:
+            handle.sync()
+            small = {"path": "kmx_eval from host rows (PCIe included), %s" % dtype, "ms_per_pass": {}, "rows_per_s": {}}
+            sp3, gl2 = sp.reshape(B, S, -1), gl.reshape(B, -1)
+            for n in (1, 8, 32):
+                if n > B:
+                    continue
+                for _ in range(3):
+                    nn.getOutput(handle, sp3[:n], gl2[:n], sym[:n], opt[:n])
+                reps = 20
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    nn.getOutput(handle, sp3[:n], gl2[:n], sym[:n], opt[:n])
+                ms = (time.perf_counter() - t0) / reps * 1e3
+                small["ms_per_pass"][str(n)] = round(ms, 3)
+                small["rows_per_s"][str(n)] = round(n / ms * 1e3)
+        except Exception as e:  # noqa: BLE001
+            small = {"small_batches_error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+
     if rank == 0:
         value = total_rows / elapsed
         flops_eval = model.info.flops_per_position * S
@@ -429,6 +454,8 @@ def main():
         }
         if callers:
             out.update(callers)
+        if small:
+            out["small_batches"] = small
         if host_rate is not None:
             out["host_buffer_evals_per_s"] = round(host_rate, 1)
             out["host_buffer_packed_evals_per_s"] = round(host_packed_rate, 1)
