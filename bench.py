@@ -226,6 +226,29 @@ def caller_rates(model_path, tmp):
     return out
 
 
+def small_batch_rates(nn, handle, sp, gl, sym, opt, dtype, sizes=(1, 8, 32), reps=20):
+    """Small batches of the same net on this box (outside the timed region; host rows through kmx_eval - H2D, pass, D2H, synchronous):
+    what BASELINE configs[2]'s regime (a few games per GPU) sees of the device. Informative: a failure here is recorded, not raised."""
+    try:
+        B = sp.shape[0]
+        out = {"path": "kmx_eval from host rows (PCIe included), %s" % dtype, "ms_per_pass": {}, "rows_per_s": {}}
+        sp3, gl2 = sp.reshape(B, -1, sp.shape[-1]), gl.reshape(B, -1)
+        for n in sizes:
+            if n > B:
+                continue
+            for _ in range(3):
+                nn.getOutput(handle, sp3[:n], gl2[:n], sym[:n], opt[:n])
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                nn.getOutput(handle, sp3[:n], gl2[:n], sym[:n], opt[:n])
+            ms = (time.perf_counter() - t0) / reps * 1e3
+            out["ms_per_pass"][str(n)] = round(ms, 3)
+            out["rows_per_s"][str(n)] = round(n / ms * 1e3)
+        return out
+    except Exception as e:  # noqa: BLE001
+        return {"small_batches_error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -411,28 +434,10 @@ def main():
         except Exception as e:  # noqa: BLE001
             callers = {"callers_error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
-    # Small batches of the same net on this box (outside the timed region, host rows through kmx_eval - H2D, pass, D2H, synchronous):
-    # what BASELINE configs[2]'s regime (a few games per GPU) sees of the device. Informative: a failure here must not cost the bench line.
     small = None
     if rank == 0 and world == 1 and not args.no_callers:
-        try:
-            handle.sync()
-            small = {"path": "kmx_eval from host rows (PCIe included), %s" % dtype, "ms_per_pass": {}, "rows_per_s": {}}
-            sp3, gl2 = sp.reshape(B, S, -1), gl.reshape(B, -1)
-            for n in (1, 8, 32):
-                if n > B:
-                    continue
-                for _ in range(3):
-                    nn.getOutput(handle, sp3[:n], gl2[:n], sym[:n], opt[:n])
-                reps = 20
-                t0 = time.perf_counter()
-                for _ in range(reps):
-                    nn.getOutput(handle, sp3[:n], gl2[:n], sym[:n], opt[:n])
-                ms = (time.perf_counter() - t0) / reps * 1e3
-                small["ms_per_pass"][str(n)] = round(ms, 3)
-                small["rows_per_s"][str(n)] = round(n / ms * 1e3)
-        except Exception as e:  # noqa: BLE001
-            small = {"small_batches_error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        handle.sync()
+        small = small_batch_rates(nn, handle, sp, gl, sym, opt, dtype)
 
     if rank == 0:
         value = total_rows / elapsed

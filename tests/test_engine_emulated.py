@@ -426,3 +426,34 @@ def test_persistent_seam_kernel_emulated(emu_full_lib):
         assert all(r["same"]) and r["off_board_zero"], (env, r)
         for e, sc, k in zip(r["err"], r["scale"], (1, 4, 4)):
             assert e <= 2 * 2.0 ** -7 * max(sc, 1.0) * k, (env, r)
+
+
+def test_bench_small_batch_block_emulated(emu_lib):
+    """bench.py's small_batch_rates() - the block that puts the small-batch regime into the driver's bench line - on the CPU
+    emulation of the library: same call sequence as on the GPU (kmx_eval from host rows at batch 1 / 8 on a handle made for more),
+    and its promise not to raise: a handle that was closed gives an error record, not an exception."""
+    code = r"""
+import sys, json, os
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+from katago_amd import capi
+capi._lib = capi.load_library(path=sys.argv[1])
+from katago_amd import nninterface as nn, modelgen
+import bench
+nn.globalInitialize()
+p = os.path.join(os.environ.get("TMPDIR", "/tmp"), "kmx_emu_benchsmall.bin")
+modelgen.write_model(p, "b2c32nbt", seed=9)
+ctx = nn.createComputeContext([0], 19, 19, precision="bf16")
+h = nn.createComputeHandle(ctx, nn.loadModelFile(p), 12)
+sp, gl = bench.synthetic_rows(12, 1)
+sym = (np.arange(12) %% 8).astype(np.int32); opt = np.zeros(12, np.float32)
+ok = bench.small_batch_rates(nn, h, sp, gl, sym, opt, "bf16", sizes=(1, 8, 32), reps=2)
+h.close()
+bad = bench.small_batch_rates(nn, h, sp, gl, sym, opt, "bf16", sizes=(1,), reps=1)
+print("RESULT " + json.dumps({"ok": ok, "bad": bad}))
+""" % (REPO, os.path.join(REPO, "tests"))
+    p = subprocess.run([sys.executable, "-c", code, emu_lib], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "RESULT " in p.stdout, (p.stdout + p.stderr)[-3000:]
+    res = json.loads(p.stdout.split("RESULT ")[1])
+    assert sorted(res["ok"]["ms_per_pass"]) == ["1", "8"] and all(v > 0 for v in res["ok"]["rows_per_s"].values()), res  # 32 > 12 rows: skipped
+    assert "small_batches_error" in res["bad"], res
