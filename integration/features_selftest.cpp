@@ -1,7 +1,7 @@
 // features_selftest.cpp — test infrastructure: KatamxFeatures::fillPackedV7 (integration/katamx_features.cpp) against the
 // reference's NNInputs::fillRowV7 (cpp/neuralnet/nninputs.cpp:2288-2731), both linked into this one binary, over random games.
 //
-//   features_selftest <games> <seed> [time]
+//   features_selftest <games> <seed> [time | threads N]
 //
 // Every game draws a board size (square and rectangular, smaller than or equal to the net's buffer), a full rule set (ko rule x
 // scoring x tax x suicide x button x handicap bonus x friendly pass, komi incl. extreme and integer values), optional handicap
@@ -12,7 +12,9 @@
 // globals likewise. Exit code 0 = no difference. With `time`, both are also timed on the collected positions.
 #include <chrono>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "core/global.h"
@@ -83,16 +85,17 @@ bool compareOne(const Position& q, long long index, bool verbose) {
 
 }  // namespace
 
-int main(int argc, char** argv) {
-  const int numGames = argc > 1 ? atoi(argv[1]) : 200;
-  const uint64_t seed = argc > 2 ? strtoull(argv[2], NULL, 10) : 1;
-  const bool timeIt = argc > 3 && strcmp(argv[3], "time") == 0;
-  Board::initHash();
-  ScoreValue::initTables();
-  Rand rand(seed);
+struct Tally {
+  long long positions = 0, mismatches = 0, encore1 = 0, encore2 = 0, finished = 0, hidden = 0;
+};
 
-  long long positions = 0, mismatches = 0, encore1 = 0, encore2 = 0, finished = 0, hidden = 0, ladders = 0;
-  std::vector<Position> kept;  // a sample for the timing run
+// One stream of random games (see the header of this file); kept: a sample of 19x19 positions for the timing run (may be NULL).
+static Tally playAndCompare(int numGames, uint64_t seed, std::vector<Position>* keptOut) {
+  Rand rand(seed);
+  const bool timeIt = keptOut != NULL;
+  std::vector<Position> keptLocal;
+  std::vector<Position>& kept = keptOut != NULL ? *keptOut : keptLocal;
+  long long positions = 0, mismatches = 0, encore1 = 0, encore2 = 0, finished = 0, hidden = 0;
   for(int game = 0; game < numGames; game++) {
     const Sizes bs = BOARD_SIZES[rand.nextUInt(sizeof(BOARD_SIZES) / sizeof(BOARD_SIZES[0]))];
     const bool exactLen = rand.nextBool(0.3);
@@ -156,9 +159,36 @@ int main(int argc, char** argv) {
       hist.makeBoardMoveAssumeLegal(board, loc, pla, NULL);
     }
   }
+  Tally t;
+  t.positions = positions; t.mismatches = mismatches; t.encore1 = encore1; t.encore2 = encore2; t.finished = finished; t.hidden = hidden;
+  return t;
+}
+
+// features_selftest <games> <seed> [time | threads N]: with `threads N`, N threads play <games> games each at the same time - the
+// ladder memo is process-wide and shared by a search's threads, so a race in it would show as a wrong plane here.
+int main(int argc, char** argv) {
+  const int numGames = argc > 1 ? atoi(argv[1]) : 200;
+  const uint64_t seed = argc > 2 ? strtoull(argv[2], NULL, 10) : 1;
+  const bool timeIt = argc > 3 && strcmp(argv[3], "time") == 0;
+  const int numThreads = argc > 4 && strcmp(argv[3], "threads") == 0 ? std::max(1, atoi(argv[4])) : 1;
+  Board::initHash();
+  ScoreValue::initTables();
+  std::vector<Position> kept;
+  std::vector<Tally> tallies(numThreads);
+  if(numThreads == 1)
+    tallies[0] = playAndCompare(numGames, seed, timeIt ? &kept : NULL);
+  else {
+    std::vector<std::thread> threads;
+    for(int i = 0; i < numThreads; i++)
+      threads.emplace_back([&tallies, i, numGames, seed] { tallies[i] = playAndCompare(numGames, seed + 1000003ULL * i, NULL); });
+    for(std::thread& th : threads) th.join();
+  }
+  long long positions = 0, mismatches = 0, encore1 = 0, encore2 = 0, finished = 0, hidden = 0;
+  for(const Tally& t : tallies) {
+    positions += t.positions; mismatches += t.mismatches; encore1 += t.encore1; encore2 += t.encore2; finished += t.finished; hidden += t.hidden;
+  }
   printf("features_selftest: %d games, %lld comparisons, %lld mismatches (positions in encore 1: %lld, encore 2: %lld, where a pass would end the game: %lld, finished games: %lld)\n",
-         numGames, positions, mismatches, encore1, encore2, hidden, finished);
-  (void)ladders;
+         numGames * numThreads, positions, mismatches, encore1, encore2, hidden, finished);
 
   if(timeIt && !kept.empty()) {
     const int C = NNInputs::NUM_FEATURES_SPATIAL_V7;

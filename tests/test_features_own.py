@@ -16,12 +16,13 @@ import pytest
 from conftest import ref_binary
 
 
-def run(games, seed, memo_log2=None):
+def run(games, seed, memo_log2=None, threads=1):
     binary = ref_binary("features_selftest")
     env = dict(os.environ)
     if memo_log2 is not None:
         env["KATAMX_LADDER_MEMO_LOG2"] = str(memo_log2)
-    r = subprocess.run([binary, str(games), str(seed)], capture_output=True, text=True, timeout=900, env=env)
+    r = subprocess.run([binary, str(games), str(seed)] + (["threads", str(threads)] if threads > 1 else []), capture_output=True, text=True,
+                       timeout=900, env=env)
     m = re.search(r"(\d+) comparisons, (\d+) mismatches \(positions in encore 1: (\d+), encore 2: (\d+), where a pass would end the game: (\d+), finished games: (\d+)", r.stdout)
     assert m, r.stdout[-2000:] + r.stderr[-2000:]
     comparisons, mismatches, enc1, enc2, pass_ends, finished = map(int, m.groups())
@@ -34,3 +35,11 @@ def test_bit_planes_equal_the_reference_rows(memo_log2):
     comparisons, enc1, enc2, pass_ends, finished = run(120, 20260922 + (memo_log2 or 0), memo_log2)
     # the corpus must actually reach the rare states
     assert comparisons > 30000 and enc1 > 300 and enc2 > 300 and pass_ends > 200 and finished > 100
+
+
+@pytest.mark.parametrize("memo_log2", [None, 10])
+def test_concurrent_featurisation_shares_the_ladder_memo(memo_log2):
+    """Eight threads featurise their own games at once - the way a search's threads do - through the ONE process-wide ladder memo
+    (default size, and 1024 entries so that they evict each other's entries all the time): still no difference from the reference."""
+    comparisons, enc1, enc2, pass_ends, finished = run(30, 77 + (memo_log2 or 0), memo_log2, threads=8)
+    assert comparisons > 60000 and finished > 200
