@@ -803,7 +803,8 @@ void NNEvaluator::fillRowBufs(
   NNResultBuf& buf
 ) const {
   // the declared contract of this method is the fp32 row in buf.rowSpatialBuf: expand this repository's bit planes into it
-  EvalState& st = *stateOf(this);
+  const std::shared_ptr<EvalState> sp = stateOf(this);
+  EvalState& st = *sp;
   uint8_t packedRow[KatamxFeatures::MAX_PACKED_ROW_BYTES];
   if(featurise(st, board, history, nextPlayer, sgfMeta, nnInputParams, buf, packedRow)) {
     const int numPlanes = NNModelVersion::getNumSpatialFeatures(st.modelVersion);
