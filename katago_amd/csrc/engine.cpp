@@ -171,6 +171,7 @@ void Engine::construct(const ModelDesc& model) {
   if(const char* e = getenv("KMX_FUSE_SEAMS")) fuseSeams_ = atoi(e) != 0;
   if(const char* e = getenv("KMX_PACK_INPUTS")) packInputs_ = atoi(e) != 0;
   if(const char* e = getenv("KMX_FUSE_MIN_ROWS")) fuseMinRows_ = std::max(1, atoi(e));
+  if(const char* e = getenv("KMX_FUSE_SMALL_ROWS")) fuseSmallRows_ = std::max(0, atoi(e));
   cin_ = model.numInputChannels;
   gin_ = model.numInputGlobalChannels;
   min_ = model.metaEncoderVersion > 0 ? model.numInputMetaChannels : 0;
@@ -333,10 +334,12 @@ void Engine::addSeam(const ConvDesc& post, const void* in, int inStride, const S
   // traffic of the fused form: in + residual + trunk raw + mid raw + mid act
   const double fusedBytes = 2.0 * S_ * ((double)C1 + 2.0 * C2 + 2.0 * C3);
   addOp("conv1x1_pair", 2.0 * (c1->macPerCell + c2->macPerCell) * S_, fusedBytes, [this, a1, a2, pa, C1, C2, C3, S](int n, hipStream_t st) {
-    if(n >= fuseMinRows_) {
+    const bool smallFused = fuseSmallRows_ > 0 && n >= fuseSmallRows_ && n < fuseMinRows_;
+    if(n >= fuseMinRows_ || smallFused) {
       PwPairArgs x = pa;
       x.cells = (long long)n * S;
       x.alone = cfgScale_ <= 1 && !sharesDevice_;
+      x.smallTile = smallFused ? 1 : 0;
       hipCheck(launchPointwisePair(dtype_, C1, C2, C3, x, st), "pointwise pair launch");
     }
     else {
@@ -346,7 +349,7 @@ void Engine::addSeam(const ConvDesc& post, const void* in, int inStride, const S
   });
   // the two-launch form moves the activated trunk image through HBM: its own class and byte model in the profile
   Op& op = ops_.back();
-  op.smallBelow = fuseMinRows_;
+  op.smallBelow = fuseSmallRows_ > 0 ? std::min(fuseSmallRows_, fuseMinRows_) : fuseMinRows_;  // below it: two launches
   op.clsSmall = opClass("conv1x1_pair_unfused");
   op.bytesPerRowSmall = b1 + b2;
   op.launchesSmall = 2;

@@ -216,6 +216,10 @@ class Engine {
                             // synchronous host entry) 32.9 k evals/s with it against 39.2 k without - the caller's thread packs while the GPU idles,
                             // and that costs more than the 0.3 ms of PCIe it saves; the batcher packs on the submitters' threads instead
   int fuseMinRows_ = 24;    // KMX_FUSE_MIN_ROWS: smallest batch that takes the fused seam kernel
+  // EXPERIMENT, off (0) until measured: batches of at least this many rows BELOW fuseMinRows_ take the fused seam as the 4-wave x
+  // 64-cell one-tile kernel (6 work-groups per board) instead of two convolution launches - at small batch a launch costs ~14 us
+  // whatever it does and a pass has 17 seams. KMX_FUSE_SMALL_ROWS=1 turns it on for every small batch.
+  int fuseSmallRows_ = 0;
   int forkOps_ = 0;
   hipEvent_t forkEv_ = nullptr;
 

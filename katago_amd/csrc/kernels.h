@@ -94,6 +94,9 @@ struct PwPairArgs {
   // and let the other stream's kernels in (41.5 k against 40.5-40.9 k on one box, equal within noise on another;
   // profiles/r03_steps/seam_two_streams*.txt).
   int alone;
+  // 1: take the 4-wave x 64-cell one-tile kernel whatever KMX_PW_WAVES says - twice the work-groups of half the length each; the
+  // engine's opt-in for batches below its fusion threshold (KMX_FUSE_SMALL_ROWS, engine.h), where the chip is mostly idle
+  int smallTile;
 };
 hipError_t launchPointwisePair(int dtype, int c1, int c2, int c3, const PwPairArgs& a, hipStream_t stream);
 bool pointwisePairSupported(int c1, int c2, int c3);  // is there a kernel for these channel counts?
