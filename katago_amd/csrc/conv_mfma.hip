@@ -106,8 +106,13 @@ int chooseConvCfg(int ks, int coutPad, int batch) {
   auto wgs = [&](int cfg) { return batch * (tiles / ((cfg / 10) * (cfg % 10))); };
   const int widest8 = fits(23) ? 23 : fits(22) ? 22 : 0;
   if(widest8 && wgs(widest8) >= minWgs8) return widest8;
-  // twelve waves per 32-channel work-group while that is at most one work-group per CU (it is the only one on its CU)
-  if(ks == 3 && cw12Enabled() && batch * tiles <= 256) return CFG_CW12;
+  // twelve waves per 32-channel work-group while that is at most one work-group per CU (it is the only one on its CU; measured up to
+  // there - KMX_CONV_CW12_MAX_WGS moves the limit for scans beyond it)
+  static const int cw12MaxWgs = [] {
+    const char* e = getenv("KMX_CONV_CW12_MAX_WGS");
+    return e ? atoi(e) : 256;
+  }();
+  if(ks == 3 && cw12Enabled() && batch * tiles <= cw12MaxWgs) return CFG_CW12;
   // 3x3/5x5 narrow shapes keep two work-groups per CU (LDS), 1x1 shapes one
   const int round = ks == 1 ? 200 : 420;
   if(fits(11) && wgs(11) <= round) return 11;
