@@ -43,6 +43,17 @@ bool cw12Enabled() {
   return on;
 }
 constexpr int CFG_CW12 = 111;
+// EXPERIMENT (off unless KMX_CONV_CW12_AHEAD=1; never run on hardware yet): the same shape with its fragments read a whole step
+// ahead (conv_kernel.h ABL_AHEAD) - what is left of a twelve-wave step is LDS read latency that its two MFMAs cannot cover
+// (DESIGN.md 4.12). Verified on the CPU emulation only (tests/test_kernels_latest_completion.py), bit-identical there.
+constexpr int CFG_CW12_AHEAD = 112;
+bool cw12Ahead() {
+  static const bool on = [] {
+    const char* e = getenv("KMX_CONV_CW12_AHEAD");
+    return e != nullptr && e[0] == '1';
+  }();
+  return on;
+}
 
 // EXPERIMENT (off unless KMX_CONV_BP2=1): the 8-wave 3x3 shapes with a work-group barrier on even
 // taps only and a ring of D + 2 slabs. Not yet run on hardware.
@@ -61,6 +72,7 @@ hipError_t launchT(int ks, int cfg, const ConvArgs& a, hipStream_t stream) {
     return launchOne<TR, 3, 3, 2, 3, ABL_BP2>(a, stream);
   }
   if(ks == 3 && cfg == CFG_CW12) return launchOne<TR, 3, 1, 1, 2, 0, 12>(a, stream);
+  if(ks == 3 && cfg == CFG_CW12_AHEAD) return launchOne<TR, 3, 1, 1, 2, ABL_AHEAD, 12>(a, stream);
 #define KMX_CFG(KS_, WNW_, WN_, D_) \
   if(ks == KS_ && cfg == 10 * WNW_ + WN_) return launchOne<TR, KS_, WN_, WNW_, D_, 0>(a, stream);
   KMX_CFG_LIST(KMX_CFG)
@@ -79,7 +91,7 @@ hipError_t launchConv(int dtype, int ks, int cfg, const ConvArgs& a, hipStream_t
 }
 
 bool convCfgInstantiated(int ks, int cfg) {
-  if(ks == 3 && cfg == CFG_CW12) return true;
+  if(ks == 3 && (cfg == CFG_CW12 || cfg == CFG_CW12_AHEAD)) return true;
 #define KMX_CFG(KS_, WNW_, WN_, D_) \
   if(ks == KS_ && cfg == 10 * WNW_ + WN_) return true;
   KMX_CFG_LIST(KMX_CFG)
@@ -112,7 +124,7 @@ int chooseConvCfg(int ks, int coutPad, int batch) {
     const char* e = getenv("KMX_CONV_CW12_MAX_WGS");
     return e ? atoi(e) : 256;
   }();
-  if(ks == 3 && cw12Enabled() && batch * tiles <= cw12MaxWgs) return CFG_CW12;
+  if(ks == 3 && cw12Enabled() && batch * tiles <= cw12MaxWgs) return cw12Ahead() ? CFG_CW12_AHEAD : CFG_CW12;
   // 3x3/5x5 narrow shapes keep two work-groups per CU (LDS), 1x1 shapes one
   const int round = ks == 1 ? 200 : 420;
   if(fits(11) && wgs(11) <= round) return 11;

@@ -508,7 +508,7 @@ int kmx_debug_conv_cfg(int ks, int cout_pad, int batch, int* cfg, int* instantia
     if(!cfg || !instantiated || cout_pad < 64 || cout_pad % 64 != 0 || batch < 1 || (ks != 1 && ks != 3 && ks != 5))
       throw Error(KMX_ERR_INVALID_ARG, "kmx_debug_conv_cfg: bad argument");
     *cfg = chooseConvCfg(ks, cout_pad, batch);
-    const int ntile = *cfg == 111 ? 32 : 32 * (*cfg / 10) * (*cfg % 10);  // 111: twelve cell waves x 32 channels (conv_mfma.hip)
+    const int ntile = *cfg >= 111 ? 32 : 32 * (*cfg / 10) * (*cfg % 10);  // 111 / 112: twelve cell waves x 32 channels (conv_mfma.hip)
     *instantiated = (convCfgInstantiated(ks, *cfg) && cout_pad % ntile == 0) ? 1 : 0;
   });
 }

@@ -50,7 +50,7 @@ def emu_lib(tmp_path_factory):
 # v_permlane32_swap run as wave-collectives in the hardware's register layout.
 CONV_REWRITES = [
     (r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\(N\) : "memory"\);', "emu::waitVm(N);", 1),
-    (r'asm volatile\("" : "\+s"\(sTap\)\);', ";", 2),
+    (r'asm volatile\("" : "\+s"\(sTap\)\);', ";", 3),
     (r'asm volatile\("" ::"v"\((rawQ|actQ)\[j\]\)\);', ";", 2),
     (r'asm volatile\("" : "\+v"\(pOff\)\);', ";", 1),
     (r'extern __shared__ __attribute__\(\(aligned\(256\)\)\) char smem\[\];', "char* const smem = (char*)emu::dynLds();", 1),

@@ -117,7 +117,7 @@ def test_transformer_schedule_is_consistent(name, C, H, KVH, QD, VD, F, blocks, 
     # every convolution tiles its padded channels with the chosen shape
     for (kname, grid, block, lds, args), k in zip(launches, kinds):
         if k == "conv":
-            m = re.search(r"ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi0ELi(\d+)EEE", kname)  # kernel size, WN, WNW, ring depth, ablations, cell waves
+            m = re.search(r"ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(?:0|262144)ELi(\d+)EEE", kname)  # kernel size, WN, WNW, ring depth, ablations, cell waves
             ks, wn, wnw, cw = int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(5))
             cout_pad = int(args[4], 16) & 0xFFFFFFFF
             assert cw in (4, 12) and (cw == 4 or (ks, wn, wnw) == (3, 1, 1))
