@@ -43,9 +43,9 @@ bool cw12Enabled() {
   return on;
 }
 constexpr int CFG_CW12 = 111;
-// EXPERIMENT (off unless KMX_CONV_CW12_AHEAD=1; never run on hardware yet): the same shape with its fragments read a whole step
+// EXPERIMENT (off unless KMX_CONV_CW12_AHEAD=1; parity green on the MI355X - 34 layer tests - but not yet timed): the same shape with its fragments read a whole step
 // ahead (conv_kernel.h ABL_AHEAD) - what is left of a twelve-wave step is LDS read latency that its two MFMAs cannot cover
-// (DESIGN.md 4.12). Verified on the CPU emulation only (tests/test_kernels_latest_completion.py), bit-identical there.
+// (DESIGN.md 4.12). Bit-identical to the other shapes on the CPU emulation (tests/test_kernels_latest_completion.py).
 constexpr int CFG_CW12_AHEAD = 112;
 bool cw12Ahead() {
   static const bool on = [] {
