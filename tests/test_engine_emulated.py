@@ -447,9 +447,9 @@ ctx = nn.createComputeContext([0], 19, 19, precision="bf16")
 h = nn.createComputeHandle(ctx, nn.loadModelFile(p), 12)
 sp, gl = bench.synthetic_rows(12, 1)
 sym = (np.arange(12) %% 8).astype(np.int32); opt = np.zeros(12, np.float32)
-ok = bench.small_batch_rates(nn, h, sp, gl, sym, opt, "bf16", sizes=(1, 8, 32), reps=2)
+ok = bench.small_batch_rates(nn, h, sp, gl, sym, opt, "bf16", sizes=(1, 8, 32), reps=2, warm=1)
 h.close()
-bad = bench.small_batch_rates(nn, h, sp, gl, sym, opt, "bf16", sizes=(1,), reps=1)
+bad = bench.small_batch_rates(nn, h, sp, gl, sym, opt, "bf16", sizes=(1,), reps=1, warm=1)
 print("RESULT " + json.dumps({"ok": ok, "bad": bad}))
 """ % (REPO, os.path.join(REPO, "tests"))
     p = subprocess.run([sys.executable, "-c", code, emu_lib], capture_output=True, text=True, timeout=900)

@@ -146,10 +146,12 @@ def test_error_statistics_large_nets_default_precision(ctx19, model_dir, arch):
     h.close()
 
 
-def test_full_batch_properties(ctx19, model_dir):
-    """BASELINE size (b18c384nbt, batch 256): finite outputs; every row equals the same position evaluated in a
-    small batch (bit exact: rows never interact); evaluating with symmetry s equals evaluating the pre-symmetrised
-    board with symmetry 0 and un-symmetrising the outputs."""
+@pytest.mark.parametrize("precision", ["auto", "bf16"])
+def test_full_batch_properties(ctx19, model_dir, precision):
+    """BASELINE size (b18c384nbt, batch 256), in the backend's DEFAULT precision (what bench.py times: fp16 with the 1/8 range
+    transform) and in bf16: finite outputs; every row equals the same position evaluated in a small batch (bit exact: rows
+    never interact); evaluating with symmetry s equals evaluating the pre-symmetrised board with symmetry 0 and
+    un-symmetrising the outputs."""
     p = os.path.join(model_dir, "prop_b18.bin")
     if not os.path.exists(p):
         modelgen.write_model(p, "b18c384nbt", seed=5)
@@ -157,7 +159,9 @@ def test_full_batch_properties(ctx19, model_dir):
     base, gbase = make_rows(rng, 8)
     sp, gl = np.tile(base, (32, 1, 1)), np.tile(gbase, (32, 1))
     sym = (np.arange(256) // 8 % 8).astype(np.int32)
-    h = nn.createComputeHandle(ctx19["bf16"], nn.loadModelFile(p), 256)
+    ctx = nn.createComputeContext([0], 19, 19, precision="auto") if precision == "auto" else ctx19[precision]
+    h = nn.createComputeHandle(ctx, nn.loadModelFile(p), 256)
+    assert h.precision == ("fp16" if precision == "auto" else precision)
     big = nn.getOutput(h, sp, gl, sym)
     assert all(np.isfinite(big[k]).all() for k in big)
     small = nn.getOutput(h, sp[:8], gl[:8], sym[:8])
@@ -186,6 +190,44 @@ def test_full_batch_properties(ctx19, model_dir):
         o = nn.getOutput(h, img, gl[r:r + 1], [0])
         pol = oracle.copyWithSymmetry(o["policy"][0, :361].reshape(19, 19, 1), s, True).reshape(361)
         assert np.array_equal(pol, big["policy"][r, :361]) and np.array_equal(o["value"][0], big["value"][r])
+    h.close()
+
+
+def test_headline_batch_vs_oracle_default_precision(model_dir):
+    """BASELINE configs[1] end to end in the DEFAULT precision against the oracle: b18c384nbt, ONE batch of 256 distinct
+    positions (full boards, 13x13, 9x9 and rectangular boards in the 19x19 buffer; every symmetry; optimism 0..1) through the
+    handle bench.py times - two engines on two streams, the 8-wave convolution shapes and the persistent seam kernel - and 16
+    of its rows through the fp32 oracle (~1 s of CPU): the first and last row of the batch, both sides of the split between the
+    two half-batch engines, and small boards from either half. Tolerance as for the deep nets above: 2 % of the value + 0.05
+    (the reference's own layer tolerance is 3 % of max(|x|, 3), cpp/tests/testnn.cpp:8-15), and its cross-backend statistics
+    (testnnevalcanary.cpp:806-807) over the sample."""
+    p = os.path.join(model_dir, "prop_b18.bin")
+    if not os.path.exists(p):
+        modelgen.write_model(p, "b18c384nbt", seed=5)
+    rng = np.random.default_rng(256)
+    n = 256
+    sizes = ([(19, 19)] * 5 + [(13, 13), (9, 9), (19, 10)]) * (n // 8)
+    sp, gl = make_rows(rng, n, 19, sizes)
+    sym = rng.integers(0, 8, n).astype(np.int32)
+    opt = rng.random(n).astype(np.float32)
+    model = nn.loadModelFile(p)
+    h = nn.createComputeHandle(nn.createComputeContext([0], 19, 19, precision="auto"), model, 256)
+    assert h.precision == "fp16"
+    big = nn.getOutput(h, sp, gl, sym, opt)
+    assert all(np.isfinite(v).all() for v in big.values())
+    rows = np.array([0, 1, 5, 6, 7, 64, 126, 127, 128, 129, 133, 134, 135, 200, 254, 255])
+    assert {sizes[r] for r in rows} == {(19, 19), (13, 13), (9, 9), (19, 10)}
+    want = oracle_outputs(("headline256",), p, sp[rows], gl[rows], sym[rows], opt[rows])
+    got = {k: v[rows] for k, v in big.items()}
+    assert outputs_close(got, want, sp[rows][:, :, 0] > 0, 0.02, 0.05)
+    info = nn.getModelDesc(model)["postProcessParams"]
+    stats = ps.error_stats(ps.postprocess(want, sp[rows], info), ps.postprocess(got, sp[rows], info))
+    print("headline batch, default precision:", {k: float("%.4g" % v) for k, v in stats.items()})
+    assert not ps.check(stats, ps.LIMITS_REDUCED), stats
+    # the same rows in a batch of 16 (one engine, the 4-wave / twelve-wave shapes, two plain convolutions per seam): bit-identical
+    part = nn.getOutput(h, sp[rows], gl[rows], sym[rows], opt[rows])
+    for k in part:
+        assert np.array_equal(part[k], got[k]), k
     h.close()
 
 

@@ -11,6 +11,7 @@ import zipfile
 import numpy as np
 import pytest
 
+import shard_checks
 from conftest import REPO, ref_binary
 
 pytestmark = pytest.mark.gpu
@@ -125,3 +126,48 @@ def test_selfplay_rate_with_leaves_in_flight_per_game(tmp_path):
             f.write("\n".join(lines) + "\n")
     assert rates["8 leaves per game (fibers), visits of selfplay8mainb18.cfg"] >= 2500.0, lines
     assert rates["8 leaves per game (fibers)"] >= 2.0 * rates["1 leaf per game"], lines
+
+
+def test_mixed_board_sizes_b18_own_evaluator_writes_valid_shards(tmp_path):
+    """BASELINE configs[4] through the PRODUCT path: `katago_hipx selfplay` (this repo's NNEvaluator + featuriser + fibers over the leaf
+    batcher) on b18c384nbt with the reference's production self-play settings (tools/selfplay_cfg.py = selfplay8mainb18.cfg), board
+    sizes 9 / 13 / 19 mixed in ONE 19x19 buffer (selfplay8mainb18.cfg:76-77 mixes 13 sizes the same way), 8 games x 8 leaves in
+    flight, ownership + score targets, .npz shards. Every row the evaluator submits is also featurised by the reference's
+    NNInputs::fillRowV7 and compared (KATAMX_FEATURES=check aborts on the first difference). Visits are cut to 48 / 24 and games
+    to 50 moves so that the test takes a minute; the rates of full-length games are bench.py's and profiles/' business."""
+    import sys
+
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import selfplay_cfg
+    from katago_amd import modelgen
+
+    b = ref_binary("katago_hipx")
+    d = str(tmp_path)
+    os.makedirs(os.path.join(d, "models"))
+    modelgen.write_model(os.path.join(d, "models", "b18c384nbt-s1-d1.bin.gz"), "b18c384nbt", seed=7)
+    cfg = selfplay_cfg.write(os.path.join(d, "mixed.cfg"), numGameThreads=8, numSearchThreads=8, nnMaxBatchSize=64, maxVisits=48,
+                             cheapSearchVisits=24, reducedVisitsMin=24, estimateLeadVisits=6, maxMovesPerGame=50, logGamesEvery=1000,
+                             nnCacheSizePowerOfTwo=18, nnMutexPoolSizePowerOfTwo=14, maxRowsPerTrainFile=400, firstFileRandMinProp=1.0,
+                             switchNetsMidGame="false", **selfplay_cfg.MIXED_9_13_19)
+    env = dict(os.environ, KATAMX_LEAVES_PER_THREAD="8", KATAMX_FEATURES="check")
+    p = subprocess.run([b, "selfplay", "-config", cfg, "-models-dir", os.path.join(d, "models"), "-output-dir", os.path.join(d, "out"),
+                        "-max-games-total", "30"], capture_output=True, text=True, timeout=900, cwd=d, env=env)
+    log = p.stdout + p.stderr
+    assert p.returncode == 0 and "All cleaned up, quitting" in log, log[-3000:]
+    assert "katamx (HIP/gfx950) backend" in log
+    rows = int(log.split("Final data rows: ")[1].split()[0])
+    nn_rows = int(log.split("Final NN rows: ")[1].split()[0])
+    batches = int(log.split("Final NN batches: ")[1].split()[0])
+    games = int(log.split("Final games finished: ")[1].split()[0])
+    secs = float(log.split("Total selfplay runtime (seconds): ")[1].split()[0])
+    assert games >= 30 and rows > 0 and nn_rows > 20 * games
+    per_size = shard_checks.check_shards(shard_checks.shard_files(os.path.join(d, "out")), 19, (9, 13, 19), rows)
+    line = ("configs[4]: katago_hipx selfplay b18c384nbt, bSizes 9,13,19 in a 19x19 buffer, 8 games x 8 leaves, 48/24 visits, <=50 moves, "
+            "KATAMX_FEATURES=check: %d games, %d training rows (by board size %s), %d NN rows in %d batches (avg %.1f), %.1f s = %.0f NN rows/s"
+            % (games, rows, per_size, nn_rows, batches, nn_rows / max(batches, 1), secs, nn_rows / secs))
+    print(line)
+    keep = os.path.join(REPO, "gpurun_out")
+    if os.path.isdir(keep):
+        with open(os.path.join(keep, "selfplay_mixed_sizes_b18.txt"), "w") as f:
+            f.write(line + "\n")
+    assert all(v > 0 for v in per_size.values()), per_size  # all three board sizes produced training rows

@@ -160,3 +160,35 @@ def test_zipfile_on_its_own(tmp_path):
     with np.load(os.path.join(tmp_path, "ok.zip")) as z:
         a = z["partial"]
         assert a.dtype == np.float32 and a.shape == (3, 3, 2) and np.array_equal(a.reshape(-1), 0.5 * np.arange(18, dtype=np.float32))
+
+
+def test_mixed_board_sizes_in_one_buffer_cpu_twin(tmp_path):
+    """The CPU twin of tests/test_gpu_selfplay.py::test_mixed_board_sizes_b18_own_evaluator_writes_valid_shards (BASELINE configs[4]):
+    the reference's production self-play settings (tools/selfplay_cfg.py) with 9 / 13 / 19 boards mixed in one 19x19 buffer, through
+    this repo's NNEvaluator and featuriser (oracle/_ref/katago_oraclex: the same host code over the CPU oracle instead of the
+    MI355X), every submitted row compared with NNInputs::fillRowV7 (KATAMX_FEATURES=check); the small g170 net and a handful of
+    visits keep it to seconds. The shards are checked for all three sizes, ownership / policy targets confined to the board."""
+    import shard_checks
+
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import selfplay_cfg
+
+    bx = os.path.join(REF_BIN_DIR, "katago_oraclex")
+    if not (os.path.exists(bx) and os.path.exists(MODEL)):
+        pytest.skip("oracle/_ref/katago_oraclex not built (make -C oracle ref needs the reference checkout)")
+    d = str(tmp_path)
+    os.makedirs(os.path.join(d, "models"))
+    shutil.copy(MODEL, os.path.join(d, "models"))
+    cfg = selfplay_cfg.write(os.path.join(d, "mixed.cfg"), numGameThreads=4, numSearchThreads=2, nnMaxBatchSize=8, maxVisits=6,
+                             cheapSearchVisits=3, reducedVisitsMin=3, estimateLeadVisits=2, maxMovesPerGame=24, logGamesEvery=1000,
+                             nnCacheSizePowerOfTwo=14, nnMutexPoolSizePowerOfTwo=10, maxRowsPerTrainFile=60, firstFileRandMinProp=1.0,
+                             switchNetsMidGame="false", **selfplay_cfg.MIXED_9_13_19)
+    env = dict(os.environ, KATAMX_FEATURES="check", KATAMX_LEAVES_PER_THREAD="2")
+    p = subprocess.run([bx, "selfplay", "-config", cfg, "-models-dir", os.path.join(d, "models"), "-output-dir", os.path.join(d, "out"),
+                        "-max-games-total", "24"], capture_output=True, text=True, timeout=900, cwd=d, env=env)
+    log = p.stdout + p.stderr
+    assert p.returncode == 0 and "All cleaned up, quitting" in log, log[-3000:]
+    rows = int(log.split("Final data rows: ")[1].split()[0])
+    per_size = shard_checks.check_shards(shard_checks.shard_files(os.path.join(d, "out")), 19, (9, 13, 19), rows)
+    print("training rows by board size:", per_size)
+    assert all(v > 0 for v in per_size.values()), per_size
