@@ -32,8 +32,20 @@
 
 namespace {
 
-constexpr size_t STACK_BYTES = 2u << 20;  // the descent is recursive (one frame per ply, search.cpp:1440); pages are committed on touch
+// The descent is recursive (one frame per ply, search.cpp:1440, with Board copies and per-move arrays in it) and normally runs on an
+// 8 MiB thread stack: a fiber gets the same (KATAMX_FIBER_STACK_MB overrides, 1..64). The mapping is MAP_NORESERVE and pages are
+// committed on touch, so the size costs address space only. Below it sits a guard page: running into it is a SIGSEGV, not silent
+// corruption of a neighbour's stack - and a guard that cannot be installed is an error, not a warning.
 constexpr size_t GUARD_BYTES = 1u << 12;
+size_t stackBytes() {
+  static const size_t bytes = [] {
+    const char* e = getenv("KATAMX_FIBER_STACK_MB");
+    long mb = e ? atol(e) : 8;
+    mb = mb < 1 ? 1 : mb > 64 ? 64 : mb;
+    return (size_t)mb << 20;
+  }();
+  return bytes;
+}
 
 std::atomic<uint64_t> gFibersRun{0}, gParks{0}, gBlockingWaits{0};
 
@@ -50,10 +62,13 @@ struct StackPool {
         return s;
       }
     }
-    void* p = mmap(NULL, STACK_BYTES + GUARD_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK | MAP_NORESERVE, -1, 0);
+    void* p = mmap(NULL, stackBytes() + GUARD_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK | MAP_NORESERVE, -1, 0);
     if(p == MAP_FAILED)
       throw StringError("katamx fibers: cannot map a fiber stack");
-    mprotect(p, GUARD_BYTES, PROT_NONE);  // the stack grows down towards it
+    if(mprotect(p, GUARD_BYTES, PROT_NONE) != 0) {  // the stack grows down towards it
+      munmap(p, stackBytes() + GUARD_BYTES);
+      throw StringError("katamx fibers: cannot protect the guard page of a fiber stack");
+    }
     return (char*)p;
   }
   void put(char* s) {
@@ -73,6 +88,7 @@ struct Fiber {
   Sched* sched = NULL;
   int logicalIdx = 0;
   bool done = false;
+  bool yielded = false;    // sits in the queue because it yielded (waitForNextNNEvalIfAny), not because it is new or parked on a ticket
   bool hasTicket = false;
   KatamxLeaf::Port* port = NULL;
   uint64_t ticket = 0;
@@ -180,9 +196,19 @@ bool KatamxFibers::yieldToOthers() {
   Sched* s = tlsSched;
   if(s == NULL || s->current == NULL || s->queue.empty())
     return false;
+  // Someone to yield TO: a fiber that has not started yet or one parked on a ticket. When every queued fiber is itself a yielder,
+  // they are all waiting for evaluations of OTHER OS threads: passing the thread round among them would spin hot - the caller
+  // then sleeps on the evaluator's completion count instead (as the reference's waitForNextNNEvalIfAny does).
+  bool useful = false;
+  for(const Fiber* q : s->queue)
+    useful = useful || !q->yielded;
+  if(!useful)
+    return false;
   Fiber* f = s->current;
+  f->yielded = true;
   s->queue.push_back(f);
   swapcontext(&f->ctx, &s->mainCtx);
+  f->yielded = false;
   return true;
 }
 
@@ -205,7 +231,7 @@ void KatamxFibers::runOnFibers(std::function<void(int)>* task, const int* indice
     f->stack = stackPool().get();
     getcontext(&f->ctx);
     f->ctx.uc_stack.ss_sp = f->stack + GUARD_BYTES;
-    f->ctx.uc_stack.ss_size = STACK_BYTES;
+    f->ctx.uc_stack.ss_size = stackBytes();
     f->ctx.uc_link = NULL;
     const uintptr_t p = (uintptr_t)f.get();
     makecontext(&f->ctx, (void (*)())trampoline, 2, (unsigned)(p & 0xffffffffu), (unsigned)(p >> 32));

@@ -6,8 +6,9 @@
 // on top of the persistent leaf batcher of the C ABI (include/katamx.h, kmx_batcher_*). integration/katamx_nneval.cpp
 // (this repo's NNEvaluator) is its caller; nothing in the unmodified reference needs this header.
 //
-// In the CPU-oracle build of the binding (-DKMX_USE_ORACLE, test infrastructure) a port evaluates each row synchronously
-// inside submit(): same interface, so that the evaluator's host logic runs under the reference's own tests without a GPU.
+// (Test builds link the binding against an implementation of the C ABI on the CPU oracle, oracle/kmx_abi_on_oracle.cpp, whose
+// "batcher" evaluates each row synchronously inside submit: the evaluator's host logic then runs under the reference's own
+// tests without a GPU. Nothing in this header or in the binding knows about that.)
 #ifndef KATAMX_LEAF_H_
 #define KATAMX_LEAF_H_
 

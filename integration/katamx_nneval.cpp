@@ -107,6 +107,7 @@ struct PortSlot {
   bool usingFP16 = false;
   std::mutex randMutex;
   std::unique_ptr<Rand> rand;  // seeded like the reference's server thread of the same index: the symmetry draws match
+  std::atomic<int> rowsInFlight{0};  // submitted to this port's batcher and not yet collected (begin -> finish)
 };
 
 struct EvalState {
@@ -452,6 +453,32 @@ bool featurise(EvalState& st, const Board& board, const BoardHistory& history, P
   return own;
 }
 
+// Which device gets this row (one port per server-thread index of the reference's configuration, i.e. per GPU: nneval.cpp:399-407).
+// The reference's server threads pull from ONE queue, so an idle GPU takes the next rows whatever the others are doing; the
+// equivalent for rows that are pushed is the port with the FEWEST rows in flight. (Round 3 dealt rows round-robin: with cache
+// hits, games ending and searches of different length the ports drift apart, and a pass costs the same for 40 rows as for 60 -
+// the lighter device idles while the heavier one queues a second batch.) Ties go round: the scan starts one port further each time,
+// which with equal loads is exactly the round-robin order. Spreading, not filling one device first: a pass over L/N rows is
+// shorter than a pass over L, so N devices with L/N rows each finish L rows sooner than L/256 devices with full batches.
+PortSlot& pickPort(EvalState& st) {
+  const size_t n = st.ports.size();
+  const size_t start = st.nextPort.fetch_add(1, std::memory_order_relaxed) % n;
+  size_t best = start;
+  if(n > 1) {
+    int bestLoad = st.ports[start]->rowsInFlight.load(std::memory_order_relaxed);
+    for(size_t k = 1; k < n && bestLoad > 0; k++) {
+      const size_t i = (start + k) % n;
+      const int load = st.ports[i]->rowsInFlight.load(std::memory_order_relaxed);
+      if(load < bestLoad) {
+        bestLoad = load;
+        best = i;
+      }
+    }
+  }
+  st.ports[best]->rowsInFlight.fetch_add(1, std::memory_order_relaxed);
+  return *st.ports[best];
+}
+
 }  // namespace
 
 // ---- begin / finish -----------------------------------------------------------------------------------------------------
@@ -528,7 +555,8 @@ void KatamxNNEval::begin(
     const bool rowIsPacked = featurise(st, board, history, nextPlayer, sgfMeta, params, buf, packedRow);
     if(st.ports.empty())
       throw StringError("NNEvaluator::evaluate called before spawnServerThreads");
-    PortSlot& slot = *st.ports[st.nextPort.fetch_add(1, std::memory_order_relaxed) % st.ports.size()];
+    PortSlot& slot = pickPort(st);
+    leaf.portSlot = &slot;
     if(buf.symmetry == NNInputs::SYMMETRY_NOTSPECIFIED) {
       if(st.doRandomize->load(std::memory_order_acquire)) {
         std::lock_guard<std::mutex> lock(slot.randMutex);
@@ -552,6 +580,10 @@ void KatamxNNEval::begin(
     leaf.inFlight = true;
   }
   catch(...) {
+    if(leaf.portSlot != NULL) {
+      static_cast<PortSlot*>(leaf.portSlot)->rowsInFlight.fetch_sub(1, std::memory_order_relaxed);
+      leaf.portSlot = NULL;
+    }
     flightEnd(st);
     throw;
   }
@@ -565,6 +597,10 @@ void KatamxNNEval::finish(NNEvaluator& nnEval, Leaf& leaf) {
   EvalState& st = *sp;
   NNResultBuf& buf = *leaf.buf;
   leaf.inFlight = false;
+  if(leaf.portSlot != NULL) {
+    static_cast<PortSlot*>(leaf.portSlot)->rowsInFlight.fetch_sub(1, std::memory_order_relaxed);
+    leaf.portSlot = NULL;
+  }
   if(leaf.port != NULL) {
     try {
       if(!leaf.ticketCollected)
@@ -847,6 +883,7 @@ std::shared_ptr<NNOutput>* NNEvaluator::averageMultipleSymmetries(
   std::iota(order.begin(), order.end(), 0);
   std::vector<std::unique_ptr<NNResultBuf>> bufs;
   std::vector<std::unique_ptr<KatamxNNEval::Leaf>> leaves;
+  std::exception_ptr failure;
   for(int i = 0; i < numSymmetriesToSample; i++) {
     std::swap(order[i], order[rand.nextInt(i, SymmetryHelpers::NUM_SYMMETRIES - 1)]);
     MiscNNInputParams params = baseNNInputParams;
@@ -854,11 +891,20 @@ std::shared_ptr<NNOutput>* NNEvaluator::averageMultipleSymmetries(
     bufs.emplace_back(new NNResultBuf());
     leaves.emplace_back(new KatamxNNEval::Leaf());
     // no cache: nothing says which symmetry a cached entry was computed with
-    KatamxNNEval::begin(*this, board, history, nextPlayer, sgfMeta, params, *bufs.back(), true, includeOwnerMap, *leaves.back());
+    try {
+      KatamxNNEval::begin(*this, board, history, nextPlayer, sgfMeta, params, *bufs.back(), true, includeOwnerMap, *leaves.back());
+    }
+    catch(...) {
+      // (the batcher is shutting down, a submit failed) The leaves begun so far are on the device, and the batcher's completion
+      // thread will write into their Leaf / NNOutput buffers: they must be collected before those buffers go out of scope
+      failure = std::current_exception();
+      leaves.pop_back();
+      bufs.pop_back();
+      break;
+    }
   }
   vector<std::shared_ptr<NNOutput>> results;
-  std::exception_ptr failure;
-  for(int i = 0; i < numSymmetriesToSample; i++) {
+  for(size_t i = 0; i < leaves.size(); i++) {
     try {
       KatamxNNEval::finish(*this, *leaves[i]);
       results.push_back(std::move(bufs[i]->result));

@@ -38,6 +38,7 @@ struct Leaf {
   MiscNNInputParams nnInputParams;
   Hash128 nnHash;
   KatamxLeaf::Port* port = NULL;
+  void* portSlot = NULL;   // the evaluator's bookkeeping of that port (rows in flight per device); owned by the evaluator
   uint64_t ticket = 0;
   bool inFlight = false;   // handed to the device, finish() must be called
   bool done = false;       // buf->result is final (cache hit, or finish() ran)

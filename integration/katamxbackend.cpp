@@ -6,11 +6,9 @@
 // (nninterface.h:15-28) on top of include/katamx.h, so that the UNMODIFIED reference host code
 // (nneval.cpp, search/, command/benchmark.cpp, gputest.cpp, tests/*) runs on the MI355X backend.
 // It is compiled against the reference headers with -I<reference>/cpp (see INTEGRATION.md and
-// oracle/Makefile); it contains no arithmetic.
-//
-// With -DKMX_USE_ORACLE the same TU binds the CPU oracle (oracle/kmx_oracle.h) instead. That build
-// (oracle/_ref/katago_oracle) is test infrastructure: it lets the reference's own known-answer
-// tests pin the oracle, and plays the role of the reference's Eigen build in `testgpuerror`.
+// oracle/Makefile); it contains no arithmetic and knows nothing but the C ABI.
+// (The test builds oracle/_ref/katago_oracle{,x} link this same object file against an implementation of the ABI on the CPU
+// oracle, oracle/kmx_abi_on_oracle.cpp, instead of libkatamx.so - that lives under oracle/, not here.)
 
 #include "neuralnet/nninterface.h"
 #include "neuralnet/nneval.h"
@@ -29,17 +27,18 @@
 
 #include "katamx.h"
 #include "katamx_leaf.h"
-#ifdef KMX_USE_ORACLE
-#include "kmx_oracle.h"
-#endif
 
 using namespace std;
 
-#ifdef KMX_USE_ORACLE
-static string lastError() { return string(okmx_last_error()); }
-#else
 static string lastError() { return string(kmx_last_error()); }
-#endif
+// what the library says it runs on (the device's marketing name)
+static string deviceLabel(int gpuIdx) {
+  char name[256];
+  return kmx_device_name(gpuIdx < 0 ? 0 : gpuIdx, name, sizeof(name)) == KMX_OK ? string(name) : string("?");
+}
+static const char* precisionName(int prec) {
+  return prec == KMX_PREC_FP32 ? "fp32" : prec == KMX_PREC_FP16 ? "fp16" : "bf16";
+}
 static void check(int status, const char* what) {
   if(status != KMX_OK)
     throw StringError(string("katamx backend: ") + what + ": " + lastError());
@@ -48,28 +47,16 @@ static void check(int status, const char* what) {
 // ---------------------------------------------------------------------------------------------
 struct LoadedModel {
   ModelDesc modelDesc;  // parsed by the reference loader: NNEvaluator reads name/version/postprocess
-#ifdef KMX_USE_ORACLE
-  okmx_model* model = NULL;
-#else
   kmx_model* model = NULL;
-#endif
   LoadedModel(const string& file, const string& expectedSha256) {
     ModelDesc::loadFromFileMaybeGZipped(file, modelDesc, expectedSha256);
     // The backend re-parses the file itself; it does not depend on the host's ModelDesc layout.
-#ifdef KMX_USE_ORACLE
-    check(okmx_model_load(file.c_str(), expectedSha256.c_str(), &model), "loading model");
-#else
     check(kmx_model_load(file.c_str(), expectedSha256.c_str(), &model), "loading model");
-#endif
     // This backend never applies the scale-8 transform (desc.cpp:2718-2736): outputScaleMultiplier stays 1.
     modelDesc.releaseWeights();
   }
   ~LoadedModel() {
-#ifdef KMX_USE_ORACLE
-    okmx_model_free(model);
-#else
     kmx_model_free(model);
-#endif
   }
   LoadedModel() = delete;
   LoadedModel(const LoadedModel&) = delete;
@@ -80,7 +67,6 @@ struct ComputeContext {
   int nnXLen;
   int nnYLen;
   int precisionMode;
-#ifndef KMX_USE_ORACLE
   kmx_context* ctx = NULL;
   // katamxBatcher = true: every server thread of this context that serves the same (model, device) feeds ONE persistent leaf
   // batcher (kmx_batcher_*) instead of owning a handle: its getOutput submits the rows NNEvaluator::serve popped and waits
@@ -95,7 +81,6 @@ struct ComputeContext {
   };
   std::mutex batcherMutex;
   std::map<std::pair<const LoadedModel*, int>, SharedBatcher> batchers;
-#endif
 };
 
 struct ComputeHandle {
@@ -106,11 +91,9 @@ struct ComputeHandle {
   int numInputChannels;
   int numInputGlobalChannels;
   int numInputMetaChannels;
-#ifndef KMX_USE_ORACLE
   kmx_handle* handle = NULL;
   kmx_batcher* batcher = NULL;  // shared (ComputeContext::batchers); NULL when katamxBatcher is off
   int gpuIdx = 0;
-#endif
 };
 
 struct InputBuffers {
@@ -135,26 +118,18 @@ struct InputBuffers {
 
 // ---------------------------------------------------------------------------------------------
 void NeuralNet::globalInitialize() {
-#ifndef KMX_USE_ORACLE
   check(kmx_global_init(), "global init");
-#endif
 }
 void NeuralNet::globalCleanup() {
-#ifndef KMX_USE_ORACLE
   kmx_global_cleanup();
-#endif
 }
 void NeuralNet::printDevices() {
-#ifdef KMX_USE_ORACLE
-  cout << "katamx CPU oracle (no devices)" << endl;
-#else
   int n = kmx_device_count();
   for(int i = 0; i < n; i++) {
     char name[256];
     if(kmx_device_name(i, name, sizeof(name)) == KMX_OK)
       cout << "Found HIP device " << i << ": " << name << endl;
   }
-#endif
 }
 
 LoadedModel* NeuralNet::loadModelFile(const string& file, const string& expectedSha256) {
@@ -202,7 +177,6 @@ ComputeContext* NeuralNet::createComputeContext(
     else if(p != "auto" && p != "") throw StringError("KATAMX_PRECISION must be one of fp16, bf16, auto");
   }
   context->precisionMode = precisionMode;
-#ifndef KMX_USE_ORACLE
   if(cfg.contains("katamxBatcher")) context->useBatcher = cfg.getBool("katamxBatcher");
   else if(const char* e = getenv("KATAMX_BATCHER")) context->useBatcher = atoi(e) != 0;
   if(cfg.contains("katamxBatcherInFlight")) context->batcherInFlight = cfg.getInt("katamxBatcherInFlight", 1, 8);
@@ -210,17 +184,12 @@ ComputeContext* NeuralNet::createComputeContext(
   check(
     kmx_context_create(gpuIdxs.data(), (int)gpuIdxs.size(), nnXLen, nnYLen, precisionMode, &context->ctx),
     "creating compute context");
-#else
-  (void)gpuIdxs;
-#endif
   return context.release();
 }
 void NeuralNet::freeComputeContext(ComputeContext* computeContext) {
   if(computeContext == NULL)
     return;
-#ifndef KMX_USE_ORACLE
   kmx_context_free(computeContext->ctx);
-#endif
   delete computeContext;
 }
 
@@ -242,7 +211,6 @@ ComputeHandle* NeuralNet::createComputeHandle(
   handle->numInputChannels = loadedModel->modelDesc.numInputChannels;
   handle->numInputGlobalChannels = loadedModel->modelDesc.numInputGlobalChannels;
   handle->numInputMetaChannels = loadedModel->modelDesc.numInputMetaChannels;
-#ifndef KMX_USE_ORACLE
   handle->gpuIdx = gpuIdxForThisThread;
   if(context->useBatcher) {
     std::lock_guard<std::mutex> lock(context->batcherMutex);
@@ -265,23 +233,14 @@ ComputeHandle* NeuralNet::createComputeHandle(
     int prec = handle->batcher != NULL ? kmx_batcher_precision(handle->batcher) : kmx_handle_precision(handle->handle);
     logger->write(
       "katamx (HIP/gfx950) backend thread " + Global::intToString(serverThreadIdx) + ": device " +
-      Global::intToString(gpuIdxForThisThread) + " precision " +
-      (prec == KMX_PREC_FP32 ? "fp32" : prec == KMX_PREC_FP16 ? "fp16" : "bf16") + (handle->batcher != NULL ? " (shared leaf batcher)" : "") +
-      " model " + loadedModel->modelDesc.name);
+      Global::intToString(gpuIdxForThisThread) + " [" + deviceLabel(gpuIdxForThisThread) + "] precision " + precisionName(prec) +
+      (handle->batcher != NULL ? " (shared leaf batcher)" : "") + " model " + loadedModel->modelDesc.name);
   }
-#else
-  (void)maxBatchSize;
-  (void)requireExactNNLen;
-  (void)gpuIdxForThisThread;
-  if(logger != NULL)
-    logger->write("katamx CPU ORACLE backend thread " + Global::intToString(serverThreadIdx) + " model " + loadedModel->modelDesc.name);
-#endif
   return handle.release();
 }
 void NeuralNet::freeComputeHandle(ComputeHandle* handle) {
   if(handle == NULL)
     return;
-#ifndef KMX_USE_ORACLE
   if(handle->batcher != NULL) {
     ComputeContext* context = const_cast<ComputeContext*>(handle->context);
     std::lock_guard<std::mutex> lock(context->batcherMutex);
@@ -293,17 +252,11 @@ void NeuralNet::freeComputeHandle(ComputeHandle* handle) {
   }
   else
     kmx_handle_free(handle->handle);
-#endif
   delete handle;
 }
 
 bool NeuralNet::isUsingFP16(const ComputeHandle* handle) {
-#ifdef KMX_USE_ORACLE
-  (void)handle;
-  return false;
-#else
   return (handle->batcher != NULL ? kmx_batcher_precision(handle->batcher) : kmx_handle_precision(handle->handle)) != KMX_PREC_FP32;
-#endif
 }
 bool NeuralNet::setIsWarmup(const ComputeHandle* handle, bool isWarmup) {
   (void)handle;
@@ -376,14 +329,6 @@ void NeuralNet::getOutput(
     buffers->outOwnership[row] = out->whiteOwnerMap;  // NULL => skipped
   }
 
-#ifdef KMX_USE_ORACLE
-  check(
-    okmx_eval_meta(
-      handle->loadedModel->model, nnXLen, nnYLen, batchSize, buffers->rowSpatial.data(), buffers->rowGlobal.data(),
-      handle->numInputMetaChannels > 0 ? buffers->rowMeta.data() : NULL, buffers->symmetry.data(), buffers->policyOptimism.data(), buffers->outPolicy.data(), buffers->value.data(),
-      buffers->score.data(), buffers->outOwnership.data(), 1),
-    "evaluating batch");
-#else
   if(handle->batcher != NULL) {
     // the rows join whatever batch is filling (other server threads' rows included); every ticket is waited for even after a
     // failure, so that no staging slot stays occupied
@@ -421,7 +366,6 @@ void NeuralNet::getOutput(
         buffers->policyOptimism.data(), buffers->outPolicy.data(), buffers->value.data(), buffers->score.data(),
         buffers->outOwnership.data()),
       "evaluating batch");
-#endif
 
   // Scalars -> NNOutput, exactly the field mapping of eigenbackend.cpp:2569-2626.
   const int modelVersion = handle->modelVersion;
@@ -453,11 +397,7 @@ struct KatamxLeaf::Port {
   const ComputeContext* context = NULL;
   const LoadedModel* loadedModel = NULL;
   int numInputMetaChannels = 0;
-#ifdef KMX_USE_ORACLE
-  std::atomic<uint64_t> rows{0};
-#else
   kmx_batcher* batcher = NULL;
-#endif
 };
 
 KatamxLeaf::Port* KatamxLeaf::openPort(
@@ -467,64 +407,35 @@ KatamxLeaf::Port* KatamxLeaf::openPort(
   port->context = context;
   port->loadedModel = loadedModel;
   port->numInputMetaChannels = loadedModel->modelDesc.numInputMetaChannels;
-#ifdef KMX_USE_ORACLE
-  (void)maxBatchSize;
-  (void)batchesInFlight;
-  if(logger != NULL)
-    logger->write("katamx CPU ORACLE leaf port " + Global::intToString(gpuIdx) + " model " + loadedModel->modelDesc.name);
-#else
   check(
     kmx_batcher_create(context->ctx, loadedModel->model, maxBatchSize, batchesInFlight, gpuIdx, &port->batcher),
     "creating the leaf batcher");
   if(logger != NULL) {
-    int prec = kmx_batcher_precision(port->batcher);
     logger->write(
-      "katamx (HIP/gfx950) leaf port: device " + Global::intToString(gpuIdx < 0 ? 0 : gpuIdx) + " precision " +
-      (prec == KMX_PREC_FP16 ? "fp16" : "bf16") + " batch " + Global::intToString(maxBatchSize) + " model " + loadedModel->modelDesc.name);
+      "katamx (HIP/gfx950) leaf port: device " + Global::intToString(gpuIdx < 0 ? 0 : gpuIdx) + " [" + deviceLabel(gpuIdx) + "] precision " +
+      precisionName(kmx_batcher_precision(port->batcher)) + " batch " + Global::intToString(maxBatchSize) + " model " + loadedModel->modelDesc.name);
   }
-#endif
   return port.release();
 }
 void KatamxLeaf::closePort(Port* port) {
   if(port == NULL)
     return;
-#ifndef KMX_USE_ORACLE
   kmx_batcher_free(port->batcher);
-#endif
   delete port;
 }
 bool KatamxLeaf::isUsingFP16(const Port* port) {
-#ifdef KMX_USE_ORACLE
-  (void)port;
-  return false;
-#else
   return kmx_batcher_precision(port->batcher) != KMX_PREC_FP32;
-#endif
 }
 uint64_t KatamxLeaf::submit(
   Port* port, const float* rowSpatial, const float* rowGlobal, const float* rowMeta, int symmetry, float policyOptimism,
   float* outPolicy, float* outValue, float* outScore, float* outOwnership
 ) {
   testAssert((rowMeta != NULL) == (port->numInputMetaChannels > 0));
-#ifdef KMX_USE_ORACLE
-  const float* sp[1] = {rowSpatial};
-  const float* gl[1] = {rowGlobal};
-  const float* mt[1] = {rowMeta};
-  float* pol[1] = {outPolicy};
-  float* own[1] = {outOwnership};
-  check(
-    okmx_eval_meta(
-      port->loadedModel->model, port->context->nnXLen, port->context->nnYLen, 1, sp, gl, rowMeta != NULL ? mt : NULL, &symmetry,
-      &policyOptimism, pol, outValue, outScore, own, 1),
-    "evaluating a leaf");
-  return port->rows.fetch_add(1) + 1;
-#else
   uint64_t ticket = 0;
   check(
     kmx_batcher_submit(port->batcher, rowSpatial, rowGlobal, rowMeta, symmetry, policyOptimism, outPolicy, outValue, outScore, outOwnership, &ticket),
     "submitting a leaf");
   return ticket;
-#endif
 }
 uint64_t KatamxLeaf::submitPacked(
   Port* port, const uint8_t* rowPacked, int numPlanes, const float* rowGlobal, const float* rowMeta, int symmetry, float policyOptimism,
@@ -532,37 +443,17 @@ uint64_t KatamxLeaf::submitPacked(
 ) {
   testAssert((rowMeta != NULL) == (port->numInputMetaChannels > 0));
   testAssert(numPlanes == port->loadedModel->modelDesc.numInputChannels);
-#ifdef KMX_USE_ORACLE
-  // the oracle knows fp32 rows only: expand the bits (what the device's input stage does, misc_kernels.hip inputExpand)
-  const int cells = port->context->nnXLen * port->context->nnYLen, planeBytes = (cells + 7) / 8;
-  std::vector<float> row((size_t)cells * numPlanes);
-  for(int pos = 0; pos < cells; pos++)
-    for(int p = 0; p < numPlanes; p++)
-      row[(size_t)pos * numPlanes + p] = (float)((rowPacked[(size_t)p * planeBytes + (pos >> 3)] >> (7 - (pos & 7))) & 1);
-  return submit(port, row.data(), rowGlobal, rowMeta, symmetry, policyOptimism, outPolicy, outValue, outScore, outOwnership);
-#else
   uint64_t ticket = 0;
   check(
     kmx_batcher_submit_packed(port->batcher, rowPacked, rowGlobal, rowMeta, symmetry, policyOptimism, outPolicy, outValue, outScore, outOwnership, &ticket),
     "submitting a leaf");
   return ticket;
-#endif
 }
 void KatamxLeaf::wait(Port* port, uint64_t ticket) {
-#ifdef KMX_USE_ORACLE
-  (void)port;
-  (void)ticket;
-#else
   check(kmx_batcher_wait(port->batcher, ticket), "evaluating a leaf");
-#endif
 }
 void KatamxLeaf::stats(Port* port, uint64_t& rows, uint64_t& batches) {
-#ifdef KMX_USE_ORACLE
-  rows = port->rows.load();
-  batches = rows;
-#else
   check(kmx_batcher_stats(port->batcher, &rows, &batches), "reading the leaf batcher's counters");
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -612,11 +503,7 @@ static kmx_matmul_desc matmulDesc(const MatMulLayerDesc& d) {
   m.weights = d.weights.data();
   return m;
 }
-#ifdef KMX_USE_ORACLE
-static bool precisionSupported(bool useFP16, int& mode) { mode = KMX_PREC_FP32; return !useFP16; }
-#else
 static bool precisionSupported(bool useFP16, int& mode) { mode = useFP16 ? KMX_PREC_AUTO : KMX_PREC_FP32; return true; }
-#endif
 static bool hookResult(int status, const char* what) {
   if(status == KMX_ERR_UNSUPPORTED)
     return false;
@@ -634,11 +521,7 @@ bool NeuralNet::testEvaluateConv(
   kmx_conv_desc c = convDesc(*desc);
   vector<float> in = toNHWC(inputBuffer, batchSize, desc->inChannels, nnYLen, nnXLen, useNHWC);
   vector<float> out((size_t)batchSize * nnXLen * nnYLen * desc->outChannels);
-#ifdef KMX_USE_ORACLE
-  int status = okmx_test_conv(&c, batchSize, nnXLen, nnYLen, in.data(), out.data());
-#else
   int status = kmx_test_conv(&c, batchSize, nnXLen, nnYLen, mode, in.data(), out.data());
-#endif
   if(!hookResult(status, "testEvaluateConv"))
     return false;
   outputBuffer = fromNHWC(out, batchSize, desc->outChannels, nnYLen, nnXLen, useNHWC);
@@ -655,11 +538,7 @@ bool NeuralNet::testEvaluateBatchNorm(
   kmx_bnact_desc b = bnDesc(*desc, ACTIVATION_IDENTITY);
   vector<float> in = toNHWC(inputBuffer, batchSize, desc->numChannels, nnYLen, nnXLen, useNHWC);
   vector<float> out(in.size());
-#ifdef KMX_USE_ORACLE
-  int status = okmx_test_bnact(&b, batchSize, nnXLen, nnYLen, in.data(), maskBuffer.data(), out.data());
-#else
   int status = kmx_test_bnact(&b, batchSize, nnXLen, nnYLen, mode, in.data(), maskBuffer.data(), out.data());
-#endif
   if(!hookResult(status, "testEvaluateBatchNorm"))
     return false;
   outputBuffer = fromNHWC(out, batchSize, desc->numChannels, nnYLen, nnXLen, useNHWC);
@@ -681,11 +560,7 @@ bool NeuralNet::testEvaluateResidualBlock(
   const int c = desc->preBN.numChannels;
   vector<float> in = toNHWC(inputBuffer, batchSize, c, nnYLen, nnXLen, useNHWC);
   vector<float> out(in.size());
-#ifdef KMX_USE_ORACLE
-  int status = okmx_test_resblock(&r, batchSize, nnXLen, nnYLen, in.data(), maskBuffer.data(), out.data());
-#else
   int status = kmx_test_resblock(&r, batchSize, nnXLen, nnYLen, mode, in.data(), maskBuffer.data(), out.data());
-#endif
   if(!hookResult(status, "testEvaluateResidualBlock"))
     return false;
   outputBuffer = fromNHWC(out, batchSize, c, nnYLen, nnXLen, useNHWC);
@@ -710,11 +585,7 @@ bool NeuralNet::testEvaluateGlobalPoolingResidualBlock(
   const int c = desc->preBN.numChannels;
   vector<float> in = toNHWC(inputBuffer, batchSize, c, nnYLen, nnXLen, useNHWC);
   vector<float> out(in.size());
-#ifdef KMX_USE_ORACLE
-  int status = okmx_test_gpoolblock(&g, batchSize, nnXLen, nnYLen, in.data(), maskBuffer.data(), out.data());
-#else
   int status = kmx_test_gpoolblock(&g, batchSize, nnXLen, nnYLen, mode, in.data(), maskBuffer.data(), out.data());
-#endif
   if(!hookResult(status, "testEvaluateGlobalPoolingResidualBlock"))
     return false;
   outputBuffer = fromNHWC(out, batchSize, c, nnYLen, nnXLen, useNHWC);

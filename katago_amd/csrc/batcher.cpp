@@ -47,10 +47,11 @@ class Batcher {
     : maxBatch_(maxBatch), maxInFlight_(maxInFlight) {
     S_ = nnXLen * nnYLen;
     // Seal at the device's granule. The convolutions give a board to a work-group and a work-group to a CU: a pass over 430 boards
-    // on 256 CUs costs what a pass over 512 does. A filling batch therefore counts as FULL at (a multiple of) the CU count and
-    // goes behind the running one at once, instead of growing to an odd size while the device is busy - measured with the
-    // reference's benchmark at 1024 leaves in flight: avg batch 432 -> 256, 34.8 k -> see profiles/r03_steps/fibers.txt.
-    // KMX_BATCH_QUANTUM overrides (0 = off: only max_batch_size seals).
+    // on 256 CUs costs what a pass over 512 does. A filling batch therefore counts as FULL at the largest MULTIPLE of the CU count
+    // that max_batch_size allows (256 for 256..511, 512 for 512..767, ...; max_batch_size itself below one granule) and goes behind
+    // the running one at once, instead of growing to an odd size while the device is busy - measured with the reference's
+    // benchmark at 1024 leaves in flight: avg batch 432 -> 256, 31.0 k -> 37.5 k nnEvals/s (profiles/r03_steps/fibers.txt).
+    // KMX_BATCH_QUANTUM overrides the granule (0 = off: only max_batch_size seals). include/katamx.h states this contract.
     {
       int q = -1;
       if(const char* e = getenv("KMX_BATCH_QUANTUM")) q = atoi(e);
@@ -58,9 +59,11 @@ class Batcher {
         hipDeviceProp_t prop;
         q = hipGetDeviceProperties(&prop, device < 0 ? 0 : device) == hipSuccess ? prop.multiProcessorCount : 0;
       }
-      sealAt_ = q > 0 && q < maxBatch ? q : maxBatch;
+      sealAt_ = q > 0 && q < maxBatch ? maxBatch / q * q : maxBatch;
       if(const char* e = getenv("KMX_BATCH_LINGER_US")) lingerUs_ = atoi(e) < 0 ? 0 : atoi(e);
     }
+    maxBatch = sealAt_;  // no batch ever holds more rows: engines and staging are sized for what can be used
+    maxBatch_ = sealAt_;
     for(int i = 0; i < numSlots; i++) slots_.emplace_back();
     for(Slot& s : slots_) {
       s.eng.reset(new Engine(model, nnXLen, nnYLen, maxBatch, dtype, device));
@@ -310,14 +313,31 @@ class Batcher {
       cvComplete_.wait(l, [&] { return !inflight_.empty() || (closing_ && running_ == 0); });
       if(inflight_.empty()) return;
       // Batches finish in launch order when they are large (each fills the device); small ones side by side (SMALL_ROWS) need not:
-      // a batch behind the oldest that has already finished is delivered first instead of waiting for its elder.
+      // a batch behind the oldest that has already finished is delivered first instead of waiting for its elder. The streams are
+      // queried OUTSIDE the lock (every submitter and the dispatcher need it; a query is a runtime call), on a snapshot of the
+      // batches in flight; while none of several has finished the thread naps 30 us (or until the dispatcher hands over another
+      // batch) and looks again, instead of blocking on the oldest while a younger one completes.
       size_t pick = 0;
       if(inflight_.size() > 1) {
-        for(size_t i = 0; i < inflight_.size(); i++) {
-          Slot& c = slots_[inflight_[i]];
-          bool done = false;
-          try { done = c.error == KMX_OK && c.eng->idle(); } catch(...) { done = false; }
-          if(done) { pick = i; break; }
+        bool found = false;
+        while(!found) {
+          const std::vector<int> snap(inflight_.begin(), inflight_.end());
+          l.unlock();
+          int doneSlot = -1;
+          for(int si : snap) {
+            Slot& c = slots_[si];  // RUNNING: only this thread moves it on
+            bool done = false;
+            try { done = c.error != KMX_OK || c.eng->idle(); } catch(...) { done = true; }  // a failed batch is delivered (as failed) at once
+            if(done) { doneSlot = si; break; }
+          }
+          l.lock();
+          if(doneSlot >= 0) {
+            for(size_t i = 0; i < inflight_.size(); i++)
+              if(inflight_[i] == doneSlot) pick = i;
+            found = true;
+          }
+          else if(inflight_.size() <= 1) { pick = 0; found = true; }  // (cannot shrink: only this thread removes; kept for clarity)
+          else cvComplete_.wait_for(l, std::chrono::microseconds(30));
         }
       }
       const int si = inflight_[pick];

@@ -72,7 +72,7 @@ def device_rate(model, batch):
 
 
 def test_analysis_engine_b28_batch_512(tmp_path):
-    binary = ref_binary("katago_hipx")
+    binary = ref_binary("katago_hip")
     model = str(tmp_path / "b28.bin.gz")
     modelgen.write_model(model, "b28c512nbt", seed=28)
     dev = device_rate(model, 512)  # host rows in, host rows out (kmx_eval): what a caller of the boundary can get at best

@@ -1,6 +1,6 @@
 """-m gpu: the persistent leaf batcher behind the C ABI (kmx_batcher_*, SURVEY 8 row a4 / north_star) on the MI355X.
   * rows submitted concurrently from many threads come back bit-identical to kmx_eval on the same rows, whatever batch they land in;
-  * the reference's own `benchmark` (its search, its NNEvaluator, its server threads) on katago_hip with katamxBatcher = true:
+  * the reference's own `benchmark` (its search, its NNEvaluator, its server threads) on katago_hip_refeval with katamxBatcher = true:
     several server threads feed one batcher; the rate is recorded next to the plain handle's (profiles/)."""
 import os
 import re
@@ -89,7 +89,7 @@ def test_reference_benchmark_through_the_batcher(tmp_path):
                                  ("batcher, 4 server threads", "numNNServerThreadsPerModel = 4\nkatamxBatcher = true\nkatamxBatcherInFlight = 2\n", "256,512,1024")):
         cfg = tmp_path / ("bench_%d.cfg" % len(lines))
         cfg.write_text(h.BENCH_CFG + "nnMaxBatchSize = 256\n" + extra)
-        rc, out = h.run("benchmark", "-model", model, "-config", str(cfg), "-v", "8000", "-t", threads, "-boardsize", "19", "-n", "3", timeout=900)
+        rc, out = h.run("benchmark", "-model", model, "-config", str(cfg), "-v", "8000", "-t", threads, "-boardsize", "19", "-n", "3", timeout=900, binary="katago_hip_refeval")
         assert rc == 0, out[-3000:]
         for l in out.replace("\r", "\n").splitlines():
             m = re.search(r"numSearchThreads = +(\d+):.*nnEvals/s = ([\d.]+).*avgBatchSize = ([\d.]+)", l)

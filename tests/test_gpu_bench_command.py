@@ -58,7 +58,7 @@ def test_driver_command_exits_zero_with_roofline_and_cpu_baseline():
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     # the callers' side of the same box, outside the timed region
     assert d["host_rows_through_batcher_per_s"] > 0.5 * d["value"]
-    if os.path.exists(os.path.join(REPO, "oracle", "_ref", "katago_hipx")):
+    if os.path.exists(os.path.join(REPO, "oracle", "_ref", "katago_hip")):
         assert d["reference_benchmark_nn_evals_per_s"] > 0.5 * d["value"], d
         assert d["selfplay_nn_rows_per_s"] > 1000 and d["selfplay_games_per_hour_250_move_games_derived"] > 0 and "cut after" in d["selfplay"], d
 

@@ -33,7 +33,7 @@ def benchmark(binary, model, cfg, threads, visits, leaves, n=5):
 
 
 def test_search_driven_rate_reaches_the_device_rate(tmp_path):
-    binary = ref_binary("katago_hipx")
+    binary = ref_binary("katago_hip")
     model = str(tmp_path / "b18.bin.gz")
     modelgen.write_model(model, "b18c384nbt", seed=7)
     cfg = tmp_path / "bench.cfg"

@@ -1,5 +1,6 @@
-"""-m gpu: the reference's OWN test commands running on the HIP backend (oracle/_ref/katago_hip = unmodified
-reference host code + integration/katamxbackend.cpp + libkatamx.so)."""
+"""-m gpu: the reference's OWN test commands running on the HIP backend (oracle/_ref/katago_hip = unmodified reference host
+code with this repo's NNEvaluator + featuriser in place of neuralnet/nneval.cpp, + integration/katamxbackend.cpp + libkatamx.so:
+the default binding build since round 4; katago_hip_refeval keeps the reference's own evaluator)."""
 import os
 import re
 import subprocess
@@ -12,8 +13,8 @@ pytestmark = pytest.mark.gpu
 G170 = os.path.join(REPO, "oracle", "_ref", "models", "g170-b6c96-s175395328-d26788732.bin.gz")
 
 
-def run(*args, timeout=600):
-    b = ref_binary("katago_hip")
+def run(*args, timeout=600, binary="katago_hip"):
+    b = ref_binary(binary)
     r = subprocess.run([b] + list(args), capture_output=True, text=True, timeout=timeout, cwd=os.path.dirname(b))
     return r.returncode, r.stdout + r.stderr
 
@@ -31,7 +32,7 @@ def test_tiny_model_on_hip(tmp_path):
     """cpp/tests/tinymodel.cpp through the reference NNEvaluator (featurisation, batching threads, post-processing)."""
     rc, out = run("runtinynntests", str(tmp_path), "1.0")
     assert rc == 0 and "Tiny net sanity check complete" in out, out[-3000:]
-    assert "katamx (HIP/gfx950) backend" in out
+    assert "katamx (HIP/gfx950)" in out and "CPU oracle" not in out
 
 
 def test_real_net_tiny_board_golden_on_hip():
@@ -97,7 +98,7 @@ def test_reference_benchmark_command_on_hip(tmp_path):
     cfg.write_text(BENCH_CFG)
     rc, out = run("benchmark", "-model", G170, "-config", str(cfg), "-v", "200", "-t", "8,32", "-boardsize", "9", "-n", "4")
     assert rc == 0, out[-3000:]
-    assert "katamx (HIP/gfx950) backend" in out
+    assert "katamx (HIP/gfx950)" in out and "CPU oracle" not in out
     rates = [float(x) for x in re.findall(r"nnEvals/s = ([\d.]+)", out)]
     assert len(rates) >= 2 and all(r > 0 for r in rates), out[-2000:]
     keep = os.path.join(REPO, "gpurun_out")

@@ -31,7 +31,7 @@ def test_selfplay_writes_shards_on_hip(tmp_path):
                        capture_output=True, text=True, timeout=900, cwd=d)
     log = p.stdout + p.stderr
     assert p.returncode == 0 and "All cleaned up, quitting" in log, log[-3000:]
-    assert "katamx (HIP/gfx950) backend" in log
+    assert "katamx (HIP/gfx950)" in log and "CPU oracle" not in log
     rows = int(log.split("Final data rows: ")[1].split()[0])
     nn_rows = int(log.split("Final NN rows: ")[1].split()[0])
     games = int(log.split("Final games finished: ")[1].split()[0])
@@ -59,7 +59,7 @@ def test_selfplay_rate_b18_19x19_on_hip(tmp_path):
     is the rate AT THAT SETTING together with the NN rows per second it implies - not a full-length self-play figure."""
     from katago_amd import modelgen
 
-    b = ref_binary("katago_hip")
+    b = ref_binary("katago_hip_refeval")  # the reference's own evaluator: its server threads are what this test varies
     d = str(tmp_path)
     os.makedirs(os.path.join(d, "models"))
     modelgen.write_model(os.path.join(d, "models", "b18c384nbt-s1-d1.bin.gz"), "b18c384nbt", seed=7)
@@ -94,7 +94,7 @@ def test_selfplay_rate_with_leaves_in_flight_per_game(tmp_path):
     evaluator (2.4 ms per pass whatever the batch is below 32 rows); VERDICT asked for >= 2.5 k."""
     from katago_amd import modelgen
 
-    b = ref_binary("katago_hipx")
+    b = ref_binary("katago_hip")
     d = str(tmp_path)
     os.makedirs(os.path.join(d, "models"))
     modelgen.write_model(os.path.join(d, "models", "b18c384nbt-s1-d1.bin.gz"), "b18c384nbt", seed=7)
@@ -129,7 +129,7 @@ def test_selfplay_rate_with_leaves_in_flight_per_game(tmp_path):
 
 
 def test_mixed_board_sizes_b18_own_evaluator_writes_valid_shards(tmp_path):
-    """BASELINE configs[4] through the PRODUCT path: `katago_hipx selfplay` (this repo's NNEvaluator + featuriser + fibers over the leaf
+    """BASELINE configs[4] through the PRODUCT path: `katago_hip selfplay` (this repo's NNEvaluator + featuriser + fibers over the leaf
     batcher) on b18c384nbt with the reference's production self-play settings (tools/selfplay_cfg.py = selfplay8mainb18.cfg), board
     sizes 9 / 13 / 19 mixed in ONE 19x19 buffer (selfplay8mainb18.cfg:76-77 mixes 13 sizes the same way), 8 games x 8 leaves in
     flight, ownership + score targets, .npz shards. Every row the evaluator submits is also featurised by the reference's
@@ -141,20 +141,21 @@ def test_mixed_board_sizes_b18_own_evaluator_writes_valid_shards(tmp_path):
     import selfplay_cfg
     from katago_amd import modelgen
 
-    b = ref_binary("katago_hipx")
+    b = ref_binary("katago_hip")
     d = str(tmp_path)
     os.makedirs(os.path.join(d, "models"))
     modelgen.write_model(os.path.join(d, "models", "b18c384nbt-s1-d1.bin.gz"), "b18c384nbt", seed=7)
     cfg = selfplay_cfg.write(os.path.join(d, "mixed.cfg"), numGameThreads=8, numSearchThreads=8, nnMaxBatchSize=64, maxVisits=48,
                              cheapSearchVisits=24, reducedVisitsMin=24, estimateLeadVisits=6, maxMovesPerGame=50, logGamesEvery=1000,
                              nnCacheSizePowerOfTwo=18, nnMutexPoolSizePowerOfTwo=14, maxRowsPerTrainFile=400, firstFileRandMinProp=1.0,
-                             switchNetsMidGame="false", **selfplay_cfg.MIXED_9_13_19)
+                             switchNetsMidGame="false", handicapAsymmetricPlayoutProb=0.0, normalAsymmetricPlayoutProb=0.0,  # (a visit count divided by up to 8 must stay >= 5)
+                             **selfplay_cfg.MIXED_9_13_19)
     env = dict(os.environ, KATAMX_LEAVES_PER_THREAD="8", KATAMX_FEATURES="check")
     p = subprocess.run([b, "selfplay", "-config", cfg, "-models-dir", os.path.join(d, "models"), "-output-dir", os.path.join(d, "out"),
                         "-max-games-total", "30"], capture_output=True, text=True, timeout=900, cwd=d, env=env)
     log = p.stdout + p.stderr
     assert p.returncode == 0 and "All cleaned up, quitting" in log, log[-3000:]
-    assert "katamx (HIP/gfx950) backend" in log
+    assert "katamx (HIP/gfx950)" in log and "CPU oracle" not in log
     rows = int(log.split("Final data rows: ")[1].split()[0])
     nn_rows = int(log.split("Final NN rows: ")[1].split()[0])
     batches = int(log.split("Final NN batches: ")[1].split()[0])
@@ -162,7 +163,7 @@ def test_mixed_board_sizes_b18_own_evaluator_writes_valid_shards(tmp_path):
     secs = float(log.split("Total selfplay runtime (seconds): ")[1].split()[0])
     assert games >= 30 and rows > 0 and nn_rows > 20 * games
     per_size = shard_checks.check_shards(shard_checks.shard_files(os.path.join(d, "out")), 19, (9, 13, 19), rows)
-    line = ("configs[4]: katago_hipx selfplay b18c384nbt, bSizes 9,13,19 in a 19x19 buffer, 8 games x 8 leaves, 48/24 visits, <=50 moves, "
+    line = ("configs[4]: katago_hip selfplay b18c384nbt, bSizes 9,13,19 in a 19x19 buffer, 8 games x 8 leaves, 48/24 visits, <=50 moves, "
             "KATAMX_FEATURES=check: %d games, %d training rows (by board size %s), %d NN rows in %d batches (avg %.1f), %.1f s = %.0f NN rows/s"
             % (games, rows, per_size, nn_rows, batches, nn_rows / max(batches, 1), secs, nn_rows / secs))
     print(line)

@@ -182,7 +182,8 @@ def test_mixed_board_sizes_in_one_buffer_cpu_twin(tmp_path):
     cfg = selfplay_cfg.write(os.path.join(d, "mixed.cfg"), numGameThreads=4, numSearchThreads=2, nnMaxBatchSize=8, maxVisits=6,
                              cheapSearchVisits=3, reducedVisitsMin=3, estimateLeadVisits=2, maxMovesPerGame=24, logGamesEvery=1000,
                              nnCacheSizePowerOfTwo=14, nnMutexPoolSizePowerOfTwo=10, maxRowsPerTrainFile=60, firstFileRandMinProp=1.0,
-                             switchNetsMidGame="false", **selfplay_cfg.MIXED_9_13_19)
+                             switchNetsMidGame="false", handicapAsymmetricPlayoutProb=0.0, normalAsymmetricPlayoutProb=0.0,  # (a visit count divided by up to 8 must stay >= 5)
+                             **selfplay_cfg.MIXED_9_13_19)
     env = dict(os.environ, KATAMX_FEATURES="check", KATAMX_LEAVES_PER_THREAD="2")
     p = subprocess.run([bx, "selfplay", "-config", cfg, "-models-dir", os.path.join(d, "models"), "-output-dir", os.path.join(d, "out"),
                         "-max-games-total", "24"], capture_output=True, text=True, timeout=900, cwd=d, env=env)
