@@ -288,7 +288,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # replicas only, no collective on the data path (north_star: "no RCCL needed"): the bookkeeping of the measurement - a barrier,
+        # the slowest rank's time, the total row count - goes over gloo on CPU tensors; nothing in this process initialises RCCL
+        dist.init_process_group("gloo")
 
     traffic = None
     if args.pmc and rank == 0 and world == 1:
@@ -358,7 +360,7 @@ def main():
         handle.sync()
         torch.cuda.synchronize()
         profiled_elapsed = (time.perf_counter() - t1) / prof_steps * args.steps
-    total_rows, elapsed = replicas.whole_job(args.steps * B, elapsed, torch.device("cuda", local_rank))
+    total_rows, elapsed = replicas.whole_job(args.steps * B, elapsed)
 
     assert torch.isfinite(d_pol).all() and torch.isfinite(d_val).all(), "non-finite outputs"
 

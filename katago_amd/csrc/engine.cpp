@@ -215,6 +215,9 @@ void Engine::construct(const ModelDesc& model) {
 Engine::~Engine() { destroy(); }
 
 void Engine::destroy() noexcept {
+  // (the thread that frees a handle or a batcher need not be one that ever used it: with one port per GPU in one process the
+  // evaluator's owner tears all of them down - found by the dry run on 8 fake devices, tests/test_schedule_dryrun.py)
+  (void)hipSetDevice(device_);
   if(stream_) (void)hipStreamSynchronize(stream_);
   dropGraphs();
   for(const Pending& p : pending_) {

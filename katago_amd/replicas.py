@@ -1,7 +1,8 @@
 """Multi-GPU = independent replicas: one process per GPU, every rank evaluates its own rows, there is
 NO collective on the data path. This mirrors the reference's only multi-GPU mode — one NN server thread per GPU pulling
 from a shared queue (cpp/neuralnet/nneval.cpp:399-407, gpuIdxByServerThread) — with processes instead of threads.
-The only communication is the bookkeeping of a measurement: a barrier, the slowest rank's time, the total row count."""
+The only communication is the bookkeeping of a measurement: a barrier, the slowest rank's time, the total row count - over
+whatever backend the caller initialised torch.distributed with; bench.py uses gloo (CPU tensors): no RCCL anywhere."""
 import torch
 import torch.distributed as dist
 

@@ -170,6 +170,49 @@ def test_two_devices_in_one_process(fake_so, tmp_path):
     assert per_dev[0] > 100 and per_dev[1] > 100, per_dev  # (how the batchers cut their rows into batches depends on timing)
 
 
+def test_eight_devices_selfplay_in_one_process(fake_so, tmp_path):
+    """The 8-GPU recipe without the node: tools/selfplay_8gpu.sh - `katago_hip selfplay` with the reference's production settings, one
+    leaf port per device chosen by ...DeviceToUseThread0..7 (program/setup.cpp:174-220) - on EIGHT fake devices. The whole host
+    stack runs (search on fibers, this repo's evaluator and featuriser, eight leaf batchers with their dispatcher / completion
+    threads, engines, staging copies); kernels are not executed, so the games are random play. Checked: eight ports on eight
+    devices, no stream / event / launch touched while another device was current (also at tear-down: the main thread frees all
+    eight batchers), every device gets its share of the rows (the evaluator sends a row to the device with the fewest rows in
+    flight), all games finish and the shards hold all three board sizes."""
+    import shard_checks
+    from katago_amd import modelgen
+
+    binary = os.path.join(REPO, "oracle", "_ref", "katago_hip")
+    if not os.path.exists(binary):
+        pytest.skip("oracle/_ref/katago_hip not built (make -C oracle ref needs the reference checkout)")
+    d = str(tmp_path)
+    os.makedirs(os.path.join(d, "models"))
+    modelgen.write_model(os.path.join(d, "models", "b2c32nbt-s1-d1.bin.gz"), "b2c32nbt", seed=3)
+    log_path = os.path.join(d, "fake.log")
+    env = dict(os.environ, KMX_LAUNCH_PREFIX="env LD_PRELOAD=%s KMX_FAKEHIP_DEVICES=8 KMX_FAKEHIP_QUIET=1 KMX_FAKEHIP_LOG=%s" % (fake_so, log_path),
+               KMX_SELFPLAY_ARGS="-max-games-total 48", KATAMX_LEAVES_PER_THREAD="2")
+    extra = ["nnMaxBatchSize=16", "maxVisits=12", "cheapSearchVisits=6", "reducedVisitsMin=6", "estimateLeadVisits=3", "maxMovesPerGame=24",
+             "logGamesEvery=1000", "nnCacheSizePowerOfTwo=14", "nnMutexPoolSizePowerOfTwo=10", "handicapAsymmetricPlayoutProb=0.0",
+             "normalAsymmetricPlayoutProb=0.0", "switchNetsMidGame=false", "maxRowsPerTrainFile=100", "firstFileRandMinProp=1.0",
+             "bSizes=9,13,19", "bSizeRelProbs=1,1,1", "allowRectangleProb=0.0"]
+    p = subprocess.run([os.path.join(REPO, "tools", "selfplay_8gpu.sh"), os.path.join(d, "models"), os.path.join(d, "out"), "3", "2"] + extra,
+                       capture_output=True, text=True, timeout=900, env=env, cwd=d)
+    log = p.stdout + p.stderr
+    assert p.returncode == 0 and "All cleaned up, quitting" in log, log[-3000:]
+    ports = re.findall(r"leaf port: device (\d+) ", log)
+    assert sorted(int(x) for x in ports) == list(range(8)), ports
+    fake = open(log_path).read().splitlines()
+    assert not [l for l in fake if l.startswith("VIOLATION")], [l for l in fake if l.startswith("VIOLATION")][:10]
+    per_dev = {int(m.group(1)): int(m.group(2)) for m in (re.match(r"dev (\d+) launches (\d+)", l) for l in fake) if m}
+    assert sorted(per_dev) == list(range(8)) and min(per_dev.values()) > 1000, per_dev
+    assert max(per_dev.values()) < 1.5 * min(per_dev.values()), per_dev  # least rows in flight first: no device is left behind
+    games = int(log.split("Final games finished: ")[1].split()[0])
+    rows = int(log.split("Final data rows: ")[1].split()[0])
+    assert games >= 48
+    per_size = shard_checks.check_shards(shard_checks.shard_files(os.path.join(d, "out")), 19, (9, 13, 19), rows)
+    assert all(v > 0 for v in per_size.values()), per_size
+    print("8 fake devices: launches per device", per_dev, "training rows by board size", per_size)
+
+
 def test_small_batch_seams_as_one_launch_opt_in(fake_so, tmp_path):
     """KMX_FUSE_SMALL_ROWS=1 (an experiment, off by default): below the fusion threshold the 17 seams of b18c384nbt run as the 4-wave x
     64-cell one-tile seam kernel - one launch of ceil(cells / 64) work-groups each - instead of two convolution launches; at and above
