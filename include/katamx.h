@@ -38,7 +38,7 @@ extern "C" {
  *    + kmx_test_pointwise_pair (unit hook of the fused 1x1 -> 1x1 seam kernel); + kmx_batcher_* (persistent leaf
  *    batcher). Additive over 3.
  * 5: + kmx_batcher_submit_packed (a row that was featurised as bit planes is handed over as such). Additive over 4. */
-#define KMX_ABI_VERSION 5
+#define KMX_ABI_VERSION 6
 
 typedef enum kmx_status {
   KMX_OK = 0,
@@ -343,6 +343,15 @@ int kmx_test_pointwise_pair(int batch, int nn_x_len, int nn_y_len, int precision
                             const float* in_nhwc, const float* resid_nhwc, const float* w1_oi, const float* scale1,
                             const float* bias1, int act1, const float* w2_oi, const float* scale2, const float* bias2, int act2,
                             const float* mask_nhw, int fused, float* out_trunk_raw, float* out_mid_raw, float* out_mid_act);
+/* Unit hook for a chain of 3x3 convolutions 192 -> 192 - the inner residual blocks of a nested-bottleneck block (ResidualBlock::apply,
+ * eigenbackend.cpp:1103-1146, n_conv / 2 times): for k = 0, 2, ..:  t = act(bn_k(conv_k(x))) mask;  r += conv_{k+1}(t);
+ * x = act(bn_{k+1}(r)) mask. n_conv is 2 or 4; x and r are [cells][192] fp32 NHWC (r in: the residual stream), weights
+ * [n_conv][out][in][3][3], scale / bias [n_conv][192]. chained = 0: one launch per convolution; 2 / 4: launches of that many
+ * convolutions with the activated image handed over inside the CU (KMX_ERR_UNSUPPORTED when no such kernel exists for the
+ * activation). Both forms take the one-work-group-per-board shape whatever the batch size. Outputs: r and x after the last block. */
+int kmx_test_conv_chain(int batch, int nn_x_len, int nn_y_len, int precision_mode, int n_conv, const float* x_nhwc, const float* r_nhwc,
+                        const float* w_oihw, const float* scale, const float* bias, int activation, const float* mask_nhw, int chained,
+                        float* out_r, float* out_x);
 /* EXPERIMENTAL unit hooks for the layers of model-v17 transformer trunks that are not convolutions (the reference has no
  * test hook for them; its definitions are TransformerRMSNormLayer / RMSNormLayer, eigenbackend.cpp:867-1034, the attention
  * of TransformerAttentionBlock::apply, :1376-1600, and the SwiGLU of TransformerFFNBlock::apply, :1674-1689). fp32 NHWC

@@ -129,6 +129,7 @@ SIGNATURES = {
     "kmx_bench_mfma": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_double)] * 3),
     "kmx_test_pointwise_pair": (ctypes.c_int, [ctypes.c_int] * 7 + [_FP, _FP, _FP, _FP, _FP, ctypes.c_int, _FP, _FP, _FP, ctypes.c_int, _FP,
                                                ctypes.c_int, _FP, _FP, _FP]),
+    "kmx_test_conv_chain": (ctypes.c_int, [ctypes.c_int] * 5 + [_FP, _FP, _FP, _FP, _FP, ctypes.c_int, _FP, ctypes.c_int, _FP, _FP]),
     "kmx_test_conv": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP]),
     "kmx_test_bnact": (ctypes.c_int, [ctypes.POINTER(BnActDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP, _FP]),
     "kmx_test_resblock": (ctypes.c_int, [ctypes.POINTER(ResBlockDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _FP, _FP, _FP]),

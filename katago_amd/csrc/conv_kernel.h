@@ -67,9 +67,6 @@ enum { ABL_NO_EPILOGUE = 1, ABL_NO_COMPUTE = 2, ABL_NO_DMA = 4, ABL_NO_LDS_READ 
        ABL_NT_DMA = 65536 /* EXPERIMENT: the board image's LDS-DMA requests carry the non-temporal hint (aux = 2): each CU reads its board once */,
        ABL_BATCHED = 131072 /* the round-2 form of a step (A/B): the six fragment reads of a half-step as one batch behind its first MFMA, the step's LDS-DMA requests as one batch between the halves */,
        ABL_PRIO = 8192 /* EXPERIMENT: waves 4-7 (the younger wave of each SIMD, which loses the issue arbitration) run the main loop at s_setprio 1 */,
-       ABL_AHEAD = 262144 /* EXPERIMENT, not an ablation (twelve-wave shape only, cfg 112): the fragments of step s + 1 - both k halves - are
-                             read right after the barrier at the top of step s, which is what publishes slab s + 1, into a second
-                             register set; the two MFMAs of a step then never wait for an LDS read they have just issued */,
        ABL_BP2 = 4096 /* EXPERIMENT, not an ablation: work-group barrier on even taps only (Geom::BP = 2). Carried in this
                          parameter so that the product kernels (ABL = 0) keep their symbols and their code. */ };
 
@@ -599,69 +596,6 @@ __global__ __launch_bounds__(64 * CW * WNW) __attribute__((amdgpu_waves_per_eu(C
   if(ABL & ABL_TIMING) tPrev = __builtin_readcyclecounter();
   const unsigned long long tLoop0 = tPrev;
   int step = 0;
-  constexpr bool AHEAD = (ABL & ABL_AHEAD) != 0;
-  static_assert(!AHEAD || (CW == 12 && ROLES && !ONE && SPREAD && BP == 1), "the read-ahead loop exists for the twelve-wave 3x3 / 5x5 shape");
-  if constexpr(AHEAD) {
-    // Two register sets of (weight, activation) fragments x (k half 0, 1); step s multiplies set s & 1 while set (s + 1) & 1 is filled.
-    // A chunk has an odd number of taps, so the set of a chunk's first tap alternates: the chunk body exists for both parities
-    // (every index below is a constant once the tap loop is unrolled). Same MFMAs per accumulator in the same order - k half 0,
-    // then 1, tap by tap, chunk by chunk - as the loop below: bit-identical.
-    static_assert(NT % 2 == 1, "set parity per chunk assumes an odd number of taps");
-    V8 wfS[2][2][WN];
-    V8 afS[2][2][MT];
-    auto readAll = [&](int P, unsigned imgOff, int t, unsigned slot) {
-      if(ABL & (ABL_NO_LDS_READ | ABL_NO_COMPUTE)) return;
-#pragma unroll
-      for(int kk = 0; kk < 2; kk++) {
-        const unsigned base = wLane[kk] + slot * G::W_BYTES;
-#pragma unroll
-        for(int ct = 0; ct < WN; ct++) wfS[P][kk][ct] = ldsV8(base + ct * 32 * ROWB);
-      }
-      unsigned sTap = (unsigned)(((t / KS - HALO) * W2 + (t % KS - HALO)) * 4) + ((ldsBase + imgOff) >> 4);
-      asm volatile("" : "+s"(sTap));
-#pragma unroll
-      for(int pt = 0; pt < MT; pt++) {
-        const unsigned q4 = aRow4[pt] + sTap;
-        const unsigned addr = (q4 << 4) | ((q4 ^ c40) & 0x30u);
-        afS[P][0][pt] = ldsV8(addr);
-        afS[P][1][pt] = ldsV8(addr ^ 0x20u);
-      }
-    };
-    readAll(0, 0, 0, 0);  // step 0: slab 0 and image 0 were published by the barrier above
-    auto chunkBody = [&](auto cpTag, int chunk) {
-      constexpr int CP = decltype(cpTag)::value;
-      const unsigned curA = (unsigned)(chunk % G::NSA) * G::ACT_BYTES;
-      const unsigned nextA = (unsigned)((chunk + 1) % G::NSA) * G::ACT_BYTES;
-#pragma unroll
-      for(int t = 0; t < NT; t++, step++) {
-        const int P = (CP + t) & 1;
-        waitStep(t);
-        __builtin_amdgcn_s_barrier();  // publishes slab step + 1 (and, at the last tap, the next chunk's image)
-        asm volatile("" ::: "memory");
-        // MFMAs first, the next step's reads behind them: the compiler's own wait before an MFMA drains ALL outstanding LDS reads
-        // (lgkmcnt(0)), so reads issued ahead of these MFMAs would be waited for at once - as it is, that wait only meets the reads
-        // of the previous step, which had its request segment and the barrier to land in
-        if(!(ABL & ABL_NO_COMPUTE)) {
-#pragma unroll
-          for(int kk = 0; kk < 2; kk++)
-#pragma unroll
-            for(int ct = 0; ct < WN; ct++)
-#pragma unroll
-              for(int pt = 0; pt < MT; pt++) acc[ct][pt] = TR::mfma(wfS[P][kk][ct], afS[P][kk][pt], acc[ct][pt]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        readAll(P ^ 1, t + 1 < NT ? curA : nextA, t + 1 < NT ? t + 1 : 0, TAPSLOT ? (unsigned)((t + 1) % G::NSW) : (unsigned)((step + 1) % G::NSW));
-        __builtin_amdgcn_sched_barrier(0);
-        issueStep(chunk, t, step);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    for(int chunk = 0; chunk < nChunks; chunk++) {
-      if(chunk & 1) chunkBody(ActKindTag<1>(), chunk);
-      else chunkBody(ActKindTag<0>(), chunk);
-    }
-  }
-  else
   for(int chunk = 0; chunk < nChunks; chunk++) {
     const unsigned curA = (unsigned)(chunk % G::NSA) * G::ACT_BYTES;
     const unsigned nextA = (unsigned)((chunk + 1) % G::NSA) * G::ACT_BYTES;

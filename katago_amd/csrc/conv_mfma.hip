@@ -34,6 +34,8 @@ using namespace convk;
 // request count suggests: with two MFMAs per wave and step nothing hides the LDS read latency of the fragments any more, and a
 // launch costs ~14 us whatever it does (the 1x1 layers and the small kernels of the same pass take 14-37 us each).
 // KMX_CONV_CW12=0 / 1 overrides the default (on).
+// (Round 4 measured the variant that reads a step's fragments one step ahead, behind the current MFMAs: 25.7 against 23.4 us per launch,
+// 2.47 against 2.31 ms per pass at batch 1 - slower, removed; profiles/r04_steps/call1/small_batch_scan.txt.)
 constexpr bool kCw12Default = true;
 bool cw12Enabled() {
   static const bool on = [] {
@@ -43,18 +45,6 @@ bool cw12Enabled() {
   return on;
 }
 constexpr int CFG_CW12 = 111;
-// EXPERIMENT (off unless KMX_CONV_CW12_AHEAD=1; parity green on the MI355X - 34 layer tests - but not yet timed): the same shape with its fragments read a whole step
-// ahead (conv_kernel.h ABL_AHEAD) - what is left of a twelve-wave step is LDS read latency that its two MFMAs cannot cover
-// (DESIGN.md 4.12). Bit-identical to the other shapes on the CPU emulation (tests/test_kernels_latest_completion.py).
-constexpr int CFG_CW12_AHEAD = 112;
-bool cw12Ahead() {
-  static const bool on = [] {
-    const char* e = getenv("KMX_CONV_CW12_AHEAD");
-    return e != nullptr && e[0] == '1';
-  }();
-  return on;
-}
-
 // EXPERIMENT (off unless KMX_CONV_BP2=1): the 8-wave 3x3 shapes with a work-group barrier on even
 // taps only and a ring of D + 2 slabs. Not yet run on hardware.
 bool evenTapBarriers() {
@@ -72,7 +62,6 @@ hipError_t launchT(int ks, int cfg, const ConvArgs& a, hipStream_t stream) {
     return launchOne<TR, 3, 3, 2, 3, ABL_BP2>(a, stream);
   }
   if(ks == 3 && cfg == CFG_CW12) return launchOne<TR, 3, 1, 1, 2, 0, 12>(a, stream);
-  if(ks == 3 && cfg == CFG_CW12_AHEAD) return launchOne<TR, 3, 1, 1, 2, ABL_AHEAD, 12>(a, stream);
 #define KMX_CFG(KS_, WNW_, WN_, D_) \
   if(ks == KS_ && cfg == 10 * WNW_ + WN_) return launchOne<TR, KS_, WN_, WNW_, D_, 0>(a, stream);
   KMX_CFG_LIST(KMX_CFG)
@@ -91,7 +80,7 @@ hipError_t launchConv(int dtype, int ks, int cfg, const ConvArgs& a, hipStream_t
 }
 
 bool convCfgInstantiated(int ks, int cfg) {
-  if(ks == 3 && (cfg == CFG_CW12 || cfg == CFG_CW12_AHEAD)) return true;
+  if(ks == 3 && cfg == CFG_CW12) return true;
 #define KMX_CFG(KS_, WNW_, WN_, D_) \
   if(ks == KS_ && cfg == 10 * WNW_ + WN_) return true;
   KMX_CFG_LIST(KMX_CFG)
@@ -124,7 +113,7 @@ int chooseConvCfg(int ks, int coutPad, int batch) {
     const char* e = getenv("KMX_CONV_CW12_MAX_WGS");
     return e ? atoi(e) : 256;
   }();
-  if(ks == 3 && cw12Enabled() && batch * tiles <= cw12MaxWgs) return cw12Ahead() ? CFG_CW12_AHEAD : CFG_CW12;
+  if(ks == 3 && cw12Enabled() && batch * tiles <= cw12MaxWgs) return CFG_CW12;
   // 3x3/5x5 narrow shapes keep two work-groups per CU (LDS), 1x1 shapes one
   const int round = ks == 1 ? 200 : 420;
   if(fits(11) && wgs(11) <= round) return 11;

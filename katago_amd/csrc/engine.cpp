@@ -171,7 +171,7 @@ void Engine::construct(const ModelDesc& model) {
   if(const char* e = getenv("KMX_FUSE_SEAMS")) fuseSeams_ = atoi(e) != 0;
   if(const char* e = getenv("KMX_PACK_INPUTS")) packInputs_ = atoi(e) != 0;
   if(const char* e = getenv("KMX_FUSE_MIN_ROWS")) fuseMinRows_ = std::max(1, atoi(e));
-  if(const char* e = getenv("KMX_FUSE_SMALL_ROWS")) fuseSmallRows_ = std::max(0, atoi(e));
+  if(const char* e = getenv("KMX_CONV_CHAIN")) maxChain_ = atoi(e) >= 4 ? 4 : atoi(e) >= 2 ? 2 : 0;
   cin_ = model.numInputChannels;
   gin_ = model.numInputGlobalChannels;
   min_ = model.metaEncoderVersion > 0 ? model.numInputMetaChannels : 0;
@@ -337,12 +337,10 @@ void Engine::addSeam(const ConvDesc& post, const void* in, int inStride, const S
   // traffic of the fused form: in + residual + trunk raw + mid raw + mid act
   const double fusedBytes = 2.0 * S_ * ((double)C1 + 2.0 * C2 + 2.0 * C3);
   addOp("conv1x1_pair", 2.0 * (c1->macPerCell + c2->macPerCell) * S_, fusedBytes, [this, a1, a2, pa, C1, C2, C3, S](int n, hipStream_t st) {
-    const bool smallFused = fuseSmallRows_ > 0 && n >= fuseSmallRows_ && n < fuseMinRows_;
-    if(n >= fuseMinRows_ || smallFused) {
+    if(n >= fuseMinRows_) {
       PwPairArgs x = pa;
       x.cells = (long long)n * S;
       x.alone = cfgScale_ <= 1 && !sharesDevice_;
-      x.smallTile = smallFused ? 1 : 0;
       hipCheck(launchPointwisePair(dtype_, C1, C2, C3, x, st), "pointwise pair launch");
     }
     else {
@@ -352,7 +350,7 @@ void Engine::addSeam(const ConvDesc& post, const void* in, int inStride, const S
   });
   // the two-launch form moves the activated trunk image through HBM: its own class and byte model in the profile
   Op& op = ops_.back();
-  op.smallBelow = fuseSmallRows_ > 0 ? std::min(fuseSmallRows_, fuseMinRows_) : fuseMinRows_;  // below it: two launches
+  op.smallBelow = fuseMinRows_;  // below it: two launches
   op.clsSmall = opClass("conv1x1_pair_unfused");
   op.bytesPerRowSmall = b1 + b2;
   op.launchesSmall = 2;
@@ -367,6 +365,95 @@ void Engine::addResidualConv(const ConvDesc& conv, const void* in, int inStride,
     addConv(c, in, inStride, nullptr, 0, s.raw, s.stride, s.raw, s.stride, 0, c->coutPad, s.act, s.stride, 0, c->coutPad, nextBN->act);
   else
     addConv(c, in, inStride, nullptr, 0, s.raw, s.stride, s.raw, s.stride, 0, c->coutPad, nullptr, 0, 0, 0, KMX_ACT_IDENTITY);
+}
+
+// One or two consecutive ordinary residual blocks on a 192-channel stream (the inner blocks of b18c384nbt's nested-bottleneck
+// blocks, eigenbackend.cpp:1103-1146) as ONE op: at batch sizes that take the one-work-group-per-board shape it is one launch of
+// conv_chain_kernel.h - two or four convolutions, the activated images handed over inside the CU (with KMX_CONV_CHAIN=2: launches of
+// two) - otherwise exactly the launches the blocks get one by one. Same arithmetic either way, bit for bit. Returns the number of
+// blocks that went into the op (0: blocks[i] is not of that shape).
+int Engine::addOrdinaryChain(const std::vector<BlockDesc>& blocks, size_t i, const Stream& s, const BnDesc* bnAfter) {
+  if(maxChain_ < 2 || s.stride != CHAIN_CHANNELS) return 0;
+  auto nextBnOf = [&](size_t k) -> const BnDesc* { return k + 1 < blocks.size() ? (blocks[k + 1].isTransformer() ? nullptr : &blocks[k + 1].preBN) : bnAfter; };
+  auto eligible = [&](size_t k) {
+    if(k >= blocks.size() || blocks[k].kind != BlockKind::Ordinary) return false;
+    const BlockDesc& b = blocks[k];
+    const BnDesc* nb = nextBnOf(k);
+    if(nb == nullptr || nb->c != CHAIN_CHANNELS || b.midBN.c != CHAIN_CHANNELS) return false;
+    for(const ConvDesc* c : {&b.regularConv, &b.finalConv})
+      if(c->ky != 3 || c->kx != 3 || c->inC != CHAIN_CHANNELS || c->outC != CHAIN_CHANNELS) return false;
+    return b.midBN.act == nb->act && convChainSupported(nb->act);
+  };
+  if(!eligible(i)) return 0;
+  const int nBlocks = eligible(i + 1) && nextBnOf(i)->act == nextBnOf(i + 1)->act ? 2 : 1;
+  const int nc = 2 * nBlocks;
+  const ConvDesc* cd[MAX_CHAIN];
+  const BnDesc* bd[MAX_CHAIN];
+  for(int k = 0; k < nBlocks; k++) {
+    cd[2 * k] = &blocks[i + k].regularConv;
+    bd[2 * k] = &blocks[i + k].midBN;
+    cd[2 * k + 1] = &blocks[i + k].finalConv;
+    bd[2 * k + 1] = nextBnOf(i + k);
+  }
+  const FusedConv* fc[MAX_CHAIN];
+  for(int k = 0; k < nc; k++) fc[k] = newConv({{cd[k], bd[k]}});
+  void* tmp = acts_[0]->get();
+  // the launches of the unchained form: what buildStack adds for the blocks one by one
+  std::vector<ConvArgs> ca(nc);
+  double bytesUnchained = 0.0;
+  for(int k = 0; k < nc; k++) {
+    double b = 0.0;
+    if(k % 2 == 0)
+      ca[k] = makeConvArgs(fc[k], s.act, s.stride, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, tmp, CHAIN_CHANNELS, 0, fc[k]->coutPad, bd[k]->act, &b);
+    else
+      ca[k] = makeConvArgs(fc[k], tmp, CHAIN_CHANNELS, nullptr, 0, s.raw, s.stride, s.raw, s.stride, 0, fc[k]->coutPad, s.act, s.stride, 0,
+                           fc[k]->coutPad, bd[k]->act, &b);
+    bytesUnchained += b;
+  }
+  ConvChainArgs ch;
+  memset(&ch, 0, sizeof(ch));
+  ch.in = s.act;
+  ch.zeroPage = zeroPage_.get();
+  ch.mask = mask_.as<float>();
+  ch.X = X_;
+  ch.Y = Y_;
+  ch.actKind = bd[0]->act;
+  for(int k = 0; k < nc; k++) {
+    ch.conv[k].w = fc[k]->w.get();
+    ch.conv[k].scale = fc[k]->scale.as<float>();
+    ch.conv[k].bias = fc[k]->bias.as<float>();
+    ch.conv[k].resid = k % 2 == 1 ? s.raw : nullptr;
+    ch.conv[k].rawOut = k % 2 == 1 ? s.raw : nullptr;
+    ch.conv[k].actOut = k % 2 == 1 ? s.act : tmp;
+  }
+  double macs = 0.0;
+  for(int k = 0; k < nc; k++) macs += fc[k]->macPerCell;
+  const int perLaunch = std::min(nc, maxChain_);  // convolutions per chained launch
+  // traffic of the chained form (16-bit elements per cell): per launch the input in and the last activated image out; per residual
+  // convolution the residual in and the raw stream out; a hand-over moves half an image out and in again
+  const double C = CHAIN_CHANNELS;
+  const double launches = (double)(nc / perLaunch), handovers = (double)(nc - nc / perLaunch);
+  const double bytesChained = 2.0 * S_ * (2.0 * launches * C + (double)nBlocks * 2.0 * C + handovers * C);
+  addOp("conv3x3", 2.0 * macs * S_, bytesChained, [this, ca, ch, nc, perLaunch](int n, hipStream_t st) {
+    if(chooseConvCfg(3, CHAIN_CHANNELS, n * cfgScale_) == 23) {
+      for(int k0 = 0; k0 < nc; k0 += perLaunch) {
+        ConvChainArgs x = ch;
+        x.N = n;
+        x.nConv = perLaunch;
+        for(int k = 0; k < perLaunch; k++) x.conv[k] = ch.conv[k0 + k];
+        hipCheck(launchConvChain(dtype_, x, st), "convolution chain launch");
+      }
+    }
+    else
+      for(int k = 0; k < nc; k++) launchConvOp(ca[k], 3, n, st);
+  });
+  Op& op = ops_.back();
+  op.launches = nc;  // the profile counts convolutions: per-convolution times stay comparable between the forms
+  op.launchesSmall = nc;
+  op.clsSmall = op.cls;
+  op.bytesPerRowSmall = bytesUnchained;
+  op.smallBelow = -1;  // decided per pass, see runSchedule
+  return nBlocks;
 }
 
 namespace {
@@ -495,6 +582,9 @@ void Engine::buildStack(const std::vector<BlockDesc>& blocks, const Stream& s, c
         hipCheck(launchSwiGlu(dtype, x, st), "swiglu launch");
       });
       addResidualConv(c2, tH, hStride, s, nextBN);
+    }
+    else if(int chained = b.kind == BlockKind::Ordinary ? addOrdinaryChain(blocks, i, s, bnAfter) : 0) {
+      i += (size_t)chained - 1;  // (one or two blocks went into one op)
     }
     else if(b.kind == BlockKind::Ordinary) {
       // mid = act(midBN(conv1(s.act)));  s.raw += conv2(mid);  s.act = act(nextBN(s.raw))   (eigenbackend.cpp:1139-1145)
@@ -830,9 +920,10 @@ void Engine::runSchedule(int n, const float* dSpatial, const unsigned char* dPac
         eventPool_.pop_back();
       }
     }
-    const bool smallForm = n < op.smallBelow;
+    // (a chain op - smallBelow < 0 - takes its separate-launch form whenever the batch does not take the one-work-group-per-board shape)
+    const bool smallForm = op.smallBelow < 0 ? chooseConvCfg(3, CHAIN_CHANNELS, n * cfgScale_) != 23 : n < op.smallBelow;
     p.cls = smallForm ? op.clsSmall : op.cls;
-    p.launches = smallForm ? op.launchesSmall : 1;
+    p.launches = smallForm ? op.launchesSmall : op.launches;
     p.flops = op.flopsPerRow * n;
     p.bytes = (smallForm ? op.bytesPerRowSmall : op.bytesPerRow) * n;
     hipCheck(hipEventRecord(p.a, stream_), "hipEventRecord");
@@ -1280,6 +1371,70 @@ void testPointwisePair(int dtype, int batch, int X, int Y, int c1, int c2, int c
 }
 
 // ---- unit hooks for the transformer kernels (experimental; tests/test_gpu_transformer.py) ----
+void testConvChain(int dtype, int batch, int X, int Y, int nConv, const float* xIn, const float* rIn, const float* w, const float* scale,
+                   const float* bias, int act, const float* mask, int chained, float* outR, float* outX) {
+  if(!xIn || !rIn || !w || !scale || !bias || !outR || !outX) throw Error(KMX_ERR_INVALID_ARG, "test conv chain: null argument");
+  if(nConv != 2 && nConv != 4) throw Error(KMX_ERR_INVALID_ARG, "test conv chain: n_conv must be 2 or 4");
+  if(chained != 0 && chained != 2 && chained != 4) throw Error(KMX_ERR_INVALID_ARG, "test conv chain: chained must be 0, 2 or 4");
+  if(chained > nConv) chained = nConv;
+  if(chained != 0 && !convChainSupported(act)) throw Error(KMX_ERR_UNSUPPORTED, "test conv chain: no chained kernel for this activation");
+  const int C = CHAIN_CHANNELS;
+  HookCtx h(dtype, batch, X, Y, mask);
+  std::vector<FusedConv> fc;
+  for(int k = 0; k < nConv; k++) {
+    kmx_conv_desc d;
+    d.conv_y_size = d.conv_x_size = 3;
+    d.in_channels = d.out_channels = C;
+    d.weights = w + (size_t)k * C * C * 9;
+    const ConvDesc cd = convFromAbi(&d);
+    BnDesc bn;
+    bn.name = "testbn"; bn.c = C; bn.act = act;
+    bn.scale.assign(scale + (size_t)k * C, scale + (size_t)(k + 1) * C);
+    bn.bias.assign(bias + (size_t)k * C, bias + (size_t)(k + 1) * C);
+    fc.push_back(buildFusedConv(dtype, {{&cd, &bn}}, nullptr));
+  }
+  int stride;
+  DevBuf x = h.toDevice(xIn, C, &stride);
+  DevBuf r = h.toDevice(rIn, C, &stride);
+  const size_t cells = (size_t)batch * h.S;
+  DevBuf tmp(cells * C * 2);
+  if(chained == 0) {
+    for(int k = 0; k < nConv; k++) {
+      ConvArgs a;
+      memset(&a, 0, sizeof(a));
+      a.w = fc[k].w.get(); a.zeroPage = h.zero.get(); a.inC = C; a.nChunks = fc[k].nChunks; a.coutPad = fc[k].coutPad;
+      a.N = batch; a.X = X; a.Y = Y;
+      a.scale = fc[k].scale.as<float>(); a.bias = fc[k].bias.as<float>(); a.actKind = act; a.mask = h.mask.as<float>();
+      a.actC = C; a.actBegin = 0; a.actEnd = C;
+      if(k % 2 == 0) { a.in = x.get(); a.actOut = tmp.get(); }
+      else {
+        a.in = tmp.get(); a.actOut = x.get();
+        a.resid = r.get(); a.residC = C; a.rawOut = r.get(); a.rawC = C; a.rawBegin = 0; a.rawEnd = C;
+      }
+      hipCheck(launchConv(dtype, 3, 23, a, h.st), "test conv chain: convolution launch");
+    }
+  }
+  else {
+    for(int k0 = 0; k0 < nConv; k0 += chained) {
+      ConvChainArgs ch;
+      memset(&ch, 0, sizeof(ch));
+      ch.in = x.get(); ch.zeroPage = h.zero.get(); ch.mask = h.mask.as<float>();
+      ch.N = batch; ch.X = X; ch.Y = Y; ch.nConv = chained; ch.actKind = act;
+      for(int k = 0; k < chained; k++) {
+        ChainConv& c = ch.conv[k];
+        c.w = fc[k0 + k].w.get(); c.scale = fc[k0 + k].scale.as<float>(); c.bias = fc[k0 + k].bias.as<float>();
+        c.resid = k % 2 == 1 ? r.get() : nullptr;
+        c.rawOut = k % 2 == 1 ? r.get() : nullptr;
+        c.actOut = k % 2 == 1 ? x.get() : tmp.get();
+      }
+      hipCheck(launchConvChain(dtype, ch, h.st), "test conv chain: chain launch");
+    }
+  }
+  hipCheck(hipStreamSynchronize(h.st), "sync");
+  h.toHost(r, C, C, outR);
+  h.toHost(x, C, C, outX);
+}
+
 void testRmsNorm(int dtype, int batch, int X, int Y, int C, float eps, const float* w, const float* beta, int actKind, bool perBoard,
                  const float* in, const float* mask, float* out) {
   if(!w || !in || !out || C < 1) throw Error(KMX_ERR_INVALID_ARG, "test rmsnorm: bad argument");

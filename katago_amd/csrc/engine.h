@@ -154,6 +154,7 @@ class Engine {
     int clsSmall = -1;
     double bytesPerRowSmall = 0.0;
     int launchesSmall = 1;
+    int launches = 1;      // what one execution of the main form counts as in the profile (a chain of k convolutions counts k)
   };
   void construct(const ModelDesc& model);  // the body of the constructor
   bool scale8_ = false;  // the net runs at 1/8 of its values (fp16 range transform)
@@ -175,6 +176,8 @@ class Engine {
                const Stream& mid, const BnDesc& innerBN);
   const FusedConv* newConv(const std::vector<ConvSegment>& segs, std::vector<int>* offs = nullptr);
   void addResidualConv(const ConvDesc& conv, const void* in, int inStride, const Stream& s, const BnDesc* nextBN);
+  // blocks[i] (and blocks[i + 1]) as one chained launch where the shape allows it (conv_chain_kernel.h); returns the number of blocks consumed (0: none)
+  int addOrdinaryChain(const std::vector<BlockDesc>& blocks, size_t i, const Stream& s, const BnDesc* bnAfter);
   void addRmsNorm(const void* in, int inStride, void* out, int outStride, int C, float eps, const std::vector<float>& w,
                   const std::vector<float>* beta, int actKind, bool perBoard);
   float* uploadFloats(const std::vector<float>& v);
@@ -216,10 +219,11 @@ class Engine {
                             // synchronous host entry) 32.9 k evals/s with it against 39.2 k without - the caller's thread packs while the GPU idles,
                             // and that costs more than the 0.3 ms of PCIe it saves; the batcher packs on the submitters' threads instead
   int fuseMinRows_ = 24;    // KMX_FUSE_MIN_ROWS: smallest batch that takes the fused seam kernel
-  // EXPERIMENT, off (0) until measured: batches of at least this many rows BELOW fuseMinRows_ take the fused seam as the 4-wave x
-  // 64-cell one-tile kernel (6 work-groups per board) instead of two convolution launches - at small batch a launch costs ~14 us
-  // whatever it does and a pass has 17 seams. KMX_FUSE_SMALL_ROWS=1 turns it on for every small batch.
-  int fuseSmallRows_ = 0;
+  // KMX_CONV_CHAIN = 0 | 2 | 4: the longest chain of 3x3 192 -> 192 convolutions that runs as one launch with the activated image handed
+  // over in LDS (conv_chain_kernel.h) when the batch takes the one-work-group-per-board shape; 0 = always separate launches
+  int maxChain_ = 4;
+  // (Round 4 measured the seam below that threshold as the 4-wave x 64-cell one-tile seam kernel instead of two convolution launches:
+  // within the noise of the scan, -4 % per pass at batch 1, +3 % at batch 8 - removed; profiles/r04_steps/call1/small_batch_scan.txt.)
   int forkOps_ = 0;
   hipEvent_t forkEv_ = nullptr;
 
@@ -282,6 +286,8 @@ bool packRowNHWC(const float* row, int S, int C, unsigned char* out);
 void testPointwisePair(int dtype, int batch, int X, int Y, int c1, int c2, int c3, const float* in, const float* resid, const float* w1,
                        const float* scale1, const float* bias1, int act1, const float* w2, const float* scale2, const float* bias2,
                        int act2, const float* mask, bool fused, float* outTrunkRaw, float* outMidRaw, float* outMidAct);
+void testConvChain(int dtype, int batch, int X, int Y, int nConv, const float* x, const float* r, const float* w, const float* scale,
+                   const float* bias, int act, const float* mask, int chained, float* outR, float* outX);
 // Unit hooks for the transformer kernels (experimental): fp32 NHWC in/out like the hooks above.
 void testRmsNorm(int dtype, int batch, int X, int Y, int C, float eps, const float* w, const float* beta, int actKind, bool perBoard,
                  const float* in, const float* mask, float* out);

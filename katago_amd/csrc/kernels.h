@@ -59,6 +59,33 @@ hipError_t launchConv(int dtype, int ks, int cfg, const ConvArgs& a, hipStream_t
 int chooseConvCfg(int ks, int coutPad, int batch);
 bool convCfgInstantiated(int ks, int cfg);  // is there a kernel for this (kernel size, shape)?
 
+// A chain of 2..MAX_CHAIN 3x3 convolutions 192 -> 192 of one board as ONE launch (conv_chain_kernel.h): the inner residual blocks of a
+// nested-bottleneck block. Convolution i reads the activated image of convolution i - 1 (conv 0: `in`); every tensor has channel
+// stride 192. Epilogue of convolution i, per channel c and cell p:  v = acc + resid[p][c] (if resid);  rawOut[p][c] = v (if rawOut);
+// act = actKind((v * scale[c] + bias[c])) * mask[p]: the LAST convolution stores all of it to actOut; an earlier one hands channels
+// [0, 96) to its successor inside the CU and stores only channels [96, 192) to actOut - a scratch tensor nobody else may rely on.
+constexpr int MAX_CHAIN = 4;
+constexpr int CHAIN_CHANNELS = 192;
+struct ChainConv {
+  const void* w;       // T[6][9][192][32], the FusedConv layout
+  const float* scale;  // [192] merged BN of the activation that follows this convolution
+  const float* bias;
+  const void* resid;   // T[N][S][192] or null (may alias rawOut)
+  void* rawOut;        // T[N][S][192] or null; a convolution with a residual must have one
+  void* actOut;        // T[N][S][192], never null
+};
+struct ConvChainArgs {
+  const void* in;        // T[N][S][192]
+  const void* zeroPage;  // as ConvArgs::zeroPage
+  const float* mask;     // [N][S]
+  int N, X, Y;
+  int nConv;
+  int actKind;           // one activation kind for the whole chain
+  ChainConv conv[MAX_CHAIN];
+};
+hipError_t launchConvChain(int dtype, const ConvChainArgs& a, hipStream_t stream);
+bool convChainSupported(int actKind);  // is there a kernel for this activation?
+
 // The seam between two nested-bottleneck blocks as ONE launch (pointwise_kernel.h): block i's closing 1x1 convolution
 // (+ residual), block i+1's preBN + activation, block i+1's opening 1x1 convolution and the first inner block's
 // preBN + activation. The activated trunk image only exists in LDS. Cells are the flat N*S index.
@@ -94,9 +121,6 @@ struct PwPairArgs {
   // and let the other stream's kernels in (41.5 k against 40.5-40.9 k on one box, equal within noise on another;
   // profiles/r03_steps/seam_two_streams*.txt).
   int alone;
-  // 1: take the 4-wave x 64-cell one-tile kernel whatever KMX_PW_WAVES says - twice the work-groups of half the length each; the
-  // engine's opt-in for batches below its fusion threshold (KMX_FUSE_SMALL_ROWS, engine.h), where the chip is mostly idle
-  int smallTile;
 };
 hipError_t launchPointwisePair(int dtype, int c1, int c2, int c3, const PwPairArgs& a, hipStream_t stream);
 bool pointwisePairSupported(int c1, int c2, int c3);  // is there a kernel for these channel counts?

@@ -567,6 +567,14 @@ int kmx_test_pointwise_pair(int batch, int nn_x_len, int nn_y_len, int precision
                       w2_oi, scale2, bias2, act2, mask_nhw, fused != 0, out_trunk_raw, out_mid_raw, out_mid_act);
   });
 }
+int kmx_test_conv_chain(int batch, int nn_x_len, int nn_y_len, int precision_mode, int n_conv, const float* x_nhwc, const float* r_nhwc,
+                        const float* w_oihw, const float* scale, const float* bias, int activation, const float* mask_nhw, int chained,
+                        float* out_r, float* out_x) {
+  return guarded([&] {
+    testConvChain(hookDtype(precision_mode), batch, nn_x_len, nn_y_len, n_conv, x_nhwc, r_nhwc, w_oihw, scale, bias, activation, mask_nhw,
+                  chained, out_r, out_x);
+  });
+}
 int kmx_test_rmsnorm(int batch, int nn_x_len, int nn_y_len, int precision_mode, int num_channels, float epsilon, const float* weight,
                      const float* beta, int activation, int per_board, const float* in_nhwc, const float* mask_nhw, float* out_nhwc) {
   return guarded([&] {

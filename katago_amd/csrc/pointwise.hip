@@ -63,7 +63,7 @@ int numComputeUnits() {  // per device: one persistent work-group per CU (KMX_PW
 
 template <class TR>
 hipError_t launchT(int c1, int c2, int c3, const PwPairArgs& a, hipStream_t stream) {
-  if(c1 == 192 && c2 == 384 && c3 == 192 && a.actOut == nullptr && a.actKind1 == a.actKind2 && pwWaves() == 8 && !a.smallTile && persistentWanted() &&
+  if(c1 == 192 && c2 == 384 && c3 == 192 && a.actOut == nullptr && a.actKind1 == a.actKind2 && pwWaves() == 8 && persistentWanted() &&
      (a.alone != 0 || (a.cells + pw2::TM - 1) / pw2::TM >= 2LL * numComputeUnits() || persistentForced()))
   {
     if(a.actKind1 == KMX_ACT_MISH) {
@@ -77,7 +77,7 @@ hipError_t launchT(int c1, int c2, int c3, const PwPairArgs& a, hipStream_t stre
   // the 4-wave shape: a wave of GEMM 1 owns C2/2 channels (WN1 doubles), of GEMM 2 C3/2 (WN2 as is)
 #define KMX_PW(K1_, WN1_, WN2_) \
   if(c1 == 32 * K1_ && c2 == 128 * WN1_ && c3 == 64 * WN2_) \
-    return pwWaves() == 8 && !a.smallTile ? launchPair<TR, K1_, WN1_, WN2_, 128, 8>(a, stream) : launchPair<TR, K1_, 2 * WN1_, WN2_, 64, 4>(a, stream);
+    return pwWaves() == 8 ? launchPair<TR, K1_, WN1_, WN2_, 128, 8>(a, stream) : launchPair<TR, K1_, 2 * WN1_, WN2_, 64, 4>(a, stream);
   KMX_PW_LIST(KMX_PW)
 #undef KMX_PW
   return hipErrorInvalidValue;

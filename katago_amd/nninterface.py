@@ -371,6 +371,22 @@ def testEvaluatePointwisePair(batchSize, nnXLen, nnYLen, useFP16, x, resid, w1, 
     return out
 
 
+def testEvaluateConvChain(batchSize, nnXLen, nnYLen, useFP16, x, r, w, scale, bias, activation, mask, chained):
+    """kmx_test_conv_chain: 2 or 4 convolutions 3x3 192 -> 192 (one or two residual blocks on a 192-channel stream) as separate
+    launches (chained=0) or as launches of `chained` convolutions with the activated image handed over inside the CU. Arrays: x, r
+    [cells][192]; w [n_conv][192][192][3][3]; scale, bias [n_conv][192]; mask [cells] or None. Returns (r, x) after the last block."""
+    lib = capi.load_library()
+    cells = batchSize * nnXLen * nnYLen
+    c = [np.ascontiguousarray(v, dtype=np.float32) for v in (x, r, w, scale, bias)]
+    n_conv = c[2].shape[0]
+    assert c[0].shape == (cells, 192) and c[1].shape == (cells, 192) and c[2].shape == (n_conv, 192, 192, 3, 3) and c[3].shape == (n_conv, 192)
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.float32)
+    out = [np.empty((cells, 192), np.float32), np.empty((cells, 192), np.float32)]
+    capi.check(lib.kmx_test_conv_chain(batchSize, nnXLen, nnYLen, _prec(useFP16), n_conv, _fp(c[0]), _fp(c[1]), _fp(c[2]), _fp(c[3]), _fp(c[4]),
+                                       activation, None if m is None else _fp(m), chained, _fp(out[0]), _fp(out[1])), lib)
+    return out
+
+
 def testEvaluateConv(w_oihw, batchSize, nnXLen, nnYLen, useFP16, inputNHWC):
     lib = capi.load_library()
     d, keep = _conv_desc(w_oihw)

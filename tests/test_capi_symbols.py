@@ -25,7 +25,7 @@ def test_header_symbols_exported_and_bound():
 
 def test_abi_version_and_errors_without_gpu():
     lib = capi.load_library()
-    assert lib.kmx_abi_version() == 5
+    assert lib.kmx_abi_version() == 6
     p = ctypes.c_void_p()
     rc = lib.kmx_model_load(b"/nonexistent/model.bin.gz", b"", ctypes.byref(p))
     assert rc == capi.KMX_ERR_IO and b"model.bin.gz" in lib.kmx_last_error()

@@ -115,3 +115,51 @@ def test_fp32_mode_is_refused_not_emulated():
     with pytest.raises(nn.KatamxError) as e:
         nn.testEvaluateConv(_cw(rng, 4, 4, 3), 1, 5, 5, "fp32", rng.standard_normal((1, 5, 5, 4)).astype(np.float32))
     assert e.value.code == capi.KMX_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("n_conv,X,Y,n", [(4, 19, 19, 40), (2, 19, 19, 3), (4, 9, 9, 2), (2, 13, 7, 1)])
+def test_conv_chain_bit_identical_to_separate_launches(dtype, n_conv, X, Y, n):
+    """conv_chain_kernel.h (round 4): one or two residual blocks on a 192-channel stream (ResidualBlock::apply, eigenbackend.cpp:
+    1103-1146) as chained launches of 2 / 4 convolutions - the activated image handed over in LDS and through the scratch tensor -
+    BIT FOR BIT against one launch of conv_kernel.h per convolution (same work-group shape), and against a torch restatement with
+    the device's rounding points at the layer tolerance of the reference's tests (cpp/tests/testnn.cpp:8-15). Boards smaller than
+    the buffer exercise the mask and the zero halo of the handed-over image; 40 boards run on several XCDs at once."""
+    import torch
+
+    rng = np.random.default_rng(n_conv * 100 + X)
+    cells = n * X * Y
+    mask = np.ones((n, Y, X), np.float32)
+    if n > 1:
+        mask[1, :, X - 3:] = 0
+        mask[1, Y - 2:, :] = 0
+    if n > 20:
+        mask[17, :, 9:] = 0
+        mask[17, 13:, :] = 0
+    m = mask.reshape(-1)
+    x = (rng.normal(size=(cells, 192)) * m[:, None]).astype(np.float32)
+    r = rng.normal(size=(cells, 192)).astype(np.float32)
+    w = (rng.normal(size=(n_conv, 192, 192, 3, 3)) * 0.03).astype(np.float32)
+    scale = rng.uniform(0.6, 1.4, (n_conv, 192)).astype(np.float32)
+    bias = rng.normal(0, 0.25, (n_conv, 192)).astype(np.float32)
+    res = {c: nn.testEvaluateConvChain(n, X, Y, dtype, x, r, w, scale, bias, capi.ACT_MISH, m, c) for c in (0, 2, 4) if c <= n_conv}
+    for c in res:
+        assert np.array_equal(res[c][0], res[0][0]) and np.array_equal(res[c][1], res[0][1]), c
+    assert (res[0][1][m != 1.0] == 0).all()
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    q = lambda t: t.to(tdt).float()
+    mish = lambda t: t * torch.tanh(torch.nn.functional.softplus(t))
+    pick = list(range(n)) if n <= 4 else [0, 1, 17, n - 1]
+    mt = torch.from_numpy(mask[pick])[:, None]
+    tx = q(torch.from_numpy(x.reshape(n, Y, X, 192)[pick]).permute(0, 3, 1, 2))
+    tr = q(torch.from_numpy(r.reshape(n, Y, X, 192)[pick]).permute(0, 3, 1, 2))
+    for k in range(0, n_conv, 2):
+        sc = lambda i: torch.from_numpy(scale[i])[None, :, None, None]
+        bi = lambda i: torch.from_numpy(bias[i])[None, :, None, None]
+        t = q(mish(torch.nn.functional.conv2d(tx, q(torch.from_numpy(w[k])), padding=1) * sc(k) + bi(k)) * mt)
+        v = torch.nn.functional.conv2d(t, q(torch.from_numpy(w[k + 1])), padding=1) + tr
+        tr = q(v)
+        tx = q(mish(v * sc(k + 1) + bi(k + 1)) * mt)
+    wantR = tr.permute(0, 2, 3, 1).reshape(len(pick), -1).numpy()
+    wantX = tx.permute(0, 2, 3, 1).reshape(len(pick), -1).numpy()
+    assert close(res[0][0].reshape(n, -1)[pick], wantR) and close(res[0][1].reshape(n, -1)[pick], wantX)

@@ -89,9 +89,8 @@ def test_twelve_wave_small_batch_shape(emu_full_lib):
     immediate and with the latest legal completion of its LDS-DMA requests, and BIT-IDENTICAL to the 4-wave shapes the same layers
     take without it (same MFMAs per output in the same K order) - square, rectangular and several boards, channel counts that are
     not multiples of the tile."""
-    # ... and its read-ahead variant (cfg 112, KMX_CONV_CW12_AHEAD=1: an experiment that has not run on hardware yet)
-    runs = run_parallel([([sys.executable, "-c", CW12_CODE, emu_full_lib], dict(os.environ, KMX_CONV_CW12=cw, KMX_EMU_LATE_DMA=late, KMX_CONV_CW12_AHEAD=ahead))
-                         for cw, late, ahead in (("0", "0", "0"), ("1", "0", "0"), ("1", "1", "0"), ("1", "0", "1"), ("1", "1", "1"))])
+    runs = run_parallel([([sys.executable, "-c", CW12_CODE, emu_full_lib], dict(os.environ, KMX_CONV_CW12=cw, KMX_EMU_LATE_DMA=late))
+                         for cw, late in (("0", "0"), ("1", "0"), ("1", "1"))])
     res = []
     for rc, so, se in runs:
         assert rc == 0 and "RESULT " in so, (so + se)[-3000:]

@@ -211,28 +211,3 @@ def test_eight_devices_selfplay_in_one_process(fake_so, tmp_path):
     per_size = shard_checks.check_shards(shard_checks.shard_files(os.path.join(d, "out")), 19, (9, 13, 19), rows)
     assert all(v > 0 for v in per_size.values()), per_size
     print("8 fake devices: launches per device", per_dev, "training rows by board size", per_size)
-
-
-def test_small_batch_seams_as_one_launch_opt_in(fake_so, tmp_path):
-    """KMX_FUSE_SMALL_ROWS=1 (an experiment, off by default): below the fusion threshold the 17 seams of b18c384nbt run as the 4-wave x
-    64-cell one-tile seam kernel - one launch of ceil(cells / 64) work-groups each - instead of two convolution launches; at and above
-    the threshold nothing changes. Without the variable the schedule is the GPU-verified one (the golden test above)."""
-    from katago_amd import modelgen
-
-    model = os.path.join(str(tmp_path), "b18.bin")
-    modelgen.write_model(model, "b18c384nbt", seed=1)
-
-    def launches_of(env, n):
-        log = dry_run(fake_so, model, 32, [n], str(tmp_path / ("s%d.log" % n)), env)
-        names = [_fields(l)[0:2] for l in log.splitlines() if l.startswith("launch ")]
-        return names
-
-    for n in (1, 8):
-        plain = launches_of({}, n)
-        small = launches_of({"KMX_FUSE_SMALL_ROWS": "1"}, n)
-        seam = [(k, g) for k, g in small if "pointwisePairKernel" in k]
-        assert not any("pointwisePair" in k for k, g in plain)
-        assert len(seam) == 17 and len(small) == len(plain) - 17  # 34 plain 1x1 launches became 17
-        assert all(g == ((n * 361 + 63) // 64, 1, 1) and "Li64ELi4E" in k for k, g in seam), seam[:2]
-    at_threshold = launches_of({"KMX_FUSE_SMALL_ROWS": "1"}, 24)
-    assert at_threshold == launches_of({}, 24)
