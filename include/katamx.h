@@ -280,6 +280,9 @@ int kmx_bench_conv_streams(int ks, int cfg, int cin, int cout, int batch, int n_
  * synthetic data; timing != 0 runs the instrumented instantiation of the persistent kernel and prints per-wave cycle sums of
  * its phases on stderr. KMX_PW_V2=0 selects the one-tile-per-work-group kernel. Kernel tuning instrumentation. */
 int kmx_bench_seam(int batch, int iters, int timing, double* avg_ms);
+/* n_conv (2 | 4) convolutions 3x3 192 -> 192 on `batch` 19x19 boards, per sequence: chained = 0 one launch each, 2 | 4 chained launches
+ * (conv_chain_kernel.h); timing != 0: the chained launches print cycle stamps per phase to stderr. KMX_BENCH_DTYPE=fp16 | bf16 (default). */
+int kmx_bench_conv_chain(int batch, int n_conv, int chained, int iters, int timing, double* avg_ms);
 /* Host-only introspection of the convolution launcher (no device needed): the work-group shape chosen for a kernel size,
  * a padded channel count (multiple of 64) and a batch, and whether a kernel of that shape exists and tiles the channels.
  * tests/test_conv_chooser.py walks every combination the engine can ask for. */

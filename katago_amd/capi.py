@@ -124,6 +124,7 @@ SIGNATURES = {
     "kmx_handle_set_split_min": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "kmx_bench_conv": (ctypes.c_int, [ctypes.c_int] * 10 + [ctypes.POINTER(ctypes.c_double)]),
     "kmx_bench_conv_streams": (ctypes.c_int, [ctypes.c_int] * 6 + [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
+    "kmx_bench_conv_chain": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_double)]),
     "kmx_bench_seam": (ctypes.c_int, [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_double)]),
     "kmx_debug_conv_cfg": (ctypes.c_int, [ctypes.c_int] * 3 + [_IP, _IP]),
     "kmx_bench_mfma": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_double)] * 3),

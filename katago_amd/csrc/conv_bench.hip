@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 
+#include "conv_chain_kernel.h"
 #include "conv_kernel.h"
 #include "engine.h"
 
@@ -109,6 +110,101 @@ double benchConv(int ks, int cfg, int variant, int cin, int cout, int batch, int
   return (double)ms / iters;
 }
 
+
+// nConv (2 or 4) convolutions 3x3 192 -> 192 on `batch` boards: chained = 0: one launch of the product shape per convolution, else launches of
+// `chained` convolutions (conv_chain_kernel.h). timing: the chained launches carry cycle stamps (printed per wave of the middle board).
+double benchConvChain(int batch, int nConv, int chained, int iters, int timing) {
+  const char* dtEnv = getenv("KMX_BENCH_DTYPE");
+  const int dtype = (dtEnv && std::string(dtEnv) == "fp16") ? DT_F16 : DT_BF16;
+  const int S = 361, C = CHAIN_CHANNELS, X = 19, Y = 19;
+  const size_t cells = (size_t)batch * S;
+  uint32_t rng = 777;
+  auto rnd = [&]() {
+    rng = rng * 1664525u + 1013904223u;
+    return ((rng >> 8) & 0xffff) / 65536.0f - 0.5f;
+  };
+  std::vector<FusedConv> fc;
+  for(int k = 0; k < nConv; k++) {
+    ConvDesc c;
+    c.name = "bench"; c.ky = c.kx = 3; c.inC = c.outC = C;
+    c.w.resize((size_t)9 * C * C);
+    for(float& v : c.w) v = rnd() * 0.05f;
+    BnDesc bn;
+    bn.c = C; bn.act = KMX_ACT_MISH;
+    bn.scale.assign(C, 1.0f);
+    bn.bias.assign(C, 0.1f);
+    fc.push_back(buildFusedConv(dtype, {{&c, &bn}}, nullptr));
+  }
+  std::vector<uint16_t> hx(cells * C);
+  for(uint16_t& v : hx) v = dtype == DT_F16 ? floatToHalfBits(rnd()) : floatToBf16Bits(rnd());
+  DevBuf x(hx.size() * 2, false), r(cells * C * 2), tmp(cells * C * 2), zero(ZERO_PAGE_ALLOC);
+  x.upload(hx.data(), hx.size() * 2);
+  std::vector<float> ones(cells, 1.0f);
+  DevBuf mask(cells * sizeof(float), false);
+  mask.upload(ones.data(), cells * sizeof(float));
+  DevBuf dbg(8 * MAX_CHAIN * 8 * sizeof(unsigned long long));
+  hipStream_t st = nullptr;
+  auto launch = [&]() {
+    if(chained == 0) {
+      for(int k = 0; k < nConv; k++) {
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.w = fc[k].w.get(); a.zeroPage = zero.get(); a.inC = C; a.nChunks = fc[k].nChunks; a.coutPad = fc[k].coutPad;
+        a.N = batch; a.X = X; a.Y = Y;
+        a.scale = fc[k].scale.as<float>(); a.bias = fc[k].bias.as<float>(); a.actKind = KMX_ACT_MISH; a.mask = mask.as<float>();
+        a.actC = C; a.actBegin = 0; a.actEnd = C;
+        if(k % 2 == 0) { a.in = x.get(); a.actOut = tmp.get(); }
+        else {
+          a.in = tmp.get(); a.actOut = x.get();
+          a.resid = r.get(); a.residC = C; a.rawOut = r.get(); a.rawC = C; a.rawBegin = 0; a.rawEnd = C;
+        }
+        hipCheck(launchConv(dtype, 3, 23, a, st), "bench chain: convolution launch");
+      }
+      return;
+    }
+    for(int k0 = 0; k0 < nConv; k0 += chained) {
+      ConvChainArgs ch;
+      memset(&ch, 0, sizeof(ch));
+      ch.in = x.get(); ch.zeroPage = zero.get(); ch.mask = mask.as<float>();
+      ch.N = batch; ch.X = X; ch.Y = Y; ch.nConv = chained; ch.actKind = KMX_ACT_MISH;
+      ch.dbg = timing ? dbg.as<unsigned long long>() : nullptr;
+      for(int k = 0; k < chained; k++) {
+        ChainConv& c = ch.conv[k];
+        c.w = fc[k0 + k].w.get(); c.scale = fc[k0 + k].scale.as<float>(); c.bias = fc[k0 + k].bias.as<float>();
+        c.resid = k % 2 == 1 ? r.get() : nullptr;
+        c.rawOut = k % 2 == 1 ? r.get() : nullptr;
+        c.actOut = k % 2 == 1 ? x.get() : tmp.get();
+      }
+      hipError_t e = timing ? (dtype == DT_F16 ? chaink::launchChainOne<TraitsF16, KMX_ACT_MISH, true>(ch, st) : chaink::launchChainOne<TraitsBF16, KMX_ACT_MISH, true>(ch, st))
+                            : launchConvChain(dtype, ch, st);
+      hipCheck(e, "bench chain: chain launch");
+    }
+  };
+  for(int i = 0; i < 3; i++) launch();
+  hipCheck(hipStreamSynchronize(st), "sync");
+  hipEvent_t e0, e1;
+  hipCheck(hipEventCreate(&e0), "event");
+  hipCheck(hipEventCreate(&e1), "event");
+  hipCheck(hipEventRecord(e0, st), "record");
+  for(int i = 0; i < iters; i++) launch();
+  hipCheck(hipEventRecord(e1, st), "record");
+  hipCheck(hipStreamSynchronize(st), "sync");
+  float ms = 0;
+  hipCheck(hipEventElapsedTime(&ms, e0, e1), "elapsed");
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if(timing && chained != 0) {
+    unsigned long long h[8 * MAX_CHAIN * 8];
+    hipCheck(hipMemcpy(h, dbg.get(), sizeof(h), hipMemcpyDeviceToHost), "copy timing");
+    for(int w = 0; w < 8; w++)
+      for(int ci = 0; ci < chained; ci++) {
+        const unsigned long long* p = h + (w * MAX_CHAIN + ci) * 8;
+        fprintf(stderr, "[chain timing] wave %d conv %d: start %llu | loop %llu | wait+barrier %llu | epilogue %llu | closing wait+barrier %llu cycles\n", w, ci,
+                p[0], p[1], p[2], p[3], p[4]);
+      }
+  }
+  return (double)ms / iters;
+}
 
 // ---- two streams, half a launch apart --------------------------------------------------------------------------------
 // Round 2 staggered the second half-batch stream by WHOLE launches (after k launches both streams again start their kernels

@@ -61,7 +61,8 @@ static_assert(ldsBytes(MAX_CHAIN) <= 160 * 1024, "LDS budget exceeded");
 static_assert(NPA + 1 <= NT && NPA <= NT + 1 - D, "the next image's requests precede the slab that the last tap waits for");
 static_assert(2 * (WN * MT - WN - MT) >= 1 + NPW, "a step's requests ride behind MFMAs that carry no fragment read");
 
-template <class TR, int KIND>
+// TIMING (conv_bench.hip only): s_memtime stamps at the phase boundaries of every convolution, written per wave of the middle board to a.dbg
+template <class TR, int KIND, bool TIMING = false>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void convChainKernel(const ConvChainArgs a) {
   typedef typename TR::T T;
   typedef typename TR::V8 V8;
@@ -183,6 +184,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
   const unsigned maskAddr = ldsBase + MASK_OFFSET;
   T* const trash = (T*)((char*)const_cast<void*>(a.zeroPage) + ZERO_PAGE_BYTES) + lane * 8;
 
+  unsigned long long tPrev = TIMING ? __builtin_readcyclecounter() : 0;
+  auto stamp = [&](int ci, int which) {  // phases of convolution ci: 0 prologue / restart, 1 loop, 2 wait + barrier after the loop, 3 epilogue, 4 closing wait + barrier
+    if(!TIMING) return;
+    const unsigned long long now = __builtin_readcyclecounter();
+    if(a.dbg != nullptr && lane == 0 && (int)blockIdx.x == a.N / 2) a.dbg[(wave * MAX_CHAIN + ci) * 8 + which] = now - tPrev;
+    tPrev = now;
+  };
   for(int ci = 0; ci < a.nConv; ci++) {
     const bool first = ci == 0, last = ci + 1 == a.nConv;
     // which chunk's image is requested while the loop works on `chunk`: the next one (conv 0: everything comes from HBM) or the one
@@ -224,6 +232,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
       }
     }
 
+    stamp(ci, 0);
     int step = 0;
     for(int chunk = 0; chunk < NCHUNK; chunk++) {
       const unsigned curA = (unsigned)(chunk % NSLOT) * ACT_BYTES;
@@ -287,6 +296,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
     // (the fragments read for "step 54" are never used: slab 54 % 4 and slot 0 hold old data, which is all they are)
 
+    stamp(ci, 1);
     // ---- between two convolutions: every wave is out of the loop before anything overwrites a slot or a ring slab ----
     waitVm<0>();  // the trailing dummy requests
     if(!last) {
@@ -303,6 +313,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
       }
     }
 
+    stamp(ci, 2);
     // ---- epilogue (conv_kernel.h's, plus the hand-over): straight from the accumulator layout ----
     const ChainConv& cv = a.conv[ci];
     const bool hasResid = cv.resid != nullptr;  // uniform
@@ -419,6 +430,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
       if(hasResid) epilogue(ActKindTag<1>());
       else epilogue(ActKindTag<0>());
     }
+    stamp(ci, 3);
     if(!last) {
       // the hand-over is complete when every wave's LDS writes are done and every wave's stores to the scratch tensor have been
       // acknowledged (the other waves' LDS-DMA reads them through the same L1); the next convolution's first slabs have landed too
@@ -426,12 +438,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
+    stamp(ci, 4);
   }
 }
 
-template <class TR, int KIND>
+template <class TR, int KIND, bool TIMING = false>
 hipError_t launchChainOne(const ConvChainArgs& a, hipStream_t stream) {
-  auto kern = convChainKernel<TR, KIND>;
+  auto kern = convChainKernel<TR, KIND, TIMING>;
   constexpr int MAX_DEVICES = 64;
   static std::atomic<bool> attrSet[MAX_DEVICES];
   int dev = 0;

@@ -82,6 +82,7 @@ struct ConvChainArgs {
   int nConv;
   int actKind;           // one activation kind for the whole chain
   ChainConv conv[MAX_CHAIN];
+  unsigned long long* dbg;  // instrumentation only (conv_bench.hip benchConvChain): per-wave cycle sums of the phases of each convolution
 };
 hipError_t launchConvChain(int dtype, const ConvChainArgs& a, hipStream_t stream);
 bool convChainSupported(int actKind);  // is there a kernel for this activation?

@@ -19,6 +19,7 @@ namespace kmx {
 double benchConv(int ks, int wn, int variant, int cin, int cout, int batch, int X, int Y, int epilogueMode, int iters);  // conv_bench.hip
 double benchConvStreams(int ks, int cfg, int cin, int cout, int batch, int nStreams, double delayUs, int launches, int epilogueMode);  // conv_bench.hip
 double benchSeam(int batch, int iters, int timing);  // conv_bench.hip
+double benchConvChain(int batch, int nConv, int chained, int iters, int timing);  // conv_bench.hip
 double benchMfma(int wavesPerWg, int wgs, int mode, int steps, int iters, double* tflops, double* coreMhz);       // conv_bench.hip
 }
 
@@ -495,6 +496,13 @@ int kmx_bench_conv_streams(int ks, int cfg, int cin, int cout, int batch, int n_
   });
 }
 
+int kmx_bench_conv_chain(int batch, int n_conv, int chained, int iters, int timing, double* avg_ms) {
+  return guarded([&] {
+    if(!avg_ms || iters < 1 || batch < 1 || (n_conv != 2 && n_conv != 4) || (chained != 0 && chained != 2 && chained != 4) || chained > n_conv)
+      throw Error(KMX_ERR_INVALID_ARG, "kmx_bench_conv_chain: bad argument");
+    *avg_ms = benchConvChain(batch, n_conv, chained, iters, timing);
+  });
+}
 int kmx_bench_seam(int batch, int iters, int timing, double* avg_ms) {
   return guarded([&] {
     if(!avg_ms || iters < 1 || batch < 1) throw Error(KMX_ERR_INVALID_ARG, "kmx_bench_seam: bad argument");

@@ -25,6 +25,7 @@ double benchConv(int, int, int, int, int, int, int, int, int, int) { return 0.0;
 double benchConvStreams(int, int, int, int, int, int, double, int, int) { return 0.0; }
 double benchMfma(int, int, int, int, int, double*, double*) { return 0.0; }
 double benchSeam(int, int, int) { return 0.0; }
+double benchConvChain(int, int, int, int, int) { return 0.0; }
 
 #ifndef KMX_EMU_REAL_CONV  // the "real convolution" build compiles a transformed copy of conv_mfma.hip / conv_kernel.h instead
 namespace {

@@ -80,6 +80,7 @@ uint64_t fnv(const void* p, size_t n) {
 size_t argBytes(const std::string& name) {
   using namespace kmx;
   if(name.find("convMfmaKernel") != std::string::npos) return sizeof(ConvArgs);
+  if(name.find("convChainKernel") != std::string::npos) return sizeof(ConvChainArgs);
   if(name.find("inputExpandKernel") != std::string::npos) return sizeof(InputArgs);
   if(name.find("gpoolApply") != std::string::npos) return sizeof(GPoolArgs);
   if(name.find("policyFinal") != std::string::npos) return sizeof(PolicyArgs);
