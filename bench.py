@@ -190,40 +190,71 @@ def caller_rates(model_path, tmp):
             out["reference_benchmark_nn_evals_per_s"] = float(m[-1][1])
             out["reference_benchmark"] = ("katago benchmark -v 8000 -t 1024 -boardsize 19 (4 positions), unmodified reference search on fibers "
                                           "(16 per OS thread), this repo's NNEvaluator + leaf batcher: %s visits/s, avg device batch %s rows" % (m[-1][0], m[-1][2]))
-    cfg_sp = os.path.join(REPO, "tests", "configs", "selfplay_tiny.cfg")
-    if os.path.exists(hipx) and os.path.exists(cfg_sp):
-        # BASELINE configs[2]: `selfplay`, 8 parallel games on this GPU, the visit counts of cpp/configs/training/selfplay8mainb18.cfg
-        # (2000 / 350 cheap), every game's 8 search threads as fibers on the game's own OS thread (8 leaves in flight per game).
-        # A full-length game costs ~190 k NN rows (250 moves x ~760 visits): the games here are cut after 6 moves so that the run
-        # takes seconds - NN rows/s is the measured, transferable number; games/hour for full-length games is DERIVED from it.
-        import shutil
-        import tempfile
-
-        d = tempfile.mkdtemp(prefix="kmx_bench_selfplay_", dir=tmp)
-        try:
-            os.makedirs(os.path.join(d, "models"))
-            shutil.copy(model_path, os.path.join(d, "models", "b18c384nbt-s1-d1.bin"))
-            moves_cap = 6
-            over = ("numGameThreads=8,numSearchThreads=8,nnMaxBatchSize=64,dataBoardLen=19,bSizes=19,bSizeRelProbs=1,maxMovesPerGame=%d,maxVisits=2000,"
-                    "cheapSearchVisits=350,cheapSearchProb=0.75,reducedVisitsMin=350,maxRowsPerTrainFile=20000,maxDataQueueSize=2000,"
-                    "nnCacheSizePowerOfTwo=18,nnMutexPoolSizePowerOfTwo=14,logGamesEvery=1000,numNNServerThreadsPerModel=2" % moves_cap)
-            env = dict(os.environ, KATAMX_LEAVES_PER_THREAD="8")
-            r = subprocess.run([hipx, "selfplay", "-config", cfg_sp, "-models-dir", os.path.join(d, "models"), "-output-dir", os.path.join(d, "out"),
-                                "-max-games-total", "8", "-override-config", over], capture_output=True, text=True, timeout=120, cwd=d, env=env)
-            log = r.stdout + r.stderr
-            if r.returncode == 0 and "Total selfplay runtime (seconds): " in log:
-                games = int(log.split("Total games: ")[1].split()[0])
-                secs = float(log.split("Total selfplay runtime (seconds): ")[1].split()[0])
-                rows = int(log.split("Final NN rows: ")[1].split()[0])
-                out["selfplay_nn_rows_per_s"] = round(rows / secs, 1)
-                rows_per_move = rows / float(games * moves_cap)
-                out["selfplay_games_per_hour_250_move_games_derived"] = round(rows / secs * 3600.0 / (rows_per_move * 250.0), 1)
-                out["selfplay"] = ("katago selfplay (command/selfplay.cpp:388-389), b18c384nbt 19x19 random weights, 8 game threads x 8 search threads on "
-                                   "fibers, maxVisits 2000 / cheap 350 (selfplay8mainb18.cfg), games cut after %d moves: %d games, %d NN rows in %.1f s "
-                                   "(%.0f rows per move); games/hour is derived for 250-move games from the measured rows/s" % (moves_cap, games, rows, secs, rows_per_move))
-        finally:
-            shutil.rmtree(d, ignore_errors=True)
+    if os.path.exists(hipx):
+        # BASELINE configs[2], the second half of the metric: games/hour as the reference defines it (command/selfplay.cpp:388-389) -
+        # `selfplay` with 8 parallel games on this GPU, the reference's production settings (tools/selfplay_cfg.py =
+        # cpp/configs/training/selfplay8mainb18.cfg: 2000 / 350 visits, its rules, komi, forks ...), 19x19 only, every game's 8 search
+        # threads as fibers on the game's own OS thread (8 leaves in flight per game), games played to the reference's OWN end conditions.
+        # 8 full-length games of a random-weight net take a few minutes; KMX_BENCH_SELFPLAY_TIMEOUT (seconds, default 420; 0 skips the
+        # leg) bounds it: a run that is cut short reports its NN rows/s and no games/hour - the figure is measured or absent, never derived.
+        out.update(selfplay_rates(hipx, model_path, tmp))
     return out
+
+
+def selfplay_rates(binary, model_path, tmp, game_threads=8, search_threads=8, timeout_s=None):
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import selfplay_cfg
+
+    if timeout_s is None:
+        timeout_s = int(os.environ.get("KMX_BENCH_SELFPLAY_TIMEOUT", "420"))
+    if timeout_s <= 0:
+        return {}
+    d = tempfile.mkdtemp(prefix="kmx_bench_selfplay_", dir=tmp)
+    try:
+        os.makedirs(os.path.join(d, "models"))
+        shutil.copy(model_path, os.path.join(d, "models", "b18c384nbt-s1-d1.bin"))
+        cfg = selfplay_cfg.write(os.path.join(d, "main.cfg"), numGameThreads=game_threads, numSearchThreads=search_threads, nnMaxBatchSize=64,
+                                 logGamesEvery=1000, switchNetsMidGame="false", nnCacheSizePowerOfTwo=21, nnMutexPoolSizePowerOfTwo=16,
+                                 **selfplay_cfg.ONLY_19)
+        env = dict(os.environ, KATAMX_LEAVES_PER_THREAD=str(search_threads))
+        p = subprocess.Popen([binary, "selfplay", "-config", cfg, "-models-dir", os.path.join(d, "models"), "-output-dir", os.path.join(d, "out"),
+                              "-max-games-total", str(game_threads)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=d, env=env)
+        try:
+            log, _ = p.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            import signal
+
+            p.send_signal(signal.SIGINT)  # the reference stops its games, writes its totals and exits cleanly
+            try:
+                log, _ = p.communicate(timeout=60)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                log, _ = p.communicate()
+        g = lambda k: float((re.findall(k + r": ([\d.]+)", log) or ["nan"])[-1])
+        secs, total = g(r"Total selfplay runtime \(seconds\)"), g("Total games")
+        rows, moves, fin, batches = g("Final NN rows"), g("Final moves played"), g("Final games finished"), g("Final NN batches")
+        if not secs > 0 or not rows > 0:
+            return {"selfplay_error": log[-300:]}
+        out = {"selfplay_nn_rows_per_s": round(rows / secs, 1)}
+        what = ("katago selfplay (command/selfplay.cpp), b18c384nbt 19x19 random weights, %d game threads x %d search threads on fibers, the reference's "
+                "production settings (selfplay8mainb18.cfg: 2000 / 350 visits), product path (own evaluator + featuriser + leaf batcher)" % (game_threads, search_threads))
+        if fin >= game_threads and "Exited cleanly after signal" not in log:
+            out["selfplay_games_per_hour"] = round(fin * 3600.0 / secs, 1)
+            out["selfplay_games_per_hour_as_reference_counts"] = round(total * 3600.0 / secs, 1)
+            out["selfplay"] = ("%s: %d full-length games (reference's own end conditions) finished in %.1f s - MEASURED, finished games x 3600 / 'Total selfplay "
+                               "runtime'; the reference's own line counts 'Total games' = %d (it adds one per game thread at shutdown, selfplay.cpp:293); %.0f moves and "
+                               "%.0f NN rows per game, average device batch %.1f rows" % (what, fin, secs, total, moves / fin, rows / fin, rows / max(batches, 1)))
+        else:
+            out["selfplay"] = ("%s: interrupted after %.0f s with %d of %d games finished - NN rows/s only, no games/hour (average device batch %.1f rows)"
+                               % (what, secs, fin, game_threads, rows / max(batches, 1)))
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def small_batch_rates(nn, handle, sp, gl, sym, opt, dtype, sizes=(1, 8, 32, 64), reps=40, warm=8):
