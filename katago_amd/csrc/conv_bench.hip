@@ -26,9 +26,8 @@ hipError_t launchVariant(int ks, int cfg, int variant, const ConvArgs& a, hipStr
   V(3, 2, 3, 3, 2048) V(3, 2, 3, 3, 2049) V(3, 2, 3, 3, 2052) V(3, 2, 3, 3, 2056) V(1, 2, 3, 3, 2048) V(3, 1, 3, 2, 2048) V(3, 1, 1, 2, 2048)
   V(3, 2, 3, 3, 1) V(3, 2, 3, 3, 2) V(3, 2, 3, 3, 4) V(3, 2, 3, 3, 5) V(3, 2, 3, 3, 512) V(3, 2, 3, 3, 1024)
   V(3, 2, 3, 2, 0) V(3, 2, 3, 4, 0) V(3, 2, 3, 4, 2048)
-  V(3, 2, 3, 3, 16384 + 2048)  // ABL_TWOLOADERS
   V(3, 2, 3, 3, 131072) V(1, 2, 3, 3, 131072) V(3, 1, 3, 2, 131072)  // ABL_BATCHED: the round-2 form of a step, for A/B
-  V(3, 2, 3, 3, 0) V(3, 2, 3, 3, 32768) V(3, 2, 3, 3, 65536) V(3, 2, 3, 3, 32768 + 65536)  // product shape again / ABL_NT_EPI / ABL_NT_DMA / both
+  V(3, 2, 3, 3, 0)
 #undef V
   return hipErrorInvalidValue;
 }
@@ -98,7 +97,7 @@ double benchConv(int ks, int cfg, int variant, int cin, int cout, int batch, int
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   const int r2 = variant - 2000, r3 = variant - 3000;  // variant = D*1000 + ABL with D in {2,3} for the timing variants
-  if((r2 >= 2048 && r2 < 2304) || (r3 >= 2048 && r3 < 2304) || variant == 3000 + 6144 || variant == 4000 + 6144 || variant == 4000 + 2048 || variant == 3000 + 8192 + 2048 || variant == 3000 + 16384 + 2048) {  // ABL_TIMING: cycle sums of the last launch, one line per wave
+  if((r2 >= 2048 && r2 < 2304) || (r3 >= 2048 && r3 < 2304) || variant == 4000 + 2048) {  // ABL_TIMING: cycle sums of the last launch, one line per wave
     unsigned long long h[64];
     hipCheck(hipMemcpy(h, dbg.get(), sizeof(h), hipMemcpyDeviceToHost), "copy timing");
     const int nw = (cfg / 10) * 4;

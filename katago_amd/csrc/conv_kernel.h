@@ -62,23 +62,13 @@ constexpr int MAXLEN = 19;
 enum { ABL_NO_EPILOGUE = 1, ABL_NO_COMPUTE = 2, ABL_NO_DMA = 4, ABL_NO_LDS_READ = 8, ABL_NO_VMWAIT = 16, ABL_NO_W_DMA = 32, ABL_NO_A_DMA = 64,
        ABL_EPI_NOACT = 512, ABL_EPI_NOSTORE = 1024,
        ABL_TIMING = 2048 /* s_memtime stamps between the segments of a step, summed per wave into ConvArgs::dbg */,
-       ABL_TWOLOADERS = 16384 /* the previous division of the DMA work in the 8-wave 3x3 / 5x5 shapes: weights by waves 0-3, board image by waves 4-7 */,
-       ABL_NT_EPI = 32768 /* EXPERIMENT: the epilogue's stores and residual loads carry the non-temporal hint (streaming data: written once, read once by a later launch) */,
-       ABL_NT_DMA = 65536 /* EXPERIMENT: the board image's LDS-DMA requests carry the non-temporal hint (aux = 2): each CU reads its board once */,
-       ABL_BATCHED = 131072 /* the round-2 form of a step (A/B): the six fragment reads of a half-step as one batch behind its first MFMA, the step's LDS-DMA requests as one batch between the halves */,
-       ABL_PRIO = 8192 /* EXPERIMENT: waves 4-7 (the younger wave of each SIMD, which loses the issue arbitration) run the main loop at s_setprio 1 */,
-       ABL_BP2 = 4096 /* EXPERIMENT, not an ablation: work-group barrier on even taps only (Geom::BP = 2). Carried in this
-                         parameter so that the product kernels (ABL = 0) keep their symbols and their code. */ };
+       ABL_BATCHED = 131072 /* the round-2 form of a step (A/B): the six fragment reads of a half-step as one batch behind its first MFMA, the step's LDS-DMA requests as one batch between the halves */, };
 
-// BP = barrier period in taps (experiment; 1 in the product): with BP = 2 the work-group synchronises on even taps only.
-// A slab is then overwritten two steps after its last read with possibly no barrier in between, so the ring holds one
-// slot more (D + 2), and at a barrier the slabs of the next TWO steps must have landed (one when the next step has a
-// barrier of its own, i.e. at the last tap of a chunk).
 // CW = waves along the CELL dimension: 4 (each owns 3 tiles of 32 cells; every product shape of rounds 1-3) or 12 (each owns ONE
 // tile: the small-batch shape, see conv_mfma.hip) - CW * MTW * 32 = 384 >= 361 cells either way.
-template <int KS, int WN, int WNW, int D, int BP = 1, int CW = 4>
+template <int KS, int WN, int WNW, int D, int CW = 4>
 struct Geom {
-  static_assert(CW == 4 || (CW == 12 && WN == 1 && WNW == 1 && BP == 1), "12 cell waves exist for the 32-channel work-group only");
+  static_assert(CW == 4 || (CW == 12 && WN == 1 && WNW == 1), "12 cell waves exist for the 32-channel work-group only");
   static constexpr int MTW = 12 / CW;  // 32-cell tiles per wave
   static constexpr int NWAVES = CW * WNW;
   static constexpr int NTHREADS = NWAVES * 64;
@@ -112,9 +102,7 @@ struct Geom {
   static constexpr int PPS = SPREAD ? pickPPS() : NPA;
   static constexpr int LS = (NPA + PPS - 1) / PPS;
   static constexpr int NSA = SPREAD ? 2 : D + 1;
-  static constexpr int NSW = D + BP;
-  static_assert(BP == 1 || (BP == 2 && WNW == 2 && CW == 4 && KS * KS > 1 && (KS * KS) % 2 == 1 && D >= 3),
-                "the even-tap barrier variant exists for the 8-wave 3x3 / 5x5 shapes with a ring of at least 3 requests");
+  static constexpr int NSW = D + 1;
   static constexpr int SLACK_BYTES = 1024;  // destination of padding / past-the-end DMA instructions (never read; shared by all waves)
   static constexpr int NPM = (384 + NTHREADS - 1) / NTHREADS;          // 4-byte DMA instructions per wave for the mask
   static constexpr int MASK_BYTES = NPM * NTHREADS * 4;
@@ -133,7 +121,6 @@ struct Geom {
   static constexpr int VMCNT_PRO = SPREAD ? PPS + (D - 1) * (NPW + PPS) : (D - 1) * (NPW + NPA);
   // ROLES: a weight wave has only slabs in flight, an image wave only image pieces
   static constexpr int VMCNT_W = (D - 2) * NPW, VMCNT_PRO_W = (D - 1) * NPW;
-  static constexpr int VMCNT_W2 = D >= 3 ? (D - 3) * NPW : 0;  // BP == 2, a barrier whose next step has none: slabs s+1 AND s+2 landed
   static constexpr int VMCNT_A1 = (D - 2) * NPA, VMCNT_PRO_A1 = (D - 1) * NPA;  // 1x1: whole images ride the ring
 };
 
@@ -194,10 +181,6 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned ldsWaveBase) {
   __builtin_amdgcn_global_load_lds(
     (const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)(size_t)ldsWaveBase, 16, 0, 0);
 }
-__device__ __forceinline__ void dma16nt(const void* gsrc, unsigned ldsWaveBase) {  // aux = 2: non-temporal
-  __builtin_amdgcn_global_load_lds(
-    (const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)(size_t)ldsWaveBase, 16, 0, 2);
-}
 __device__ __forceinline__ void dma4(const void* gsrc, unsigned ldsWaveBase) {
   __builtin_amdgcn_global_load_lds(
     (const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)(size_t)ldsWaveBase, 4, 0, 0);
@@ -208,8 +191,7 @@ __global__ __launch_bounds__(64 * CW * WNW) __attribute__((amdgpu_waves_per_eu(C
   typedef typename TR::T T;
   typedef typename TR::V8 V8;
   typedef typename TR::V4 V4;
-  constexpr int BP = (ABL & ABL_BP2) ? 2 : 1;
-  typedef Geom<KS, WN, WNW, D, BP, CW> G;
+  typedef Geom<KS, WN, WNW, D, CW> G;
   constexpr int MT = G::MTW;  // (shadows convk::MT, the value of the 4-cell-wave shapes)
   constexpr int HALO = G::HALO, NT = G::NT, NPA = G::NPA, NPW = G::NPW, NWAVES = G::NWAVES;
   constexpr bool SPREAD = G::SPREAD;
@@ -266,9 +248,9 @@ __global__ __launch_bounds__(64 * CW * WNW) __attribute__((amdgpu_waves_per_eu(C
   // the older wave of each SIMD: the matrix core serves them first, and they used to idle ~27 % of the loop at the barrier
   // waiting for waves 4-7, which multiply at lower priority AND paid ~330 cycles per step for their image requests
   // (an LDS-DMA instruction costs its wave 100-200 cycles of issue). With every request on the waves that have the slack,
-  // the younger waves only multiply. (tools/conv_timing.py; ABL_TWOLOADERS restores the previous division for comparison.)
+  // the younger waves only multiply. (tools/conv_timing.py)
   // (possible when the image pieces have all been requested before the slab that is waited for at the last tap: LS <= NT + 1 - D)
-  constexpr bool ONE = ROLES && CW == 4 && SPREAD && BP == 1 && G::LS <= NT + 1 - D && !(ABL & ABL_TWOLOADERS);
+  constexpr bool ONE = ROLES && CW == 4 && SPREAD && G::LS <= NT + 1 - D;
   // the step's fragment reads (and, in the ONE division, its DMA requests) spread over its MFMAs: needs a slot per read in each half
   constexpr bool SPREAD_STEP = WN * MT >= WN + MT && !(ABL & (ABL_BATCHED | ABL_TIMING));
   constexpr int SLOTS = WN * MT - (WN + MT);                           // MFMAs of a half-step that carry no fragment read
@@ -328,8 +310,7 @@ __global__ __launch_bounds__(64 * CW * WNW) __attribute__((amdgpu_waves_per_eu(C
     const bool live = j >= 0 && chunk < nChunks && pbase * 16 < G::ACT_BYTES;
     const unsigned off = srcOff[jj];
     const char* src = (off & 0x80000000u) ? zero + (off & 0x7fffffffu) : inBoard + off;
-    if(ABL & ABL_NT_DMA) dma16nt(src, live ? bufA + (chunk % G::NSA) * G::ACT_BYTES + pbase * 16 : mySlack);
-    else dma16(src, live ? bufA + (chunk % G::NSA) * G::ACT_BYTES + pbase * 16 : mySlack);
+    dma16(src, live ? bufA + (chunk % G::NSA) * G::ACT_BYTES + pbase * 16 : mySlack);
     if(j >= 0) srcOff[jj] = off + KCHUNK * sizeof(T);
   };
 
@@ -564,11 +545,7 @@ __global__ __launch_bounds__(64 * CW * WNW) __attribute__((amdgpu_waves_per_eu(C
     }
     if(!ROLES) waitVm<G::VMCNT>();
     else if(wLoader) {
-      if constexpr(BP == 2) {
-        if(t + 1 < NT) waitVm<G::VMCNT_W2>();  // the next step has no barrier: publish two slabs
-        else waitVm<G::VMCNT_W>();
-      }
-      else waitVm<G::VMCNT_W>();
+      waitVm<G::VMCNT_W>();
     }
     else if(!SPREAD) waitVm<G::VMCNT_A1>();
     else if(t == NT - 1) waitVm<0>();  // the next chunk's image, first read at the end of this step
@@ -592,7 +569,6 @@ __global__ __launch_bounds__(64 * CW * WNW) __attribute__((amdgpu_waves_per_eu(C
     seg[which] += now - tPrev;
     tPrev = now;
   };
-  if((ABL & ABL_PRIO) && CW == 4 && wave >= 4) __builtin_amdgcn_s_setprio(1);
   if(ABL & ABL_TIMING) tPrev = __builtin_readcyclecounter();
   const unsigned long long tLoop0 = tPrev;
   int step = 0;
@@ -601,11 +577,9 @@ __global__ __launch_bounds__(64 * CW * WNW) __attribute__((amdgpu_waves_per_eu(C
     const unsigned nextA = (unsigned)((chunk + 1) % G::NSA) * G::ACT_BYTES;
 #pragma unroll
     for(int t = 0; t < NT; t++, step++) {
-      if(BP == 1 || t % 2 == 0) {
-        waitStep(t);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-      }
+      waitStep(t);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
       stamp(0);
       // The compiler's own s_waitcnt before an MFMA drains ALL outstanding LDS reads (lgkmcnt(0)), so each batch of
       // reads is issued right AFTER the first MFMA of the other fragment set: the wait it causes then only covers
@@ -676,7 +650,6 @@ __global__ __launch_bounds__(64 * CW * WNW) __attribute__((amdgpu_waves_per_eu(C
       stamp(3);
     }
   }
-  if(ABL & ABL_PRIO) __builtin_amdgcn_s_setprio(0);
   if(!(ABL & ABL_NO_DMA)) waitVm<0>();  // retire the trailing dummies before the LDS is reused / the wave exits
   const unsigned long long tLoop1 = (ABL & ABL_TIMING) ? __builtin_readcyclecounter() : 0;
 
@@ -730,7 +703,7 @@ __global__ __launch_bounds__(64 * CW * WNW) __attribute__((amdgpu_waves_per_eu(C
     for(int j = 0; j < 2; j++) {
       const int c = cout0 + wn * (32 * WN) + ct * 32 + 16 * j + 8 * khalf;
       const T* src = (c >= a.rawBegin && c < a.rawEnd) ? rrow + c : (const T*)zero;
-      dst[j] = (ABL & ABL_NT_EPI) ? __builtin_nontemporal_load((const u32x4*)src) : *(const u32x4*)src;
+      dst[j] = *(const u32x4*)src;
     }
   };
   if(RESID) loadResid(0, 0, rq[0]);
@@ -810,7 +783,6 @@ __global__ __launch_bounds__(64 * CW * WNW) __attribute__((amdgpu_waves_per_eu(C
           const int c = cout0 + chTile + 16 * j + 8 * khalf;
           T* const dst = (live && c >= a.rawBegin && c < a.rawEnd) ? rawRow + c : trash;
           if(ABL & ABL_EPI_NOSTORE) asm volatile("" ::"v"(rawQ[j]));
-          else if(ABL & ABL_NT_EPI) __builtin_nontemporal_store(rawQ[j], (u32x4*)dst);
           else *(u32x4*)dst = rawQ[j];
         }
       }
@@ -822,7 +794,6 @@ __global__ __launch_bounds__(64 * CW * WNW) __attribute__((amdgpu_waves_per_eu(C
           const int c = cout0 + chTile + 16 * j + 8 * khalf;
           T* const dst = (live && c >= a.actBegin && c < a.actEnd) ? actRow + c : trash;
           if(ABL & ABL_EPI_NOSTORE) asm volatile("" ::"v"(actQ[j]));
-          else if(ABL & ABL_NT_EPI) __builtin_nontemporal_store(actQ[j], (u32x4*)dst);
           else *(u32x4*)dst = actQ[j];
         }
       }
@@ -850,7 +821,7 @@ __global__ __launch_bounds__(64 * CW * WNW) __attribute__((amdgpu_waves_per_eu(C
 
 template <class TR, int KS, int WN, int WNW, int D, int ABL, int CW = 4>
 hipError_t launchOne(const ConvArgs& a, hipStream_t stream) {
-  typedef Geom<KS, WN, WNW, D, (ABL & ABL_BP2) ? 2 : 1, CW> G;
+  typedef Geom<KS, WN, WNW, D, CW> G;
   constexpr int ldsBytes = G::LDS_BYTES;
   static_assert(ldsBytes <= 160 * 1024, "LDS budget exceeded");
   static_assert(!G::SPREAD || G::LS + (G::ROLES ? 1 : D) <= G::NT, "image pieces must land within their chunk");

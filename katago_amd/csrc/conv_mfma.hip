@@ -2,6 +2,7 @@
 #include <cstdlib>
 
 #include "conv_kernel.h"
+#include "conv_small_kernel.h"
 
 namespace kmx {
 
@@ -45,23 +46,22 @@ bool cw12Enabled() {
   return on;
 }
 constexpr int CFG_CW12 = 111;
-// EXPERIMENT (off unless KMX_CONV_BP2=1): the 8-wave 3x3 shapes with a work-group barrier on even
-// taps only and a ring of D + 2 slabs. Not yet run on hardware.
-bool evenTapBarriers() {
+// The small-batch 3x3 shape with dedicated fetching waves, cfg 118 (conv_small_kernel.h, round 4): a board x 32 channels like cfg 11 and
+// cfg 111, four multiplying waves of three cell tiles each and four waves that issue every LDS-DMA request. KMX_CONV_LOADERS=0 / 1
+// overrides the default.
+constexpr int CFG_LOADERS = 118;
+constexpr bool kLoadersDefault = true;
+bool loadersEnabled() {
   static const bool on = [] {
-    const char* e = getenv("KMX_CONV_BP2");
-    return e != nullptr && e[0] == '1';
+    const char* e = getenv("KMX_CONV_LOADERS");
+    return e != nullptr ? e[0] == '1' : kLoadersDefault;
   }();
   return on;
 }
-
 template <class TR>
 hipError_t launchT(int ks, int cfg, const ConvArgs& a, hipStream_t stream) {
-  if(ks == 3 && (cfg == 22 || cfg == 23) && evenTapBarriers()) {
-    if(cfg == 22) return launchOne<TR, 3, 2, 2, 3, ABL_BP2>(a, stream);
-    return launchOne<TR, 3, 3, 2, 3, ABL_BP2>(a, stream);
-  }
   if(ks == 3 && cfg == CFG_CW12) return launchOne<TR, 3, 1, 1, 2, 0, 12>(a, stream);
+  if(ks == 3 && cfg == CFG_LOADERS) return smallk::launchSmall<TR>(a, stream);
 #define KMX_CFG(KS_, WNW_, WN_, D_) \
   if(ks == KS_ && cfg == 10 * WNW_ + WN_) return launchOne<TR, KS_, WN_, WNW_, D_, 0>(a, stream);
   KMX_CFG_LIST(KMX_CFG)
@@ -80,7 +80,7 @@ hipError_t launchConv(int dtype, int ks, int cfg, const ConvArgs& a, hipStream_t
 }
 
 bool convCfgInstantiated(int ks, int cfg) {
-  if(ks == 3 && cfg == CFG_CW12) return true;
+  if(ks == 3 && (cfg == CFG_CW12 || cfg == CFG_LOADERS)) return true;
 #define KMX_CFG(KS_, WNW_, WN_, D_) \
   if(ks == KS_ && cfg == 10 * WNW_ + WN_) return true;
   KMX_CFG_LIST(KMX_CFG)
@@ -113,6 +113,13 @@ int chooseConvCfg(int ks, int coutPad, int batch) {
     const char* e = getenv("KMX_CONV_CW12_MAX_WGS");
     return e ? atoi(e) : 256;
   }();
+  // the fetching-waves shape while it is the only work-group on its CU (134 VGPRs x 8 waves: one work-group per CU;
+  // KMX_CONV_LOADERS_MAX_WGS moves the limit for scans beyond it)
+  static const int loadersMaxWgs = [] {
+    const char* e = getenv("KMX_CONV_LOADERS_MAX_WGS");
+    return e ? atoi(e) : 256;
+  }();
+  if(ks == 3 && loadersEnabled() && batch * tiles <= loadersMaxWgs) return CFG_LOADERS;
   if(ks == 3 && cw12Enabled() && batch * tiles <= cw12MaxWgs) return CFG_CW12;
   // 3x3/5x5 narrow shapes keep two work-groups per CU (LDS), 1x1 shapes one
   const int round = ks == 1 ? 200 : 420;

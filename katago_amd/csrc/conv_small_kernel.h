@@ -1,0 +1,378 @@
+// conv_small_kernel.h — the 3x3 convolution for SMALL batches: four waves multiply, four waves only fetch (round 4).
+//
+// While the chip is not full a layer takes as long as ONE of its work-groups does (they all run side by side on idle CUs), and a
+// small pass is bound by the time INSIDE its kernels: a rocprofv3 trace of batch-8 passes of b18c384nbt shows 2.39 ms of kernel
+// time in 2.62 ms of wall time, the 73 3x3 convolutions 21.4 us each (profiles/r04_steps/call1). What a step of such a
+// work-group costs, per shape of conv_kernel.h (a work-group = one board x 32 output channels in all of them):
+//   * 4 waves x 3 cell tiles (cfg 11): 6 MFMAs = 192 matrix-core cycles per wave and step, but 697 cycles per step - every wave also
+//     issues two LDS-DMA requests per step at 100-160 cycles of issue each, a third of them padding (round 3 stamps);
+//   * 12 waves x 1 cell tile (cfg 111, round 3): at most one request per wave and step, but every wave reads the SAME 2 KB weight
+//     slab for its 2 MFMAs - 48 KB of LDS reads per step, 384 cycles at 128 B/cycle: ~600 cycles per step.
+// This shape keeps the reuse of the first (a wave's weight fragments serve three cell tiles: 32 KB of LDS reads per step) and takes the
+// requests off the multiplying waves altogether: waves 0-3 do what the four waves of cfg 11 do minus every request; waves 4-7 - one per
+// SIMD, beside a multiplying wave - issue the slab and image requests of the step D steps ahead, wait for what the next step needs
+// and meet the others at the step's barrier. Same decomposition (board x 32 channels: same DMA bytes, same LDS images), same MFMAs
+// per output in the same K order (chunk, tap, k half) and the same epilogue arithmetic: BIT-IDENTICAL to every other shape
+// (tests/test_kernels_latest_completion.py on the CPU emulation, tests/test_gpu_layers.py on the MI355X).
+#ifndef KMX_CONV_SMALL_KERNEL_H_
+#define KMX_CONV_SMALL_KERNEL_H_
+
+#include <atomic>
+
+#include "conv_kernel.h"
+
+namespace kmx {
+namespace smallk {
+using convk::dma16;
+using convk::dma4;
+using convk::waitVm;
+using convk::ROWB;
+
+constexpr int NT = 9, HALO = 1, MT = 3;
+constexpr int NCOMPUTE = 4, NLOAD = 4, NWAVES = NCOMPUTE + NLOAD, NTHREADS = NWAVES * 64;
+constexpr int NTILE = 32;                 // output channels per work-group
+constexpr int D = 3, NSW = D + 1;         // requests three steps ahead, ring of four slabs
+constexpr int HPMAX = 21 * 21;
+constexpr int NPA = (HPMAX * 4 + NLOAD * 64 - 1) / (NLOAD * 64);  // 7 image requests per loader wave and chunk: one per tap 0..6
+constexpr int ACT_BYTES = NPA * NLOAD * 64 * 16;                   // 28672
+constexpr int NSA = 2;
+constexpr int W_BYTES = NTILE * ROWB;     // 2048: one request of waves 4 and 5 each
+constexpr int SLACK_BYTES = 1024;
+constexpr int MASK_BYTES = NTHREADS * 4;
+constexpr int PARAM_BYTES = 256 * 4;      // scale | bias | per-board bias of the 32 channels: 96 floats, one 4-byte request per lane of waves 0-3
+constexpr int RING_OFFSET = NSA * ACT_BYTES;
+constexpr int SLACK_OFFSET = RING_OFFSET + NSW * W_BYTES;
+constexpr int MASK_OFFSET = SLACK_OFFSET + SLACK_BYTES;
+constexpr int PARAM_OFFSET = MASK_OFFSET + MASK_BYTES;
+constexpr int LDS_BYTES = PARAM_OFFSET + PARAM_BYTES;
+static_assert(NPA <= NT - 2, "the next image's requests are all issued two taps before the chunk ends");
+
+template <class TR>
+__global__ __launch_bounds__(NTHREADS) void convSmallKernel(const ConvArgs a) {
+  typedef typename TR::T T;
+  typedef typename TR::V8 V8;
+  typedef typename TR::V4 V4;
+  extern __shared__ __attribute__((aligned(256))) char smemSmall[];
+  const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smemSmall;
+  const unsigned bufW = ldsBase + RING_OFFSET;
+  const unsigned slack = ldsBase + SLACK_OFFSET;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave >= NCOMPUTE;  // wave-uniform
+  const int lw = wave - NCOMPUTE;        // index among the loader waves
+  const int wm = wave;                   // cell-tile group of a multiplying wave
+  const int n = blockIdx.y;
+  const int cout0 = blockIdx.x * NTILE;
+  const int X = a.X, Y = a.Y, S = X * Y;
+  const int W2 = X + 2 * HALO, HP = W2 * (Y + 2 * HALO);
+  const int inC = a.inC;
+  const int nChunks = a.nChunks;
+  const int nSteps = nChunks * NT;
+  const char* const zero = (const char*)a.zeroPage;
+  // GEMM column -> board cell, lane -> position inside a tile: as conv_kernel.h
+  const int mainCols = X >= 16 ? 16 * Y : 0;
+  const int restW = X - 16;
+  auto cellOf = [&](int m) -> int {
+    if(m < mainCols) return (m >> 4) * X + (m & 15);
+    if(X < 16) return m;
+    const int k = m - mainCols;
+    const int yy = k / restW;
+    return yy * X + 16 + (k - yy * restW);
+  };
+  auto posOf = [](int l) -> int { return l < 4 ? l : l < 12 ? l + 12 : l < 16 ? l - 8 : l < 20 ? l + 8 : l < 28 ? l - 12 : l; };
+  const int myPos = posOf(lane & 31);
+
+  // ---- prologue, every wave: the board's mask; waves 0-3: the tile's parameters ----
+  {
+    const int cellIdx = wave * 64 + lane;
+    dma4(cellIdx < S ? (const void*)(a.mask + (size_t)n * S + cellIdx) : (const void*)zero, ldsBase + MASK_OFFSET + wave * 256);
+  }
+  if(!loader) {
+    const int idx = wave * 64 + lane;  // 0..255: scale [0,32) | bias [64,96) | per-board bias [128,160)
+    const int arr = idx >> 6, c = idx & 63;
+    const float* psrc = (const float*)zero;
+    if(c < NTILE) {
+      if(arr == 0) psrc = a.scale + cout0 + c;
+      else if(arr == 1) psrc = a.bias + cout0 + c;
+      else if(arr == 2 && a.ncBias != nullptr) psrc = a.ncBias + (size_t)n * a.ncBiasStride + cout0 + c;
+    }
+    dma4(psrc, ldsBase + PARAM_OFFSET + wave * 256);
+  }
+
+  if(loader) {
+    // =================================================== the fetching waves ===================================================
+    const char* const inBoard = (const char*)a.in + (size_t)n * S * inC * sizeof(T);
+    const char* const wBase = (const char*)a.w + (size_t)cout0 * ROWB;
+    const size_t wSlabStride = (size_t)a.coutPad * ROWB;
+    unsigned srcOff[NPA];  // byte offset from this board's tensor, or (bit 31) the zero page; + 64 bytes per chunk
+#pragma unroll
+    for(int j = 0; j < NPA; j++) {
+      const int p = (j * NLOAD + lw) * 64 + lane;
+      const int hp = p >> 2;
+      const int slot = (p & 3) ^ ((hp >> 2) & 3);
+      unsigned off = 0x80000000u;
+      if(hp < HP) {
+        const int hy = hp / W2, hx = hp - hy * W2;
+        const int y = hy - HALO, x = hx - HALO;
+        if(y >= 0 && y < Y && x >= 0 && x < X) off = (unsigned)(((y * X + x) * inC + slot * 8) * (int)sizeof(T));
+      }
+      srcOff[j] = off;
+    }
+    const unsigned wOff = (unsigned)(lw * 64 + lane) * 16u;  // waves 4 and 5: their KiB of a slab
+    const bool slabWave = lw < 2;
+    auto issueW = [&](int step) {  // one request (waves 4, 5)
+      const bool live = step < nSteps;
+      const char* slab = wBase + (size_t)(live ? step : 0) * wSlabStride;
+      dma16(slab + wOff, live ? bufW + (unsigned)(step % NSW) * W_BYTES + (unsigned)lw * 1024u : slack);
+    };
+    auto issueA = [&](int chunk, int j) {  // request j of the image of `chunk`; the pointer then moves on to the next chunk
+      const bool live = chunk < nChunks;
+      const unsigned off = srcOff[j];
+      const char* src = (off & 0x80000000u) ? zero : inBoard + off;
+      dma16(src, live ? ldsBase + (unsigned)(chunk % NSA) * ACT_BYTES + (unsigned)((j * NLOAD + lw) * 64) * 16u : slack);
+      srcOff[j] = (off & 0x80000000u) ? off : off + KCHUNK * (unsigned)sizeof(T);
+    };
+    // fill the pipeline: image 0, slabs 0 .. D-1
+#pragma unroll
+    for(int j = 0; j < NPA; j++) issueA(0, j);
+    if(slabWave) {
+#pragma unroll
+      for(int s = 0; s < D; s++) issueW(s);
+    }
+    // slab 0 and image 0 (and the mask) have landed: in flight at most slabs 1 .. D-1
+    if(slabWave) waitVm<D - 1>();
+    else waitVm<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int step = 0;
+    for(int chunk = 0; chunk < nChunks; chunk++) {
+#pragma unroll
+      for(int t = 0; t < NT; t++, step++) {
+        // top of step s: slab s + 1 (requested in step s - 2, after that step's image request) has landed - and with it every image
+        // request issued before it; younger: the requests of step s - 1 (its image request at taps 0..6, its slab). A wave that
+        // fetches no slabs waits for all of its image requests where the next chunk's image is first read: the last tap.
+        if(slabWave) {
+          if((t + NT - 1) % NT < NPA) waitVm<2>();
+          else waitVm<1>();
+        }
+        else if(t == NT - 1) waitVm<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if(t < NPA) issueA(chunk + 1, t);
+        if(slabWave) issueW(step + D);
+      }
+    }
+    waitVm<0>();  // requests past the end went to the slack area: they must land before the LDS is released
+    return;
+  }
+
+  // ===================================================== the multiplying waves =====================================================
+  const unsigned khalf = lane >> 5;
+  const unsigned wXor = (lane >> 2) & 3;
+  unsigned wLane[2];
+#pragma unroll
+  for(int kk = 0; kk < 2; kk++) wLane[kk] = bufW + (unsigned)(lane & 31) * ROWB + (((kk * 2 + khalf) ^ wXor) << 4);
+  unsigned aRow4[MT];
+  int cellOfTile[MT];
+#pragma unroll
+  for(int pt = 0; pt < MT; pt++) {
+    int j = wm * (32 * MT) + pt * 32 + myPos;
+    j = cellOf(j < S ? j : S - 1);
+    cellOfTile[pt] = j;
+    const int y = j / X, x = j - y * X;
+    aRow4[pt] = (unsigned)((y + HALO) * W2 + (x + HALO)) << 2;
+  }
+  const unsigned c40 = khalf << 4;
+  const bool waveActive = wm * (32 * MT) < S;
+  auto ldsV8 = [&](unsigned addr) { return *(const __attribute__((address_space(3))) V8*)addr; };
+  auto ldsF4 = [&](unsigned addr) { return *(const __attribute__((address_space(3))) f32x4*)addr; };
+  auto ldsF1 = [&](unsigned addr) { return *(const __attribute__((address_space(3))) float*)addr; };
+
+  f32x16 acc[MT];
+#pragma unroll
+  for(int pt = 0; pt < MT; pt++)
+#pragma unroll
+    for(int r = 0; r < 16; r++) acc[pt][r] = 0.0f;
+
+  waitVm<0>();  // this wave's mask and parameter requests
+  __builtin_amdgcn_s_barrier();  // slab 0 and image 0 are published
+  asm volatile("" ::: "memory");
+  V8 wf[2], af[2][MT];
+  unsigned aAddr[MT];
+  // fragments of step 0, k half 0
+  {
+    wf[0] = ldsV8(wLane[0]);
+    unsigned sTap = (unsigned)(((0 - HALO) * W2 + (0 - HALO)) * 4) + (ldsBase >> 4);
+    asm volatile("" : "+s"(sTap));
+#pragma unroll
+    for(int pt = 0; pt < MT; pt++) {
+      const unsigned q4 = aRow4[pt] + sTap;
+      aAddr[pt] = (q4 << 4) | ((q4 ^ c40) & 0x30u);
+      af[0][pt] = ldsV8(aAddr[pt]);
+    }
+  }
+  int step = 0;
+  for(int chunk = 0; chunk < nChunks; chunk++) {
+    const unsigned curA = (unsigned)(chunk % NSA) * ACT_BYTES;
+    const unsigned nextA = (unsigned)((chunk + 1) % NSA) * ACT_BYTES;
+#pragma unroll
+    for(int t = 0; t < NT; t++, step++) {
+      __builtin_amdgcn_s_barrier();  // publishes slab step + 1 (and, at the last tap, the next chunk's image)
+      asm volatile("" ::: "memory");
+      // first k half: the MFMAs of fragment set 0; behind them, one by one, the reads of set 1 (this step's slab, this tap)
+      const unsigned wb1 = wLane[1] + (unsigned)(step % NSW) * W_BYTES;
+#pragma unroll
+      for(int pt = 0; pt < MT; pt++) {
+        acc[pt] = TR::mfma(wf[0], af[0][pt], acc[pt]);
+        __builtin_amdgcn_sched_barrier(0);
+        if(pt == 0) wf[1] = ldsV8(wb1);
+        af[1][pt] = ldsV8(aAddr[pt] ^ 0x20u);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // second k half; behind its MFMAs the reads of set 0 of the NEXT step (slab step + 1, next tap)
+      const unsigned wb0 = wLane[0] + (unsigned)((step + 1) % NSW) * W_BYTES;
+      {
+        const int tn = t + 1 < NT ? t + 1 : 0;
+        unsigned sTap = (unsigned)(((tn / 3 - HALO) * W2 + (tn % 3 - HALO)) * 4) + ((ldsBase + (t + 1 < NT ? curA : nextA)) >> 4);
+        asm volatile("" : "+s"(sTap));
+#pragma unroll
+        for(int pt = 0; pt < MT; pt++) {
+          const unsigned q4 = aRow4[pt] + sTap;
+          aAddr[pt] = (q4 << 4) | ((q4 ^ c40) & 0x30u);
+        }
+      }
+#pragma unroll
+      for(int pt = 0; pt < MT; pt++) {
+        acc[pt] = TR::mfma(wf[1], af[1][pt], acc[pt]);
+        __builtin_amdgcn_sched_barrier(0);
+        if(pt == 0) wf[0] = ldsV8(wb0);
+        af[0][pt] = ldsV8(aAddr[pt]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+
+  // ---- epilogue: conv_kernel.h's, for one 32-channel tile per wave and cell tile ----
+  if(!waveActive) return;
+  const unsigned maskAddr = ldsBase + MASK_OFFSET;
+  const unsigned scAddr = ldsBase + PARAM_OFFSET, biAddr = scAddr + 64 * 4, nbAddr = biAddr + 64 * 4;
+  const bool hasResid = a.resid != nullptr;
+  const bool hasNb = a.ncBias != nullptr;
+  const bool anyRaw = a.rawEnd > a.rawBegin, anyAct = a.actEnd > a.actBegin;
+  T* const rawBoard = (T*)a.rawOut + (size_t)n * S * a.rawC - a.rawBegin;
+  T* const actBoard = (T*)a.actOut + (size_t)n * S * a.actC - a.actBegin;
+  T* const trash = (T*)((char*)const_cast<void*>(a.zeroPage) + ZERO_PAGE_BYTES) + lane * 8;
+  auto epilogue = [&](auto kindTag, auto residTag) {
+    constexpr int KIND = decltype(kindTag)::value;
+    constexpr bool RESID = decltype(residTag)::value != 0;
+    u32x4 rq[2][2];
+    auto loadResid = [&](int pt, u32x4 (&dst)[2]) {
+      const T* const rrow = (const T*)a.resid + ((size_t)n * S + cellOfTile[pt]) * a.residC - a.rawBegin;
+#pragma unroll
+      for(int j = 0; j < 2; j++) {
+        const int c = cout0 + 16 * j + 8 * khalf;
+        const T* src = (c >= a.rawBegin && c < a.rawEnd) ? rrow + c : (const T*)zero;
+        dst[j] = *(const u32x4*)src;
+      }
+    };
+    if(RESID) loadResid(0, rq[0]);
+#pragma unroll
+    for(int pt = 0; pt < MT; pt++) {
+      const int cellBase = wm * (32 * MT) + pt * 32;
+      if(cellBase >= S) break;  // wave-uniform
+      const bool live = cellBase + myPos < S;
+      const int cell = cellOfTile[pt];
+      const unsigned onBits = ldsF1(maskAddr + cell * 4) == 1.0f ? 0xffffffffu : 0u;
+      T* const rawRow = rawBoard + (size_t)cell * a.rawC;
+      T* const actRow = actBoard + (size_t)cell * a.actC;
+      unsigned pOff = (unsigned)(4 * khalf) * 4u;
+      asm volatile("" : "+v"(pOff));
+      u32x2 rp[4], op[4];
+      u32x2 resP[4];
+      if(RESID) {
+        if(pt + 1 < MT) loadResid(pt + 1, rq[(pt + 1) & 1]);
+        unpair(rq[pt & 1], resP);
+      }
+#pragma unroll
+      for(int g = 0; g < 4; g++) {
+        const f32x4 sc = ldsF4(scAddr + pOff + 32 * g);
+        const f32x4 bi = ldsF4(biAddr + pOff + 32 * g);
+        f32x4 v;
+#pragma unroll
+        for(int i = 0; i < 4; i++) v[i] = acc[pt][4 * g + i];
+        if(hasNb) v += ldsF4(nbAddr + pOff + 32 * g);
+        if(RESID) {
+          const V4 rr = __builtin_bit_cast(V4, resP[g]);
+#pragma unroll
+          for(int i = 0; i < 4; i++) v[i] += TR::toFloat(rr[i]);
+        }
+        V4 r, o;
+#pragma unroll
+        for(int i = 0; i < 4; i++) r[i] = TR::fromFloat(v[i]);
+#pragma unroll
+        for(int i = 0; i < 4; i += 2) {
+          f32x2 x;
+          x[0] = v[i] * sc[i] + bi[i];
+          x[1] = v[i + 1] * sc[i + 1] + bi[i + 1];
+          const f32x2 y = actK2<KIND>(x);
+          o[i] = TR::fromFloat(y[0]);
+          o[i + 1] = TR::fromFloat(y[1]);
+        }
+        rp[g] = __builtin_bit_cast(u32x2, r);
+        op[g] = __builtin_bit_cast(u32x2, o);
+        op[g][0] &= onBits;
+        op[g][1] &= onBits;
+      }
+      if(RESID || anyRaw) {
+        u32x4 rawQ[2];
+        pairUp(rp, rawQ);
+#pragma unroll
+        for(int j = 0; j < 2; j++) {
+          const int c = cout0 + 16 * j + 8 * khalf;
+          T* const dst = (live && c >= a.rawBegin && c < a.rawEnd) ? rawRow + c : trash;
+          *(u32x4*)dst = rawQ[j];
+        }
+      }
+      if(RESID || anyAct) {
+        u32x4 actQ[2];
+        pairUp(op, actQ);
+#pragma unroll
+        for(int j = 0; j < 2; j++) {
+          const int c = cout0 + 16 * j + 8 * khalf;
+          T* const dst = (live && c >= a.actBegin && c < a.actEnd) ? actRow + c : trash;
+          *(u32x4*)dst = actQ[j];
+        }
+      }
+    }
+  };
+  withActKind(a.actKind, [&](auto kindTag) {
+    if(hasResid) epilogue(kindTag, ActKindTag<1>());
+    else epilogue(kindTag, ActKindTag<0>());
+  });
+}
+
+template <class TR>
+hipError_t launchSmall(const ConvArgs& a, hipStream_t stream) {
+  if(a.coutPad % NTILE != 0) return hipErrorInvalidValue;
+  auto kern = convSmallKernel<TR>;
+  constexpr int MAX_DEVICES = 64;  // the > 64 KiB LDS opt-in is per function AND device (conv_kernel.h launchOne)
+  static std::atomic<bool> attrSet[MAX_DEVICES];
+  int dev = 0;
+  hipError_t de = hipGetDevice(&dev);
+  if(de != hipSuccess) return de;
+  if(dev < 0 || dev >= MAX_DEVICES) return hipErrorInvalidDevice;
+  if(!attrSet[dev].load(std::memory_order_acquire)) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if(e != hipSuccess) return e;
+    attrSet[dev].store(true, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(kern, dim3(a.coutPad / NTILE, a.N, 1), dim3(NTHREADS), LDS_BYTES, stream, a);
+  return hipGetLastError();
+}
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
+
+}  // namespace smallk
+}  // namespace kmx
+#endif

@@ -54,7 +54,7 @@ CONV_REWRITES = [
     (r'asm volatile\("" ::"v"\((rawQ|actQ)\[j\]\)\);', ";", 2),
     (r'asm volatile\("" : "\+v"\(pOff\)\);', ";", 1),
     (r'extern __shared__ __attribute__\(\(aligned\(256\)\)\) char smem\[\];', "char* const smem = (char*)emu::dynLds();", 1),
-    (r'__builtin_amdgcn_global_load_lds\(', "emu::globalLoadLds(", 3),
+    (r'__builtin_amdgcn_global_load_lds\(', "emu::globalLoadLds(", 2),
     (r'__attribute__\(\(amdgpu_waves_per_eu\(CW / 4 \+ 1, CW / 4 \+ 1\)\)\)', "", 1),
 ]
 
@@ -110,7 +110,15 @@ CHAIN_REWRITES = [
 ]
 
 
-def build_emu_full(d, conv_mutations=(), pw2_mutations=(), chain_mutations=()):
+# conv_small_kernel.h (the small-batch 3x3 shape with dedicated fetching waves)
+SMALL_REWRITES = [
+    (r'asm volatile\("" : "\+s"\(sTap\)\);', ";", 2),
+    (r'asm volatile\("" : "\+v"\(pOff\)\);', ";", 1),
+    (r'extern __shared__ __attribute__\(\(aligned\(256\)\)\) char smemSmall\[\];', "char* const smemSmall = (char*)emu::dynLds();", 1),
+]
+
+
+def build_emu_full(d, conv_mutations=(), pw2_mutations=(), chain_mutations=(), small_mutations=()):
     """conv_mutations: further (pattern, replacement, count) rewrites of conv_kernel.h - deliberate defects for the tests of the
     emulator's own teeth."""
     import re
@@ -128,6 +136,11 @@ def build_emu_full(d, conv_mutations=(), pw2_mutations=(), chain_mutations=()):
         assert k == count, "conv_chain_kernel.h changed: %r matched %d times, expected %d" % (pat, k, count)
     open(os.path.join(d, "conv_chain_kernel.h"), "w").write(src)
     shutil.copy(os.path.join(CSRC, "conv_chain.hip"), os.path.join(d, "conv_chain.hip"))
+    src = open(os.path.join(CSRC, "conv_small_kernel.h")).read()
+    for pat, rep, count in list(SMALL_REWRITES) + list(small_mutations):
+        src, k = re.subn(pat, rep, src)
+        assert k == count, "conv_small_kernel.h changed: %r matched %d times, expected %d" % (pat, k, count)
+    open(os.path.join(d, "conv_small_kernel.h"), "w").write(src)
     src = open(os.path.join(CSRC, "pointwise_kernel.h")).read()
     for pat, rep, count in PW_REWRITES:
         src, k = re.subn(pat, rep, src)
@@ -237,11 +250,9 @@ print("RESULT " + json.dumps(out))
         assert err <= 0.08 + 0.03 * scale, (k, err, scale)
 
 
-def test_even_tap_barrier_variant_emulated(emu_full_lib):
-    """The experimental 8-wave 3x3 kernels that synchronise on even taps only (KMX_CONV_BP2=1; ring of D + 2 slabs) and, for
-    comparison, the product's 8-wave shapes, both forced at a small batch with KMX_MIN_WGS8=1: same answers as conv2d.
-    (Index arithmetic and ring-slot bookkeeping only: copies are immediate under emulation, so the s_waitcnt counts of the
-    variant are NOT exercised here - that needs the GPU.)"""
+def test_eight_wave_shapes_emulated(emu_full_lib):
+    """The product's 8-wave 3x3 shapes forced at a small batch with KMX_MIN_WGS8=1: same answers as conv2d. (The even-tap-barrier
+    variant that this test also ran in rounds 2-3 spilled registers on the hardware and is deleted; DESIGN.md 4.8 keeps the record.)"""
     code = r"""
 import sys, json
 sys.path.insert(0, %r)
@@ -261,12 +272,10 @@ for (cin, cout, X, Y, n) in ((64, 192, 19, 19, 1), (96, 128, 13, 9, 1)):
     out["%%d_%%d" %% (cin, cout)] = [float(np.abs(got.reshape(want.shape) - want).max()), float(np.abs(want).max())]
 print("RESULT " + json.dumps(out))
 """ % (REPO,)
-    runs = run_parallel([([sys.executable, "-c", code, emu_full_lib], dict(os.environ, KMX_MIN_WGS8="1", KMX_CONV_BP2=bp2)) for bp2 in ("0", "1")])
-    for bp2, (rc, so, se) in zip(("0", "1"), runs):
-        assert rc == 0, (so + se)[-3000:]
-        res = json.loads(so.split("RESULT ")[1])
-        for k, v in res.items():
-            assert v[0] <= 2.0 ** -7 * max(1.0, v[1]) * 1.5, (bp2, k, v)
+    (rc, so, se), = run_parallel([([sys.executable, "-c", code, emu_full_lib], dict(os.environ, KMX_MIN_WGS8="1"))])
+    assert rc == 0, (so + se)[-3000:]
+    for k, v in json.loads(so.split("RESULT ")[1]).items():
+        assert v[0] <= 2.0 ** -7 * max(1.0, v[1]) * 1.5, (k, v)
 
 
 def run_parallel(cmds_envs, timeout=1800):

@@ -13,13 +13,11 @@ from test_engine_emulated import PW2_CODE, build_emu_full, conv_only, emu_full_l
 def test_convolution_waitcnt_logic_with_latest_completion(emu_full_lib):
     """KMX_EMU_LATE_DMA=1: an LDS-DMA copy lands only when an s_waitcnt vmcnt(N) of its wave forces it (requests retire in order) -
     the latest the hardware may complete it. The convolution's compile-time counts, ring depths and barrier placement must be
-    right for the answers to be: 4-wave and 8-wave shapes, 1x1 / 3x3 / 5x5, with the product's barrier on every tap and with the
-    even-tap variant."""
-    runs = run_parallel([conv_only(emu_full_lib, {"KMX_EMU_LATE_DMA": "1", "KMX_CONV_BP2": bp2}) for bp2 in ("0", "1")])
-    for bp2, (rc, so, se) in zip(("0", "1"), runs):
-        assert rc == 0 and "RESULT " in so, (so + se)[-3000:]
-        for k, v in json.loads(so.split("RESULT ")[1]).items():
-            assert v[0] <= 2.0 ** -7 * max(1.0, v[1]) * 1.5, (bp2, k, v)
+    right for the answers to be: 4-wave and 8-wave shapes, 1x1 / 3x3 / 5x5."""
+    (rc, so, se), = run_parallel([conv_only(emu_full_lib, {"KMX_EMU_LATE_DMA": "1"})])
+    assert rc == 0 and "RESULT " in so, (so + se)[-3000:]
+    for k, v in json.loads(so.split("RESULT ")[1]).items():
+        assert v[0] <= 2.0 ** -7 * max(1.0, v[1]) * 1.5, (k, v)
 
 
 def test_latest_completion_catches_a_wrong_count(tmp_path):
@@ -89,8 +87,9 @@ def test_twelve_wave_small_batch_shape(emu_full_lib):
     immediate and with the latest legal completion of its LDS-DMA requests, and BIT-IDENTICAL to the 4-wave shapes the same layers
     take without it (same MFMAs per output in the same K order) - square, rectangular and several boards, channel counts that are
     not multiples of the tile."""
-    runs = run_parallel([([sys.executable, "-c", CW12_CODE, emu_full_lib], dict(os.environ, KMX_CONV_CW12=cw, KMX_EMU_LATE_DMA=late))
-                         for cw, late in (("0", "0"), ("1", "0"), ("1", "1"))])
+    # ... and the shape with dedicated fetching waves (cfg 118, conv_small_kernel.h, round 4): same decomposition, same bits
+    runs = run_parallel([([sys.executable, "-c", CW12_CODE, emu_full_lib], dict(os.environ, KMX_CONV_LOADERS=ld, KMX_CONV_CW12=cw, KMX_EMU_LATE_DMA=late))
+                         for ld, cw, late in (("0", "0", "0"), ("0", "1", "0"), ("0", "1", "1"), ("1", "0", "0"), ("1", "0", "1"))])
     res = []
     for rc, so, se in runs:
         assert rc == 0 and "RESULT " in so, (so + se)[-3000:]

@@ -56,10 +56,10 @@ if os.environ.get("KMX_EXPERIMENTAL_TRANSFORMER") == "1":
     h = nn.createComputeHandle(ctx, nn.loadModelFile("$REPO/tests/golden/torch_tfb.bin.gz"), 2)
     assert all(np.isfinite(o).all() for o in nn.getOutput(h, v["spatial_nhwc"][2:4], v["glob"][2:4], None, np.zeros(2, np.float32)).values())
     h.close()
-print("clean: KMX_MIN_WGS8=%s KMX_CONV_BP2=%s KMX_ATTENTION_VALU=%s" % tuple(os.environ.get(k) for k in ("KMX_MIN_WGS8", "KMX_CONV_BP2", "KMX_ATTENTION_VALU")))
+print("clean: KMX_MIN_WGS8=%s KMX_ATTENTION_VALU=%s" % tuple(os.environ.get(k) for k in ("KMX_MIN_WGS8", "KMX_ATTENTION_VALU")))
 PY
 export LD_PRELOAD="$ASAN" ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 KMX_EXPERIMENTAL_TRANSFORMER=1
 python3 run.py                                   # narrow shapes, matrix-core attention
 KMX_MIN_WGS8=1 python3 run.py                    # 8-wave product shapes
-KMX_MIN_WGS8=1 KMX_CONV_BP2=1 KMX_ATTENTION_VALU=1 python3 run.py   # even-tap barrier kernels, plain attention
+KMX_MIN_WGS8=1 KMX_ATTENTION_VALU=1 python3 run.py   # 8-wave shapes at a small batch, plain attention
 rm -rf "$D"
