@@ -199,50 +199,61 @@ __global__ __launch_bounds__(NTHREADS) void convSmallKernel(const ConvArgs a) {
   waitVm<0>();  // this wave's mask and parameter requests
   __builtin_amdgcn_s_barrier();  // slab 0 and image 0 are published
   asm volatile("" ::: "memory");
-  // Fragments are read a WHOLE step ahead, into the register set the current step does not multiply from: with one multiplying wave
-  // per SIMD and three MFMAs per k half nothing else hides an LDS read's latency (read -> wait -> 3 MFMAs -> read -> wait -> 3 MFMAs
-  // measured ~430 cycles per step for 192 cycles of matrix work). The barrier at the top of step s publishes slab s + 1 and, at the
-  // last tap, the next chunk's image - exactly what step s + 1 reads; the reads of step s + 1 then have the six MFMAs of step s to
-  // land in. Same MFMAs per accumulator in the same order (k half 0, then 1, tap by tap, chunk by chunk).
-  V8 wfS[2][2], afS[2][2][MT];  // [set][k half]
-  auto readStep = [&](int set, unsigned imgOff, int t, unsigned ringSlot) {
-#pragma unroll
-    for(int kk = 0; kk < 2; kk++) wfS[set][kk] = ldsV8(wLane[kk] + ringSlot * W_BYTES);
-    unsigned sTap = (unsigned)(((t / 3 - HALO) * W2 + (t % 3 - HALO)) * 4) + ((ldsBase + imgOff) >> 4);
+  V8 wf[2], af[2][MT];
+  unsigned aAddr[MT];
+  // fragments of step 0, k half 0
+  {
+    wf[0] = ldsV8(wLane[0]);
+    unsigned sTap = (unsigned)(((0 - HALO) * W2 + (0 - HALO)) * 4) + (ldsBase >> 4);
     asm volatile("" : "+s"(sTap));
 #pragma unroll
     for(int pt = 0; pt < MT; pt++) {
       const unsigned q4 = aRow4[pt] + sTap;
-      const unsigned addr = (q4 << 4) | ((q4 ^ c40) & 0x30u);
-      afS[set][0][pt] = ldsV8(addr);
-      afS[set][1][pt] = ldsV8(addr ^ 0x20u);
+      aAddr[pt] = (q4 << 4) | ((q4 ^ c40) & 0x30u);
+      af[0][pt] = ldsV8(aAddr[pt]);
     }
-  };
-  readStep(0, 0, 0, 0);  // step 0: slab 0 and image 0 were published by the barrier above
+  }
   int step = 0;
-  auto chunkBody = [&](auto parityTag, int chunk) {
-    constexpr int CP = decltype(parityTag)::value;  // register set of the chunk's first tap (a chunk has an odd number of taps)
+  for(int chunk = 0; chunk < nChunks; chunk++) {
     const unsigned curA = (unsigned)(chunk % NSA) * ACT_BYTES;
     const unsigned nextA = (unsigned)((chunk + 1) % NSA) * ACT_BYTES;
 #pragma unroll
     for(int t = 0; t < NT; t++, step++) {
-      constexpr int dummy = 0;
-      (void)dummy;
-      const int P = (CP + t) & 1;
       __builtin_amdgcn_s_barrier();  // publishes slab step + 1 (and, at the last tap, the next chunk's image)
       asm volatile("" ::: "memory");
-      readStep(P ^ 1, t + 1 < NT ? curA : nextA, t + 1 < NT ? t + 1 : 0, (unsigned)((step + 1) % NSW));
-      __builtin_amdgcn_sched_barrier(0);
+      // (Round 4 also measured the fragments read a WHOLE step ahead into a second register set - slower: 18.7 against 17.3 us per launch at
+  // batch 1, as the same idea was for the twelve-wave shape; profiles/r04_steps/small_batch.)
+  // first k half: the MFMAs of fragment set 0; behind them, one by one, the reads of set 1 (this step's slab, this tap)
+      const unsigned wb1 = wLane[1] + (unsigned)(step % NSW) * W_BYTES;
 #pragma unroll
-      for(int kk = 0; kk < 2; kk++)
+      for(int pt = 0; pt < MT; pt++) {
+        acc[pt] = TR::mfma(wf[0], af[0][pt], acc[pt]);
+        __builtin_amdgcn_sched_barrier(0);
+        if(pt == 0) wf[1] = ldsV8(wb1);
+        af[1][pt] = ldsV8(aAddr[pt] ^ 0x20u);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // second k half; behind its MFMAs the reads of set 0 of the NEXT step (slab step + 1, next tap)
+      const unsigned wb0 = wLane[0] + (unsigned)((step + 1) % NSW) * W_BYTES;
+      {
+        const int tn = t + 1 < NT ? t + 1 : 0;
+        unsigned sTap = (unsigned)(((tn / 3 - HALO) * W2 + (tn % 3 - HALO)) * 4) + ((ldsBase + (t + 1 < NT ? curA : nextA)) >> 4);
+        asm volatile("" : "+s"(sTap));
 #pragma unroll
-        for(int pt = 0; pt < MT; pt++) acc[pt] = TR::mfma(wfS[P][kk], afS[P][kk][pt], acc[pt]);
-      __builtin_amdgcn_sched_barrier(0);
+        for(int pt = 0; pt < MT; pt++) {
+          const unsigned q4 = aRow4[pt] + sTap;
+          aAddr[pt] = (q4 << 4) | ((q4 ^ c40) & 0x30u);
+        }
+      }
+#pragma unroll
+      for(int pt = 0; pt < MT; pt++) {
+        acc[pt] = TR::mfma(wf[1], af[1][pt], acc[pt]);
+        __builtin_amdgcn_sched_barrier(0);
+        if(pt == 0) wf[0] = ldsV8(wb0);
+        af[0][pt] = ldsV8(aAddr[pt]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-  };
-  for(int chunk = 0; chunk < nChunks; chunk++) {
-    if(chunk & 1) chunkBody(ActKindTag<1>(), chunk);
-    else chunkBody(ActKindTag<0>(), chunk);
   }
 
   // ---- epilogue: conv_kernel.h's, for one 32-channel tile per wave and cell tile ----

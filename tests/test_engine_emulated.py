@@ -112,7 +112,7 @@ CHAIN_REWRITES = [
 
 # conv_small_kernel.h (the small-batch 3x3 shape with dedicated fetching waves)
 SMALL_REWRITES = [
-    (r'asm volatile\("" : "\+s"\(sTap\)\);', ";", 1),
+    (r'asm volatile\("" : "\+s"\(sTap\)\);', ";", 2),
     (r'asm volatile\("" : "\+v"\(pOff\)\);', ";", 1),
     (r'extern __shared__ __attribute__\(\(aligned\(256\)\)\) char smemSmall\[\];', "char* const smemSmall = (char*)emu::dynLds();", 1),
 ]
