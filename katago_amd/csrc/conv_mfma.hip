@@ -50,6 +50,7 @@ constexpr int CFG_CW12 = 111;
 // cfg 111, four multiplying waves of three cell tiles each and four waves that issue every LDS-DMA request. KMX_CONV_LOADERS=0 / 1
 // overrides the default.
 constexpr int CFG_LOADERS = 118;
+constexpr int CFG_LOADERS_PACKED = 119;  // the same with two work-groups per CU (conv_small_kernel.h PACK)
 constexpr bool kLoadersDefault = true;
 bool loadersEnabled() {
   static const bool on = [] {
@@ -61,7 +62,8 @@ bool loadersEnabled() {
 template <class TR>
 hipError_t launchT(int ks, int cfg, const ConvArgs& a, hipStream_t stream) {
   if(ks == 3 && cfg == CFG_CW12) return launchOne<TR, 3, 1, 1, 2, 0, 12>(a, stream);
-  if(ks == 3 && cfg == CFG_LOADERS) return smallk::launchSmall<TR>(a, stream);
+  if(ks == 3 && cfg == CFG_LOADERS) return smallk::launchSmall<TR, false>(a, stream);
+  if(ks == 3 && cfg == CFG_LOADERS_PACKED) return smallk::launchSmall<TR, true>(a, stream);
 #define KMX_CFG(KS_, WNW_, WN_, D_) \
   if(ks == KS_ && cfg == 10 * WNW_ + WN_) return launchOne<TR, KS_, WN_, WNW_, D_, 0>(a, stream);
   KMX_CFG_LIST(KMX_CFG)
@@ -80,7 +82,7 @@ hipError_t launchConv(int dtype, int ks, int cfg, const ConvArgs& a, hipStream_t
 }
 
 bool convCfgInstantiated(int ks, int cfg) {
-  if(ks == 3 && (cfg == CFG_CW12 || cfg == CFG_LOADERS)) return true;
+  if(ks == 3 && (cfg == CFG_CW12 || cfg == CFG_LOADERS || cfg == CFG_LOADERS_PACKED)) return true;
 #define KMX_CFG(KS_, WNW_, WN_, D_) \
   if(ks == KS_ && cfg == 10 * WNW_ + WN_) return true;
   KMX_CFG_LIST(KMX_CFG)
@@ -120,6 +122,12 @@ int chooseConvCfg(int ks, int coutPad, int batch) {
     return e ? atoi(e) : 256;
   }();
   if(ks == 3 && loadersEnabled() && batch * tiles <= loadersMaxWgs) return CFG_LOADERS;
+  // ... and two per CU up to twice that (KMX_CONV_LOADERS_PACKED_MAX_WGS; 0 = off)
+  static const int packedMaxWgs = [] {
+    const char* e = getenv("KMX_CONV_LOADERS_PACKED_MAX_WGS");
+    return e ? atoi(e) : 0;
+  }();
+  if(ks == 3 && loadersEnabled() && batch * tiles <= packedMaxWgs) return CFG_LOADERS_PACKED;
   if(ks == 3 && cw12Enabled() && batch * tiles <= cw12MaxWgs) return CFG_CW12;
   // 3x3/5x5 narrow shapes keep two work-groups per CU (LDS), 1x1 shapes one
   const int round = ks == 1 ? 200 : 420;

@@ -47,8 +47,10 @@ constexpr int PARAM_OFFSET = MASK_OFFSET + MASK_BYTES;
 constexpr int LDS_BYTES = PARAM_OFFSET + PARAM_BYTES;
 static_assert(NPA <= NT - 2, "the next image's requests are all issued two taps before the chunk ends");
 
-template <class TR>
-__global__ __launch_bounds__(NTHREADS) void convSmallKernel(const ConvArgs a) {
+// PACK (the second instantiation): register allocation capped at 128 per lane so that TWO work-groups share a CU (4 waves per SIMD, 2 x 68 KB
+// of LDS) - for batches whose work-groups outnumber the CUs; the cap costs 48 bytes of scratch per lane outside the loop.
+template <class TR, bool PACK>
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ? 4 : 2, PACK ? 4 : 3))) void convSmallKernel(const ConvArgs a) {
   typedef typename TR::T T;
   typedef typename TR::V8 V8;
   typedef typename TR::V4 V4;
@@ -355,10 +357,10 @@ __global__ __launch_bounds__(NTHREADS) void convSmallKernel(const ConvArgs a) {
   });
 }
 
-template <class TR>
+template <class TR, bool PACK>
 hipError_t launchSmall(const ConvArgs& a, hipStream_t stream) {
   if(a.coutPad % NTILE != 0) return hipErrorInvalidValue;
-  auto kern = convSmallKernel<TR>;
+  auto kern = convSmallKernel<TR, PACK>;
   constexpr int MAX_DEVICES = 64;  // the > 64 KiB LDS opt-in is per function AND device (conv_kernel.h launchOne)
   static std::atomic<bool> attrSet[MAX_DEVICES];
   int dev = 0;
