@@ -64,13 +64,11 @@ enum { ABL_NO_EPILOGUE = 1, ABL_NO_COMPUTE = 2, ABL_NO_DMA = 4, ABL_NO_LDS_READ 
        ABL_TIMING = 2048 /* s_memtime stamps between the segments of a step, summed per wave into ConvArgs::dbg */,
        ABL_BATCHED = 131072 /* the round-2 form of a step (A/B): the six fragment reads of a half-step as one batch behind its first MFMA, the step's LDS-DMA requests as one batch between the halves */, };
 
-// CW = waves along the CELL dimension: 4 (each owns 3 tiles of 32 cells; every product shape of rounds 1-3) or 12 (each owns ONE
-// tile: the small-batch shape, see conv_mfma.hip) - CW * MTW * 32 = 384 >= 361 cells either way.
-template <int KS, int WN, int WNW, int D, int CW = 4>
+// Four waves along the cell dimension, each owning 3 tiles of 32 cells (4 x 96 = 384 >= 361). (Round 3's small-batch shape of twelve
+// cell waves with one tile each lost to conv_small_kernel.h in round 4 and is gone)
+template <int KS, int WN, int WNW, int D>
 struct Geom {
-  static_assert(CW == 4 || (CW == 12 && WN == 1 && WNW == 1), "12 cell waves exist for the 32-channel work-group only");
-  static constexpr int MTW = 12 / CW;  // 32-cell tiles per wave
-  static constexpr int NWAVES = CW * WNW;
+  static constexpr int NWAVES = 4 * WNW;
   static constexpr int NTHREADS = NWAVES * 64;
   static constexpr int HALO = KS / 2;
   static constexpr int NT = KS * KS;
@@ -79,11 +77,9 @@ struct Geom {
   // first and which otherwise idles at the barrier; tools/conv_timing.py) fetch the weight slabs, waves 4-7 the board image.
   // No dummy requests, per-role s_waitcnt constants, and a weight wave never waits behind an HBM-latency image piece.
   // 4-wave work-groups: every wave does both, padded with dummies to a constant per-step count.
-  // 12-wave work-groups split by role too: a 32-channel slab is 2 KB = the requests of two waves (waves 0-1), the other ten share the
-  // board image - one request per wave and step at most, none of them padding.
-  static constexpr bool ROLES = WNW == 2 || CW == 12;
-  static constexpr int NLW = !ROLES ? NWAVES : CW == 12 ? (32 * WN * WNW * 4 + 63) / 64 : 4;  // waves that fetch weights
-  static constexpr int NLA = !ROLES ? NWAVES : CW == 12 ? NWAVES - NLW : 4;                    // waves that fetch the image
+  static constexpr bool ROLES = WNW == 2;
+  static constexpr int NLW = !ROLES ? NWAVES : 4;  // waves that fetch weights
+  static constexpr int NLA = !ROLES ? NWAVES : 4;  // waves that fetch the image
   static constexpr int NPA = (HPMAX * 4 + NLA * 64 - 1) / (NLA * 64);   // DMA instructions per image-loading wave per board image
   static constexpr int ACT_BYTES = (HPMAX * ROWB + 1023) / 1024 * 1024;  // instructions wholly past it go to the slack
   static constexpr int NTILE = 32 * WN * WNW;
@@ -186,13 +182,12 @@ __device__ __forceinline__ void dma4(const void* gsrc, unsigned ldsWaveBase) {
     (const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)(size_t)ldsWaveBase, 4, 0, 0);
 }
 
-template <class TR, int KS, int WN, int WNW, int D, int ABL, int CW = 4>
-__global__ __launch_bounds__(64 * CW * WNW) __attribute__((amdgpu_waves_per_eu(CW / 4 + 1, CW / 4 + 1))) void convMfmaKernel(const ConvArgs a) {
+template <class TR, int KS, int WN, int WNW, int D, int ABL>
+__global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2))) void convMfmaKernel(const ConvArgs a) {
   typedef typename TR::T T;
   typedef typename TR::V8 V8;
   typedef typename TR::V4 V4;
-  typedef Geom<KS, WN, WNW, D, CW> G;
-  constexpr int MT = G::MTW;  // (shadows convk::MT, the value of the 4-cell-wave shapes)
+  typedef Geom<KS, WN, WNW, D> G;
   constexpr int HALO = G::HALO, NT = G::NT, NPA = G::NPA, NPW = G::NPW, NWAVES = G::NWAVES;
   constexpr bool SPREAD = G::SPREAD;
 
@@ -250,16 +245,15 @@ __global__ __launch_bounds__(64 * CW * WNW) __attribute__((amdgpu_waves_per_eu(C
   // (an LDS-DMA instruction costs its wave 100-200 cycles of issue). With every request on the waves that have the slack,
   // the younger waves only multiply. (tools/conv_timing.py)
   // (possible when the image pieces have all been requested before the slab that is waited for at the last tap: LS <= NT + 1 - D)
-  constexpr bool ONE = ROLES && CW == 4 && SPREAD && G::LS <= NT + 1 - D;
+  constexpr bool ONE = ROLES && SPREAD && G::LS <= NT + 1 - D;
   // the step's fragment reads (and, in the ONE division, its DMA requests) spread over its MFMAs: needs a slot per read in each half
   constexpr bool SPREAD_STEP = WN * MT >= WN + MT && !(ABL & (ABL_BATCHED | ABL_TIMING));
   constexpr int SLOTS = WN * MT - (WN + MT);                           // MFMAs of a half-step that carry no fragment read
   constexpr bool SPREAD_DMA = SPREAD_STEP && ONE && 2 * SLOTS >= 1 + NPW;  // the image piece(s) of the tap + the slab's instructions
-  constexpr bool TAPSLOT = CW == 12 && NT % G::NSW == 0;  // ring slot of a step = ring slot of its tap
   const bool wLoader = !ROLES || wave < G::NLW;   // wave-uniform
   const bool aLoader = !ROLES || (ONE ? wave < 4 : wave >= G::NLW);
   const int lw = wave;                            // index among the weight-loading waves
-  const int la = !ROLES ? wave : CW == 12 ? (wave >= G::NLW ? wave - G::NLW : 0) : (wave & 3);  // index among the image-loading waves
+  const int la = !ROLES ? wave : (wave & 3);  // index among the image-loading waves
   unsigned srcOff[NPA];  // byte offset from this board's tensor, or (bit 31 set) into the zero page; +64 per chunk
 #pragma unroll
   for(int j = 0; j < NPA; j++) {
@@ -287,13 +281,11 @@ __global__ __launch_bounds__(64 * CW * WNW) __attribute__((amdgpu_waves_per_eu(C
   }
 
   // Every call issues exactly NPW instructions (into the slack area when `step` is past the end).
-  // (slot: the ring slot when the caller knows it at compile time - the 12-wave shape, whose ring of 3 divides the 9 taps of a
-  // chunk, so that step % 3 = tap % 3 and the scalar division by 3 leaves the loop; -1: computed from the step)
-  auto issueW = [&](int step, int slot = -1) {
+  auto issueW = [&](int step) {
     if(ABL & (ABL_NO_DMA | ABL_NO_W_DMA)) return;
     const bool live = step < nSteps;
     const char* slab = wBase + (size_t)(live ? step : 0) * wSlabStride;
-    const unsigned dst = bufW + (slot >= 0 ? slot : step % G::NSW) * G::W_BYTES;
+    const unsigned dst = bufW + (step % G::NSW) * G::W_BYTES;
 #pragma unroll
     for(int j = 0; j < NPW; j++) {
       const int pbase = (j * G::NLW + (lw % G::NLW)) * 64;
@@ -341,9 +333,9 @@ __global__ __launch_bounds__(64 * CW * WNW) __attribute__((amdgpu_waves_per_eu(C
   V8 af[2][MT];
   unsigned aAddr[MT];  // kk=0 addresses of the tap last prepared; the kk=1 fragments sit 32 bytes away (slot ^ 2)
   auto ldsV8 = [&](unsigned addr) { return *(const __attribute__((address_space(3))) V8*)addr; };
-  auto readW = [&](int kk, int stepIdx, int slot = -1) {
+  auto readW = [&](int kk, int stepIdx) {
     if(ABL & (ABL_NO_LDS_READ | ABL_NO_COMPUTE)) return;
-    const unsigned base = wLane[kk] + (unsigned)(slot >= 0 ? slot : stepIdx % G::NSW) * G::W_BYTES;
+    const unsigned base = wLane[kk] + (unsigned)(stepIdx % G::NSW) * G::W_BYTES;
 #pragma unroll
     for(int ct = 0; ct < WN; ct++) wf[kk][ct] = ldsV8(base + ct * 32 * ROWB);
   };
@@ -483,7 +475,7 @@ __global__ __launch_bounds__(64 * CW * WNW) __attribute__((amdgpu_waves_per_eu(C
       return;
     }
     if(ROLES) {
-      if(wLoader) issueW(step + D, TAPSLOT ? (t + D) % G::NSW : -1);
+      if(wLoader) issueW(step + D);
       else if(SPREAD) {
         // real pieces only; nothing after the image is complete (this wave waits with vmcnt(0) once per chunk)
         if(t * G::PPS < NPA && chunk + 1 < nChunks) {
@@ -631,7 +623,7 @@ __global__ __launch_bounds__(64 * CW * WNW) __attribute__((amdgpu_waves_per_eu(C
       }
       mfmaPart(0, 0, 1, acc);
       __builtin_amdgcn_sched_barrier(0);
-      readW(1, step, TAPSLOT ? t % G::NSW : -1);
+      readW(1, step);
       readA1();
       __builtin_amdgcn_sched_barrier(0);
       mfmaPart(0, 1, WN * MT, acc);
@@ -642,7 +634,7 @@ __global__ __launch_bounds__(64 * CW * WNW) __attribute__((amdgpu_waves_per_eu(C
       stamp(2);
       mfmaPart(1, 0, 1, acc);
       __builtin_amdgcn_sched_barrier(0);
-      readW(0, step + 1, TAPSLOT ? (t + 1) % G::NSW : -1);
+      readW(0, step + 1);
       readA0(t + 1 < NT ? curA : nextA, t + 1 < NT ? t + 1 : 0);
       __builtin_amdgcn_sched_barrier(0);
       mfmaPart(1, 1, WN * MT, acc);
@@ -819,13 +811,13 @@ __global__ __launch_bounds__(64 * CW * WNW) __attribute__((amdgpu_waves_per_eu(C
   }
 }
 
-template <class TR, int KS, int WN, int WNW, int D, int ABL, int CW = 4>
+template <class TR, int KS, int WN, int WNW, int D, int ABL>
 hipError_t launchOne(const ConvArgs& a, hipStream_t stream) {
-  typedef Geom<KS, WN, WNW, D, CW> G;
+  typedef Geom<KS, WN, WNW, D> G;
   constexpr int ldsBytes = G::LDS_BYTES;
   static_assert(ldsBytes <= 160 * 1024, "LDS budget exceeded");
   static_assert(!G::SPREAD || G::LS + (G::ROLES ? 1 : D) <= G::NT, "image pieces must land within their chunk");
-  auto kern = convMfmaKernel<TR, KS, WN, WNW, D, ABL, CW>;
+  auto kern = convMfmaKernel<TR, KS, WN, WNW, D, ABL>;
   // The opt-in to more than 64 KiB of dynamic LDS is a property of the function ON ONE DEVICE, and one process may hold
   // handles on several GPUs (the reference runs one server thread per GPU in a single process): one flag per
   // instantiation and device. The call is idempotent, so a race between two handles' first launches is harmless.

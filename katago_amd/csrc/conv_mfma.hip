@@ -23,32 +23,10 @@ using namespace convk;
 // (no 5x5 4-wave x 64-channel shape: it spills 50 registers to scratch - found in round 3 with -Rpass-analysis=kernel-resource-usage,
 // the same cause as the two "unexplained" 2x cliffs of round 2, ring depth 4 and the even-tap barrier variant)
 
-// The small-batch 3x3 shape, cfg 111 = 12 cell waves x 32 channels (conv_kernel.h, Geom<.., CW = 12>): a work-group still owns a board
-// and 32 output channels, but twelve waves of ONE 32-cell tile each instead of four waves of three. While the chip is not full a
-// layer takes as long as ONE work-group does (they all run side by side on idle CUs), and a 4-wave work-group's step is 6 MFMAs plus
-// two LDS-DMA requests per wave (a third of them padding) at ~160 cycles of issue each: 697 cycles per step, 320 of them requests
-// (profiles/r03_steps/small_batch_conv_timing.txt). With twelve waves a step is 2 MFMAs per wave and at most ONE request (two
-// waves fetch the 2 KB slab, ten share the board image, none padded). Same MFMAs per output in the same K order: bit-identical
-// results (on the MI355X: the digest of 64 rows' outputs is the same with either shape and at every batch size,
-// profiles/r03_steps/small_batch_cw12/). Measured there, b18c384nbt through kmx_eval: 26.9 -> 23.4 us per 3x3 launch at batch 1,
-// 28.1 -> 23.8 at batch 8; a pass 2.59 -> 2.35 ms (batch 1), 2.94 -> 2.60 (8), 3.36 -> 3.10 (32), 3.58 -> 3.30 (42). Less than the
-// request count suggests: with two MFMAs per wave and step nothing hides the LDS read latency of the fragments any more, and a
-// launch costs ~14 us whatever it does (the 1x1 layers and the small kernels of the same pass take 14-37 us each).
-// KMX_CONV_CW12=0 / 1 overrides the default (on).
-// (Round 4 measured the variant that reads a step's fragments one step ahead, behind the current MFMAs: 25.7 against 23.4 us per launch,
-// 2.47 against 2.31 ms per pass at batch 1 - slower, removed; profiles/r04_steps/call1/small_batch_scan.txt.)
-constexpr bool kCw12Default = true;
-bool cw12Enabled() {
-  static const bool on = [] {
-    const char* e = getenv("KMX_CONV_CW12");
-    return e != nullptr ? e[0] == '1' : kCw12Default;
-  }();
-  return on;
-}
-constexpr int CFG_CW12 = 111;
-// The small-batch 3x3 shape with dedicated fetching waves, cfg 118 (conv_small_kernel.h, round 4): a board x 32 channels like cfg 11 and
-// cfg 111, four multiplying waves of three cell tiles each and four waves that issue every LDS-DMA request. KMX_CONV_LOADERS=0 / 1
-// overrides the default.
+// The small-batch 3x3 shape with dedicated fetching waves, cfg 118 (conv_small_kernel.h, round 4): a board x 32 channels like cfg 11,
+// four multiplying waves of three cell tiles each and four waves that issue every LDS-DMA request: 22.0 -> 17.3 us per 3x3 launch at
+// batch 1 against round 3's shape of twelve cell waves (cfg 111, removed), a pass 2.30 -> 2.00 ms at batch 1, 2.51 -> 2.34 at batch 8
+// (profiles/r04_steps/small_batch). KMX_CONV_LOADERS=0 / 1 overrides the default (0: the 4-wave shapes of conv_kernel.h).
 constexpr int CFG_LOADERS = 118;
 constexpr int CFG_LOADERS_PACKED = 119;  // the same with two work-groups per CU (conv_small_kernel.h PACK)
 constexpr bool kLoadersDefault = true;
@@ -61,7 +39,6 @@ bool loadersEnabled() {
 }
 template <class TR>
 hipError_t launchT(int ks, int cfg, const ConvArgs& a, hipStream_t stream) {
-  if(ks == 3 && cfg == CFG_CW12) return launchOne<TR, 3, 1, 1, 2, 0, 12>(a, stream);
   if(ks == 3 && cfg == CFG_LOADERS) return smallk::launchSmall<TR, false>(a, stream);
   if(ks == 3 && cfg == CFG_LOADERS_PACKED) return smallk::launchSmall<TR, true>(a, stream);
 #define KMX_CFG(KS_, WNW_, WN_, D_) \
@@ -82,7 +59,7 @@ hipError_t launchConv(int dtype, int ks, int cfg, const ConvArgs& a, hipStream_t
 }
 
 bool convCfgInstantiated(int ks, int cfg) {
-  if(ks == 3 && (cfg == CFG_CW12 || cfg == CFG_LOADERS || cfg == CFG_LOADERS_PACKED)) return true;
+  if(ks == 3 && (cfg == CFG_LOADERS || cfg == CFG_LOADERS_PACKED)) return true;
 #define KMX_CFG(KS_, WNW_, WN_, D_) \
   if(ks == KS_ && cfg == 10 * WNW_ + WN_) return true;
   KMX_CFG_LIST(KMX_CFG)
@@ -109,12 +86,6 @@ int chooseConvCfg(int ks, int coutPad, int batch) {
   auto wgs = [&](int cfg) { return batch * (tiles / ((cfg / 10) * (cfg % 10))); };
   const int widest8 = fits(23) ? 23 : fits(22) ? 22 : 0;
   if(widest8 && wgs(widest8) >= minWgs8) return widest8;
-  // twelve waves per 32-channel work-group while that is at most one work-group per CU (it is the only one on its CU; measured up to
-  // there - KMX_CONV_CW12_MAX_WGS moves the limit for scans beyond it)
-  static const int cw12MaxWgs = [] {
-    const char* e = getenv("KMX_CONV_CW12_MAX_WGS");
-    return e ? atoi(e) : 256;
-  }();
   // the fetching-waves shape while it is the only work-group on its CU (134 VGPRs x 8 waves: one work-group per CU;
   // KMX_CONV_LOADERS_MAX_WGS moves the limit for scans beyond it)
   static const int loadersMaxWgs = [] {
@@ -122,13 +93,14 @@ int chooseConvCfg(int ks, int coutPad, int batch) {
     return e ? atoi(e) : 256;
   }();
   if(ks == 3 && loadersEnabled() && batch * tiles <= loadersMaxWgs) return CFG_LOADERS;
-  // ... and two per CU up to twice that (KMX_CONV_LOADERS_PACKED_MAX_WGS; 0 = off)
+  // ... and two per CU up to twice that (KMX_CONV_LOADERS_PACKED_MAX_WGS; 0 = off). Measured on the MI355X, b18c384nbt device-resident:
+  // batch 43 2.72 -> 2.43 ms per pass, 48 2.77 -> 2.51, 64 2.86 -> 2.69, 85 3.06 -> 3.05; beyond two per CU it loses (96: 3.89 -> 4.10 ms),
+  // profiles/r04_steps/small_batch/mid_batch_packed.txt
   static const int packedMaxWgs = [] {
     const char* e = getenv("KMX_CONV_LOADERS_PACKED_MAX_WGS");
-    return e ? atoi(e) : 0;
+    return e ? atoi(e) : 512;
   }();
   if(ks == 3 && loadersEnabled() && batch * tiles <= packedMaxWgs) return CFG_LOADERS_PACKED;
-  if(ks == 3 && cw12Enabled() && batch * tiles <= cw12MaxWgs) return CFG_CW12;
   // 3x3/5x5 narrow shapes keep two work-groups per CU (LDS), 1x1 shapes one
   const int round = ks == 1 ? 200 : 420;
   if(fits(11) && wgs(11) <= round) return 11;

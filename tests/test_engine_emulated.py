@@ -198,8 +198,9 @@ LATE_DMA_SHAPES = [(3, 64, 32, 9, 9, 1), (1, 96, 64, 13, 13, 1), (5, 32, 64, 9, 
 
 
 def conv_only(lib, env):
-    # (KMX_CONV_CW12=0: the small 3x3 case is to take the padded 4-wave shape here; the twelve-wave shape has its own tests)
-    return [sys.executable, "-c", CONV_ONLY, lib, json.dumps(LATE_DMA_SHAPES)], dict(os.environ, KMX_MIN_WGS8="1", KMX_CONV_CW12="0", **env)
+    # (KMX_CONV_LOADERS=0: the small 3x3 case is to take the padded 4-wave shape of conv_kernel.h here; the shape with fetching waves,
+    # conv_small_kernel.h, has its own tests)
+    return [sys.executable, "-c", CONV_ONLY, lib, json.dumps(LATE_DMA_SHAPES)], dict(os.environ, KMX_MIN_WGS8="1", KMX_CONV_LOADERS="0", **env)
 
 
 def test_real_convolution_kernel_emulated(emu_full_lib):

@@ -30,6 +30,9 @@ def test_latest_completion_catches_a_wrong_count(tmp_path):
         (r"        waitVmSel\(n\);\n      \}\n      return;", "        waitVmSel(n + 1);\n      }\n      return;", 1),
         # the weight waves of the role-split shapes (the twelve-wave small-batch shape among them)
         (r"static constexpr int VMCNT_W = \(D - 2\) \* NPW,", "static constexpr int VMCNT_W = 1 + (D - 2) * NPW,", 1),
+    ], small_mutations=[
+        # the fetching waves of the small-batch shape let one request more stay in flight than slab s + 1 allows
+        (r"if\(\(t \+ NT - 1\) % NT < NPA\) waitVm<2>\(\);\n          else waitVm<1>\(\);", "if((t + NT - 1) % NT < NPA) waitVm<3>();\n          else waitVm<2>();", 1),
     ], pw2_mutations=[
         # the persistent seam kernel: phase 2 of a part lets one request more stay in flight than its loads and stores account for
         (r"waitVmSel\(G::nR\(q\) \+ 2\);", "waitVmSel(G::nR(q) + 2 + 1);", 1),
@@ -43,13 +46,13 @@ def test_latest_completion_catches_a_wrong_count(tmp_path):
     wrong = [k for k, v in late.items() if not v[0] <= 2.0 ** -7 * max(1.0, v[1]) * 1.5]
     print("late completion, one request too generous:", late)
     assert "conv3_64_32" in wrong and "conv3_96_192" in wrong, late  # the padded 4-wave shape and the 8-wave loader shape
-    # the twelve-wave shape with its weight waves' wait one request too generous
-    runs = run_parallel([([sys.executable, "-c", CW12_CODE, lib], dict(os.environ, KMX_CONV_CW12="1", KMX_EMU_LATE_DMA=late_)) for late_ in ("0", "1")])
+    # the small-batch shape with its fetching waves' wait one request too generous
+    runs = run_parallel([([sys.executable, "-c", CW12_CODE, lib], dict(os.environ, KMX_CONV_LOADERS="1", KMX_EMU_LATE_DMA=late_)) for late_ in ("0", "1")])
     (rc0, so0, se0), (rc1, so1, se1) = runs
     assert rc0 == 0 and rc1 == 0, (so0 + se0 + so1 + se1)[-3000:]
     c0, c1 = json.loads(so0.split("RESULT ")[1]), json.loads(so1.split("RESULT ")[1])
     ok = lambda v: v[0] <= 2.0 ** -7 * max(1.0, v[1]) * 1.5  # noqa: E731
-    print("twelve-wave shape, one request too generous: latest completion", {k: v[:2] for k, v in c1.items()})
+    print("fetching-waves shape, one request too generous: latest completion", {k: v[:2] for k, v in c1.items()})
     assert all(ok(v) for v in c0.values()) and not any(ok(v) for v in c1.values()), (c0, c1)
     # the seam kernel with its defect: right with immediate copies, wrong when a W2 slab may land as late as the count allows
     runs = run_parallel([([sys.executable, "-c", PW2_CODE, lib], dict(os.environ, KMX_PW_GRID="1", KMX_EMU_LATE_DMA=late_)) for late_ in ("0", "1")])
@@ -82,14 +85,13 @@ print("RESULT " + json.dumps(out))
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
 
 
-def test_twelve_wave_small_batch_shape(emu_full_lib):
-    """cfg 111 (conv_mfma.hip: 12 cell waves x 32 channels, two waves fetch the slabs, ten the board image): against conv2d with
-    immediate and with the latest legal completion of its LDS-DMA requests, and BIT-IDENTICAL to the 4-wave shapes the same layers
-    take without it (same MFMAs per output in the same K order) - square, rectangular and several boards, channel counts that are
-    not multiples of the tile."""
-    # ... and the shape with dedicated fetching waves (cfg 118, conv_small_kernel.h, round 4): same decomposition, same bits
-    runs = run_parallel([([sys.executable, "-c", CW12_CODE, emu_full_lib], dict(os.environ, KMX_CONV_LOADERS=ld, KMX_CONV_CW12=cw, KMX_EMU_LATE_DMA=late))
-                         for ld, cw, late in (("0", "0", "0"), ("0", "1", "0"), ("0", "1", "1"), ("1", "0", "0"), ("1", "0", "1"))])
+def test_small_batch_shape_with_fetching_waves(emu_full_lib):
+    """cfg 118 (conv_small_kernel.h: four multiplying waves of three cell tiles, four waves that issue every LDS-DMA request): against
+    conv2d with immediate and with the latest legal completion of its requests, and BIT-IDENTICAL to the 4-wave shapes of
+    conv_kernel.h the same layers take without it (same MFMAs per output in the same K order) - square, rectangular and several
+    boards, channel counts that are not multiples of the tile."""
+    runs = run_parallel([([sys.executable, "-c", CW12_CODE, emu_full_lib], dict(os.environ, KMX_CONV_LOADERS=ld, KMX_EMU_LATE_DMA=late))
+                         for ld, late in (("0", "0"), ("1", "0"), ("1", "1"))])
     res = []
     for rc, so, se in runs:
         assert rc == 0 and "RESULT " in so, (so + se)[-3000:]
