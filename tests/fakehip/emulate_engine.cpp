@@ -20,6 +20,9 @@ bool convCfgInstantiated(int, int) { return true; }
 // no fused seam kernel in this build: the engine then schedules the two convolution launches
 bool pointwisePairSupported(int, int, int) { return false; }
 hipError_t launchPointwisePair(int, int, int, int, const PwPairArgs&, hipStream_t) { return 801; }
+// ... and no chained convolution kernel: the engine then schedules one launch per convolution
+bool convChainSupported(int) { return false; }
+hipError_t launchConvChain(int, const ConvChainArgs&, hipStream_t) { return 801; }
 #endif
 double benchConv(int, int, int, int, int, int, int, int, int, int) { return 0.0; }
 double benchConvStreams(int, int, int, int, int, int, double, int, int) { return 0.0; }

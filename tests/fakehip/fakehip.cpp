@@ -79,7 +79,7 @@ uint64_t fnv(const void* p, size_t n) {
 // demangled-ish short name: keep the mangled string (stable across builds of the same source)
 size_t argBytes(const std::string& name) {
   using namespace kmx;
-  if(name.find("convMfmaKernel") != std::string::npos) return sizeof(ConvArgs);
+  if(name.find("convMfmaKernel") != std::string::npos || name.find("convSmallKernel") != std::string::npos) return sizeof(ConvArgs);
   if(name.find("convChainKernel") != std::string::npos) return sizeof(ConvChainArgs);
   if(name.find("inputExpandKernel") != std::string::npos) return sizeof(InputArgs);
   if(name.find("gpoolApply") != std::string::npos) return sizeof(GPoolArgs);

@@ -55,7 +55,7 @@ CONV_REWRITES = [
     (r'asm volatile\("" : "\+v"\(pOff\)\);', ";", 1),
     (r'extern __shared__ __attribute__\(\(aligned\(256\)\)\) char smem\[\];', "char* const smem = (char*)emu::dynLds();", 1),
     (r'__builtin_amdgcn_global_load_lds\(', "emu::globalLoadLds(", 2),
-    (r'__attribute__\(\(amdgpu_waves_per_eu\(CW / 4 \+ 1, CW / 4 \+ 1\)\)\)', "", 1),
+    (r'__attribute__\(\(amdgpu_waves_per_eu\(2, 2\)\)\)', "", 1),
 ]
 
 
@@ -115,6 +115,7 @@ SMALL_REWRITES = [
     (r'asm volatile\("" : "\+s"\(sTap\)\);', ";", 2),
     (r'asm volatile\("" : "\+v"\(pOff\)\);', ";", 1),
     (r'extern __shared__ __attribute__\(\(aligned\(256\)\)\) char smemSmall\[\];', "char* const smemSmall = (char*)emu::dynLds();", 1),
+    (r'__attribute__\(\(amdgpu_waves_per_eu\(PACK \? 4 : 2, PACK \? 4 : 3\)\)\)', "", 1),
 ]
 
 

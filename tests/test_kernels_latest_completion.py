@@ -53,7 +53,9 @@ def test_latest_completion_catches_a_wrong_count(tmp_path):
     c0, c1 = json.loads(so0.split("RESULT ")[1]), json.loads(so1.split("RESULT ")[1])
     ok = lambda v: v[0] <= 2.0 ** -7 * max(1.0, v[1]) * 1.5  # noqa: E731
     print("fetching-waves shape, one request too generous: latest completion", {k: v[:2] for k, v in c1.items()})
-    assert all(ok(v) for v in c0.values()) and not any(ok(v) for v in c1.values()), (c0, c1)
+    # (the fetching waves run ahead of the multiplying ones between two barriers, so under emulation a late copy may still land before a
+    # small case reads it: the defect must show in at least one case - the two-board 19x19 one in practice - and never with immediate copies)
+    assert all(ok(v) for v in c0.values()) and not all(ok(v) for v in c1.values()), (c0, c1)
     # the seam kernel with its defect: right with immediate copies, wrong when a W2 slab may land as late as the count allows
     runs = run_parallel([([sys.executable, "-c", PW2_CODE, lib], dict(os.environ, KMX_PW_GRID="1", KMX_EMU_LATE_DMA=late_)) for late_ in ("0", "1")])
     (rc0, so0, se0), (rc1, so1, se1) = runs

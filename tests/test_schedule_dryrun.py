@@ -90,7 +90,7 @@ def test_transformer_schedule_is_consistent(name, C, H, KVH, QD, VD, F, blocks, 
     log = dry_run(fake_so, model, 8, [n], str(tmp_path / "tf.log"), {"KMX_EXPERIMENTAL_TRANSFORMER": "1"})
     launches = [_fields(l) for l in log.splitlines() if l.startswith("launch ")]
     kinds = [("attention" if "attentionMfmaKernel" in k else "rmsnorm" if "rmsNormKernel" in k else "boardrms" if "boardRmsKernel" in k else
-              "swiglu" if "swiGluKernel" in k else "conv" if "convMfmaKernel" in k else "other") for k, *_ in launches]
+              "swiglu" if "swiGluKernel" in k else "conv" if ("convMfmaKernel" in k or "convSmallKernel" in k) else "other") for k, *_ in launches]
     S = 361
     att = [l for l, k in zip(launches, kinds) if k == "attention"]
     assert att
@@ -116,12 +116,14 @@ def test_transformer_schedule_is_consistent(name, C, H, KVH, QD, VD, F, blocks, 
         assert "boardrms" in kinds and kinds.count("attention") == 3  # two inside the nested block, one in the trunk
     # every convolution tiles its padded channels with the chosen shape
     for (kname, grid, block, lds, args), k in zip(launches, kinds):
-        if k == "conv":
-            m = re.search(r"ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(?:0|262144)ELi(\d+)EEE", kname)  # kernel size, WN, WNW, ring depth, ablations, cell waves
-            ks, wn, wnw, cw = int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(5))
+        if k == "conv" and "convSmallKernel" in kname:  # the small-batch 3x3 shape: a board x 32 channels, 4 + 4 waves
             cout_pad = int(args[4], 16) & 0xFFFFFFFF
-            assert cw in (4, 12) and (cw == 4 or (ks, wn, wnw) == (3, 1, 1))
-            assert grid == (cout_pad // (32 * wn * wnw), n, 1) and block == 64 * cw * wnw and lds <= 160 * 1024
+            assert grid == (cout_pad // 32, n, 1) and block == 512 and lds <= 160 * 1024
+        elif k == "conv":
+            m = re.search(r"ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi0EEE", kname)  # kernel size, WN, WNW, ring depth, ablations
+            ks, wn, wnw = int(m.group(1)), int(m.group(2)), int(m.group(3))
+            cout_pad = int(args[4], 16) & 0xFFFFFFFF
+            assert grid == (cout_pad // (32 * wn * wnw), n, 1) and block == 256 * wnw and lds <= 160 * 1024
 
 
 def test_reference_transformer_nets_build_a_schedule(fake_so, tmp_path):
