@@ -510,7 +510,7 @@ w = (rng.normal(size=(n_conv, 192, 192, 3, 3)) * 0.03).astype(np.float32)
 scale = rng.uniform(0.6, 1.4, (n_conv, 192)).astype(np.float32)
 bias = rng.normal(0, 0.25, (n_conv, 192)).astype(np.float32)
 out = {}
-for dtype in ("bf16", "fp16"):
+for dtype in sys.argv[6].split(","):
     res = {}
     for chained in (0, 2, 4):
         if chained > n_conv: continue
@@ -549,9 +549,10 @@ def test_convolution_chain_kernel_emulated(emu_full_lib):
     immediate LDS-DMA copies (a hand-over written into a slot that some wave still reads shows as a wrong answer) and with the
     latest completion the kernel's waits allow (a wait that does not cover a slab, an image chunk or the scratch stores leaves
     stale data)."""
-    cases = [("4", "9", "9", "2", "0"), ("2", "13", "7", "1", "0"), ("4", "9", "9", "2", "1"), ("2", "13", "7", "1", "1"),
-             ("2", "19", "19", "1", "0"), ("4", "19", "19", "1", "1")]  # 19 x 19: the column order of boards at least 16 wide
-    runs = run_parallel([([sys.executable, "-c", CHAIN_CODE, emu_full_lib, nc, X, Y, b], dict(os.environ, KMX_EMU_LATE_DMA=late)) for nc, X, Y, b, late in cases])
+    # (chain length, X, Y, boards, late completion, precisions); 19 x 19: the column order of boards at least 16 wide
+    cases = [("4", "9", "9", "2", "0", "bf16"), ("4", "9", "9", "2", "1", "fp16"), ("2", "13", "7", "1", "1", "bf16"),
+             ("2", "19", "19", "1", "0", "fp16"), ("4", "19", "19", "1", "1", "bf16")]
+    runs = run_parallel([([sys.executable, "-c", CHAIN_CODE, emu_full_lib, nc, X, Y, b, dt], dict(os.environ, KMX_EMU_LATE_DMA=late)) for nc, X, Y, b, late, dt in cases])
     for case, (rc, so, se) in zip(cases, runs):
         assert rc == 0 and "RESULT " in so, (case, (so + se)[-3000:])
         res = json.loads(so.split("RESULT ")[1])
