@@ -122,24 +122,49 @@ def measured_traffic(args):
     with contextlib.redirect_stdout(sys.stderr):  # the summariser reports what it wrote; stdout carries ONE line, the JSON
         rocpd_summary.main(d, os.path.join(d, "summary"))
 
-    def per_dispatch(counter, key):
+    return traffic_totals(lambda counter: os.path.join(d, "summary", "benchpmc_%s_pmc.csv" % counter))
+
+
+def traffic_totals(csv_of):
+    """Per kernel class, the FETCH_SIZE / WRITE_SIZE totals of a counted run (csv_of(counter) -> tools/rocpd_summary.py's *_pmc.csv)."""
+    import csv
+
+    def totals(counter, keys):
         tot = disp = 0.0
-        for r in csv.DictReader(open(os.path.join(d, "summary", "benchpmc_%s_pmc.csv" % counter))):
-            if r["Counter"] == counter and key in r["Kernel"]:
+        passes = 0
+        for r in csv.DictReader(open(csv_of(counter))):
+            if r["Counter"] != counter:
+                continue
+            if any(k in r["Kernel"] for k in keys):
                 tot += float(r["Sum"])
                 disp += float(r["Dispatches"])
-        return (tot / disp, int(disp)) if disp else (None, 0)
+            if "inputExpandKernel" in r["Kernel"]:
+                passes = int(float(r["Dispatches"]))  # one per pass (one stream, no split)
+        return tot, int(disp), passes
 
+    # A "launch" of the bench line's conv3x3 class is one CONVOLUTION: a chained dispatch (conv_chain_kernel.h) holds two or four, so
+    # the class's bytes are summed over both kernels' dispatches and divided by the convolutions the passes held (finish_traffic).
     out = {}
-    for name, key in (("conv3x3", "KS=3"), ("conv1x1_pair", "pointwisePair")):
-        f, nf = per_dispatch("FETCH_SIZE", key)
-        w, nw = per_dispatch("WRITE_SIZE", key)
-        if f is not None and w is not None:
-            out[name] = {"hbm_bytes_per_launch": round((2.0 * f + w) * 1024.0), "fetch_kib_raw": round(f, 1), "write_kib_raw": round(w, 1),
-                         "dispatches": [nf, nw],
-                         "source": "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 3 --warmup 2`, one stream; "
-                                   "FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE x1"}
+    for name, keys in (("conv3x3", ("KS=3", "convChainKernel")), ("conv1x1_pair", ("pointwisePair",))):
+        f, nf, pf = totals("FETCH_SIZE", keys)
+        w, nw, pw = totals("WRITE_SIZE", keys)
+        if nf and nw and pf and pw:
+            out[name] = {"fetch_kib_total": f, "write_kib_total": w, "dispatches": [nf, nw], "passes": [pf, pw]}
     return out
+
+
+def finish_traffic(t, launches_per_pass):
+    """HBM bytes per launch from measured_traffic's totals: a class's bytes over its launches (for the 3x3 class: convolutions) in the
+    counted passes; FETCH_SIZE x2 on gfx950 (see measured_traffic)."""
+    if not t or "error" in t or launches_per_pass <= 0:
+        return t
+    f = t["fetch_kib_total"] / (t["passes"][0] * launches_per_pass)
+    w = t["write_kib_total"] / (t["passes"][1] * launches_per_pass)
+    return {"hbm_bytes_per_launch": round((2.0 * f + w) * 1024.0), "fetch_kib_raw": round(f, 1), "write_kib_raw": round(w, 1),
+            "dispatches": t["dispatches"], "launches_per_pass": launches_per_pass,
+            "source": "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 3 --warmup 2`, one stream, summed "
+                      "over the class's dispatches (3x3: convMfmaKernel KS=3 + convChainKernel) and divided by its launches in those passes (a "
+                      "chained dispatch counts as the convolutions it holds); FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE x1"}
 
 
 CALLER_CFG = """logDir = %s
@@ -450,7 +475,7 @@ def main():
         achieved = flops / (ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[dtype]
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": (traffic or {}).get(name),
+                    "frac": round(achieved / peak, 4), "traffic": finish_traffic((traffic or {}).get(name), launches / args.steps),
                     "pass": "single stream, hipEvent pair per launch (the timed pass runs two half-batch streams)",
                     "profiled_ms_per_step": round(profiled_elapsed / args.steps * 1e3, 4),
                     "avg_launch_ms": round(ms / launches, 5), "launches": int(launches),
@@ -463,7 +488,7 @@ def main():
         launches, ms, flops, nbytes = prof_entries["conv1x1_pair"]
         gbs = nbytes / (ms * 1e-3) / 1e9
         roofline_seam = {"bound": "hbm", "kernel": "conv1x1_pair", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": (traffic or {}).get("conv1x1_pair"),
+                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": finish_traffic((traffic or {}).get("conv1x1_pair"), launches / args.steps),
                          "avg_launch_ms": round(ms / launches, 5), "launches": int(launches),
                          "algorithmic_bytes_per_launch": nbytes / launches, "flops_per_launch": flops / launches}
 

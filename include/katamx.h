@@ -211,10 +211,13 @@ int kmx_handle_sync(kmx_handle* handle);
  * batch is on the device the next one accumulates, and FULL batches are launched behind it, up to max_in_flight
  * (default 2 when <= 0) between H2D and D2H at once on their own engines and streams, so that copies and kernels of
  * consecutive batches overlap. FULL means the device's granule, not necessarily max_batch_size: a convolution gives a board to
- * a work-group and a work-group to a compute unit, so a batch is sealed at the largest multiple of the device's CU count that is
- * <= max_batch_size (MI355X: 256 for max_batch_size 256..511, 512 for 512..767; max_batch_size itself below 256) and no batch is
- * ever larger - engines and staging are sized for that. Environment KMX_BATCH_QUANTUM overrides the granule (0: seal at
- * max_batch_size only). rows/batches as nneval.cpp:712-713. A row's outputs are bit-identical to the same row through kmx_eval. */
+ * a work-group and a work-group to a compute unit, so a batch is sealed at the device's CU count (MI355X: 256; max_batch_size itself
+ * below that) and no batch is ever larger - engines and staging are sized for that. Larger batches were measured and lose (a caller
+ * with L leaves in flight is served best by batches well below L/2; batcher.cpp has the numbers): environment
+ * KMX_BATCH_GROW_AHEAD=k allows them all the same - the limit is then the largest multiple of the CU count <= max_batch_size, and a
+ * batch is sealed at a smaller multiple only while fewer than k batches are launched or queued. KMX_BATCH_QUANTUM overrides the
+ * granule (0: seal at max_batch_size only).
+ * rows/batches as nneval.cpp:712-713. A row's outputs are bit-identical to the same row through kmx_eval. */
 typedef struct kmx_batcher kmx_batcher;
 int kmx_batcher_create(kmx_context* ctx, const kmx_model* model, int max_batch_size, int max_in_flight, int gpu_idx,
                        kmx_batcher** out);

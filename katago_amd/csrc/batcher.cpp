@@ -47,19 +47,35 @@ class Batcher {
     : maxBatch_(maxBatch), maxInFlight_(maxInFlight) {
     S_ = nnXLen * nnYLen;
     // Seal at the device's granule. The convolutions give a board to a work-group and a work-group to a CU: a pass over 430 boards
-    // on 256 CUs costs what a pass over 512 does. A filling batch therefore counts as FULL at the largest MULTIPLE of the CU count
-    // that max_batch_size allows (256 for 256..511, 512 for 512..767, ...; max_batch_size itself below one granule) and goes behind
-    // the running one at once, instead of growing to an odd size while the device is busy - measured with the reference's
-    // benchmark at 1024 leaves in flight: avg batch 432 -> 256, 31.0 k -> 37.5 k nnEvals/s (profiles/r03_steps/fibers.txt).
+    // on 256 CUs costs what a pass over 512 does. A filling batch therefore counts as FULL at ONE granule - the device's CU count
+    // (max_batch_size itself below that) - and goes behind the running one at once, instead of growing to an odd size while the device
+    // is busy: the reference's benchmark at 1024 leaves in flight, avg batch 432 -> 256, 31.0 k -> 37.5 k nnEvals/s
+    // (profiles/r03_steps/fibers.txt).
+    // Round 4 measured the alternatives a larger max_batch_size invites (advisor, round 3), same benchmark with max_batch_size 1024,
+    // A/B on one box whose device does 38.5 k (profiles/r04_steps/batcher/seal_rule_ab.txt): sealed at the LARGEST multiple only:
+    // 34.4 of 43.3 k on another box (avg batch 492: with L leaves in flight, batches of L/2 leave the host's turnaround uncovered);
+    // at any multiple while fewer than two batches are ahead, growing on otherwise: 36.2 k (avg 337); at any multiple while a slot of
+    // the device is free: 37.0 k (avg 275: a batch that grows past a boundary must reach the NEXT one before it can go, and the
+    // device drains meanwhile); at one granule always: 38.7 k, 100 % of the device (avg 248). So one granule it is, and engines and
+    // staging are sized for that. KMX_BATCH_GROW_AHEAD=k restores growth: the largest multiple of the granule that max_batch_size
+    // allows is the limit, and a batch is sealed at a smaller multiple only while fewer than k batches are launched or queued.
     // KMX_BATCH_QUANTUM overrides the granule (0 = off: only max_batch_size seals). include/katamx.h states this contract.
     {
       int q = -1;
       if(const char* e = getenv("KMX_BATCH_QUANTUM")) q = atoi(e);
       if(q < 0) {
+        int dev = device;
+        if(dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;  // "the current device" is what the engines below take as well
         hipDeviceProp_t prop;
-        q = hipGetDeviceProperties(&prop, device < 0 ? 0 : device) == hipSuccess ? prop.multiProcessorCount : 0;
+        q = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 0;
       }
-      sealAt_ = q > 0 && q < maxBatch ? maxBatch / q * q : maxBatch;
+      growAhead_ = 0;
+      if(const char* e = getenv("KMX_BATCH_GROW_AHEAD")) growAhead_ = atoi(e) < 0 ? 0 : atoi(e);
+      if(q > 0 && q < maxBatch) {
+        sealAt_ = growAhead_ > 0 ? maxBatch / q * q : q;
+        granule_ = q < sealAt_ ? q : 0;
+      }
+      else sealAt_ = maxBatch;
       if(const char* e = getenv("KMX_BATCH_LINGER_US")) lingerUs_ = atoi(e) < 0 ? 0 : atoi(e);
     }
     maxBatch = sealAt_;  // no batch ever holds more rows: engines and staging are sized for what can be used
@@ -146,7 +162,8 @@ class Batcher {
         Pending& p = pending_[ticket];
         p.slot = si;
         s.rows[r] = RowOut{ticket, outPolicy, outValue, outScore, outOwnership};
-        if(s.count == sealAt_) {  // full: no further reservations, the next row opens a new batch
+        // full - or at a granule boundary with the device about to run dry: no further reservations, the next row opens a new batch
+        if(s.count == sealAt_ || (granule_ > 0 && s.count % granule_ == 0 && running_ + (int)sealed_.size() < growAhead_)) {
           s.state = SEALED;
           sealed_.push_back(filling_);
           filling_ = -1;
@@ -374,7 +391,7 @@ class Batcher {
     }
   }
 
-  int maxBatch_, maxInFlight_, sealAt_ = 0, S_ = 0, cin_ = 0, gin_ = 0, min_ = 0;
+  int maxBatch_, maxInFlight_, sealAt_ = 0, granule_ = 0, growAhead_ = 0, S_ = 0, cin_ = 0, gin_ = 0, min_ = 0;
   std::deque<Slot> slots_;  // a Slot holds a condition variable: never moved
   std::mutex mu_;
   std::condition_variable cvWork_, cvComplete_, cvFree_;

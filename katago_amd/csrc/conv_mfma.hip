@@ -37,10 +37,23 @@ bool loadersEnabled() {
   }();
   return on;
 }
+// how far ahead the fetching waves of the one-per-CU shape run (conv_small_kernel.h SG): KMX_CONV_LOADERS_DEPTH = 0 | 1. Same box, 3x3
+// launch at batch 1: 16.94 -> 16.47 us, a pass 1.93 -> 1.88 ms (profiles/r04_steps/small_batch/depth_scan.txt)
+constexpr int kLoadersDepthDefault = 1;
+int loadersDepth() {
+  static const int d = [] {
+    const char* e = getenv("KMX_CONV_LOADERS_DEPTH");
+    return e != nullptr && e[0] >= '0' && e[0] <= '1' ? e[0] - '0' : kLoadersDepthDefault;
+  }();
+  return d;
+}
 template <class TR>
 hipError_t launchT(int ks, int cfg, const ConvArgs& a, hipStream_t stream) {
-  if(ks == 3 && cfg == CFG_LOADERS) return smallk::launchSmall<TR, false>(a, stream);
-  if(ks == 3 && cfg == CFG_LOADERS_PACKED) return smallk::launchSmall<TR, true>(a, stream);
+  if(ks == 3 && cfg == CFG_LOADERS) {
+    const int depth = loadersDepth();
+    return depth == 0 ? smallk::launchSmall<TR, false, 0>(a, stream) : smallk::launchSmall<TR, false, 1>(a, stream);
+  }
+  if(ks == 3 && cfg == CFG_LOADERS_PACKED) return smallk::launchSmall<TR, true, 0>(a, stream);
 #define KMX_CFG(KS_, WNW_, WN_, D_) \
   if(ks == KS_ && cfg == 10 * WNW_ + WN_) return launchOne<TR, KS_, WN_, WNW_, D_, 0>(a, stream);
   KMX_CFG_LIST(KMX_CFG)

@@ -31,33 +31,75 @@ using convk::ROWB;
 constexpr int NT = 9, HALO = 1, MT = 3;
 constexpr int NCOMPUTE = 4, NLOAD = 4, NWAVES = NCOMPUTE + NLOAD, NTHREADS = NWAVES * 64;
 constexpr int NTILE = 32;                 // output channels per work-group
-constexpr int D = 3, NSW = D + 1;         // requests three steps ahead, ring of four slabs
 constexpr int HPMAX = 21 * 21;
 constexpr int NPA = (HPMAX * 4 + NLOAD * 64 - 1) / (NLOAD * 64);  // 7 image requests per loader wave and chunk: one per tap 0..6
 constexpr int ACT_BYTES = NPA * NLOAD * 64 * 16;                   // 28672
-constexpr int NSA = 2;
 constexpr int W_BYTES = NTILE * ROWB;     // 2048: one request of waves 4 and 5 each
 constexpr int SLACK_BYTES = 1024;
 constexpr int MASK_BYTES = NTHREADS * 4;
 constexpr int PARAM_BYTES = 256 * 4;      // scale | bias | per-board bias of the 32 channels: 96 floats, one 4-byte request per lane of waves 0-3
-constexpr int RING_OFFSET = NSA * ACT_BYTES;
-constexpr int SLACK_OFFSET = RING_OFFSET + NSW * W_BYTES;
-constexpr int MASK_OFFSET = SLACK_OFFSET + SLACK_BYTES;
-constexpr int PARAM_OFFSET = MASK_OFFSET + MASK_BYTES;
-constexpr int LDS_BYTES = PARAM_OFFSET + PARAM_BYTES;
-static_assert(NPA <= NT - 2, "the next image's requests are all issued two taps before the chunk ends");
+// How far ahead the fetching waves run. One work-group per CU (PACK = false): slabs SIX steps ahead on a ring of eight, the board image TWO
+// chunks ahead in three buffers - at batch 1-8 every operand comes from HBM or the Infinity Cache (55 MB of weights cycle through 32 MB of L2
+// per pass), ~0.6 us away, and three steps of ~0.2 us did not cover that: the multiplying waves waited at the barrier for the fetching
+// waves' s_waitcnt. Two work-groups per CU (PACK = true, 128 registers): three steps and one chunk ahead, 68 KB of LDS each.
+// DEPTH 0: three steps / one chunk ahead (all that fits twice per CU); 1: six steps / two chunks.
+template <bool PACK, int DEPTH>
+struct SG {
+  static_assert(!PACK || DEPTH == 0, "two work-groups per CU leave 80 KB of LDS each");
+  static_assert(DEPTH == 0 || DEPTH == 1, "");
+  static constexpr int D = DEPTH == 0 ? 3 : 6;
+  static constexpr int NSW = DEPTH == 0 ? 4 : 8;
+  static constexpr int NSA = DEPTH == 1 ? 3 : 2;
+  static constexpr int DIST = NSA - 1;  // the image of chunk c + DIST is requested while the loop works on chunk c
+  static constexpr int RING_OFFSET = NSA * ACT_BYTES;
+  static constexpr int SLACK_OFFSET = RING_OFFSET + NSW * W_BYTES;
+  static constexpr int MASK_OFFSET = SLACK_OFFSET + SLACK_BYTES;
+  static constexpr int PARAM_OFFSET = MASK_OFFSET + MASK_BYTES;
+  static constexpr int LDS_BYTES = PARAM_OFFSET + PARAM_BYTES;
+  // image requests a slab-fetching wave issues at tap t (steady state): one at taps 0 .. NPA-1
+  static constexpr int imgAt(int t) { return ((t % NT) + NT) % NT < NPA ? 1 : 0; }
+  // top of step s (tap t): slab s + 1 - requested in step s + 1 - D, after that step's image request - has landed; younger: the requests
+  // of steps s + 2 - D .. s - 1
+  static constexpr int vmAt(int t) {
+    int n = 0;
+    for(int k = 1; k <= D - 2; k++) n += 1 + imgAt(t - k);
+    return n;
+  }
+  // the D virtual steps -D .. -1 of the prologue issue what the steady state would: slab k in virtual step k - D, after an image request
+  // where the steady state has one (pieces of image DIST, the last of them; its first pieces and all of images 0 .. DIST-1 go before)
+  static constexpr int virtualImg() {
+    int n = 0;
+    for(int v = -D; v < 0; v++) n += imgAt(v);
+    return n;
+  }
+};
+// The slab waves never wait for an image by name. The image of chunk c + DIST is first read in the LAST step of chunk c + DIST - 1 (the
+// fragments of a step are read behind the second half of the step before), i.e. after the barrier at the top of step 9 (c + DIST) - 1,
+// where slab 9 (c + DIST) - requested in step 9 (c + DIST) - D - has landed: the image's last piece (tap NPA - 1 of chunk c) must not be
+// requested later than that slab. (Round 4 ran a third depth - four steps / one chunk ahead - that broke this by one step: right under
+// the emulator's latest-completion mode 1, in which the fetching waves run far ahead of the multiplying ones, 5 % faster on the MI355X and
+// NOT bit-identical there; mode 2 of the emulator, which lands a copy at the barrier after its wait, now fails it. Deleted.)
+template <bool PACK, int DEPTH>
+constexpr bool imagesLandWithSlabs() { return NPA - 1 <= NT * SG<PACK, DEPTH>::DIST - SG<PACK, DEPTH>::D; }
+static_assert(imagesLandWithSlabs<true, 0>() && imagesLandWithSlabs<false, 0>() && imagesLandWithSlabs<false, 1>(),
+              "an image piece would be requested after the slab whose arrival stands for it");
+static_assert(SG<false, 1>::LDS_BYTES <= 160 * 1024 && 2 * SG<true, 0>::LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
+static_assert(SG<true, 0>::virtualImg() == 1 && SG<false, 1>::virtualImg() == 4, "prologue bookkeeping below");
 
 // PACK (the second instantiation): register allocation capped at 128 per lane so that TWO work-groups share a CU (4 waves per SIMD, 2 x 68 KB
 // of LDS) - for batches whose work-groups outnumber the CUs; the cap costs 48 bytes of scratch per lane outside the loop.
-template <class TR, bool PACK>
+template <class TR, bool PACK, int DEPTH>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ? 4 : 2, PACK ? 4 : 3))) void convSmallKernel(const ConvArgs a) {
   typedef typename TR::T T;
   typedef typename TR::V8 V8;
   typedef typename TR::V4 V4;
   extern __shared__ __attribute__((aligned(256))) char smemSmall[];
   const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smemSmall;
-  const unsigned bufW = ldsBase + RING_OFFSET;
-  const unsigned slack = ldsBase + SLACK_OFFSET;
+  typedef SG<PACK, DEPTH> G;
+  constexpr int D = G::D, NSW = G::NSW, NSA = G::NSA, DIST = G::DIST;
+  constexpr int MASK_OFFSET = G::MASK_OFFSET, PARAM_OFFSET = G::PARAM_OFFSET;
+  const unsigned bufW = ldsBase + G::RING_OFFSET;
+  const unsigned slack = ldsBase + G::SLACK_OFFSET;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -136,33 +178,43 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
       dma16(src, live ? ldsBase + (unsigned)(chunk % NSA) * ACT_BYTES + (unsigned)((j * NLOAD + lw) * 64) * 16u : slack);
       srcOff[j] = (off & 0x80000000u) ? off : off + KCHUNK * (unsigned)sizeof(T);
     };
-    // fill the pipeline: image 0, slabs 0 .. D-1
+    // Fill the pipeline in the order the steady state would have: the D virtual steps -D .. -1 stand for the last D taps of a "chunk -1",
+    // whose image requests would have been for image DIST - 1. So: images 0 .. DIST-2 whole, the first pieces of image DIST - 1, then per
+    // virtual step the next piece of it where the steady state has an image request, followed by the step's slab (slab k in virtual step
+    // k - D) - and the loop's compile-time wait counts hold from its first step on.
+    constexpr int VIMG = G::virtualImg();  // pieces of image DIST - 1 that ride the virtual steps
 #pragma unroll
-    for(int j = 0; j < NPA; j++) issueA(0, j);
-    if(slabWave) {
+    for(int c = 0; c + 1 < DIST; c++)
 #pragma unroll
-      for(int s = 0; s < D; s++) issueW(s);
+      for(int j = 0; j < NPA; j++) issueA(c, j);
+#pragma unroll
+    for(int j = 0; j < NPA - VIMG; j++) issueA(DIST - 1, j);
+    {
+      int piece = NPA - VIMG;
+#pragma unroll
+      for(int v = -D; v < 0; v++) {
+        if(G::imgAt(v)) issueA(DIST - 1, piece++);
+        if(slabWave) issueW(v + D);
+      }
     }
-    // slab 0 and image 0 (and the mask) have landed: in flight at most slabs 1 .. D-1
-    if(slabWave) waitVm<D - 1>();
-    else waitVm<0>();
+    // slab 0 and image 0 (and the mask) have landed; in flight at most what was issued after slab 0 / after image 0
+    // (one chunk ahead, D = 3: the last piece of image 0 rides virtual step -D, before slab 0)
+    if(slabWave) waitVm<(D - 1) + VIMG - G::imgAt(-D)>();
+    else waitVm<(DIST - 1) * NPA>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     int step = 0;
     for(int chunk = 0; chunk < nChunks; chunk++) {
 #pragma unroll
       for(int t = 0; t < NT; t++, step++) {
-        // top of step s: slab s + 1 (requested in step s - 2, after that step's image request) has landed - and with it every image
-        // request issued before it; younger: the requests of step s - 1 (its image request at taps 0..6, its slab). A wave that
-        // fetches no slabs waits for all of its image requests where the next chunk's image is first read: the last tap.
-        if(slabWave) {
-          if((t + NT - 1) % NT < NPA) waitVm<2>();
-          else waitVm<1>();
-        }
-        else if(t == NT - 1) waitVm<0>();
+        // top of step s: slab s + 1 has landed - and with it every image request issued before it (G::vmAt). A wave that fetches no slabs
+        // waits where the next chunk's image is first read, the last tap: for everything but the pieces of this chunk's own requests
+        // (PACK: those ARE the next chunk's image)
+        if(slabWave) convk::waitVmSel(G::vmAt(t));
+        else if(t == NT - 1) waitVm<(DIST - 1) * NPA>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if(t < NPA) issueA(chunk + 1, t);
+        if(t < NPA) issueA(chunk + DIST, t);
         if(slabWave) issueW(step + D);
       }
     }
@@ -357,10 +409,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
   });
 }
 
-template <class TR, bool PACK>
+template <class TR, bool PACK, int DEPTH>
 hipError_t launchSmall(const ConvArgs& a, hipStream_t stream) {
   if(a.coutPad % NTILE != 0) return hipErrorInvalidValue;
-  auto kern = convSmallKernel<TR, PACK>;
+  auto kern = convSmallKernel<TR, PACK, DEPTH>;
+  constexpr int LDS_BYTES = SG<PACK, DEPTH>::LDS_BYTES;
   constexpr int MAX_DEVICES = 64;  // the > 64 KiB LDS opt-in is per function AND device (conv_kernel.h launchOne)
   static std::atomic<bool> attrSet[MAX_DEVICES];
   int dev = 0;
@@ -375,7 +428,6 @@ hipError_t launchSmall(const ConvArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3(a.coutPad / NTILE, a.N, 1), dim3(NTHREADS), LDS_BYTES, stream, a);
   return hipGetLastError();
 }
-static_assert(LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
 
 }  // namespace smallk
 }  // namespace kmx

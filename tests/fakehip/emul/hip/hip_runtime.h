@@ -166,7 +166,19 @@ inline F16 mfma16(V8 a, V8 b, F16 c) {
 }
 }  // namespace emu
 
-inline void __syncthreads() { emu::cur->bar->arrive_and_wait(); }
+namespace emu {
+inline void vmAtBarrier();
+int lateDmaMode();
+}
+inline void __syncthreads() {
+  if(emu::lateDmaMode() == 2) {
+    // every lane has arrived - whatever the phase before the barrier reads has been read - THEN the required copies land, and only
+    // then does anyone go on
+    emu::cur->bar->arrive_and_wait();
+    emu::vmAtBarrier();
+  }
+  emu::cur->bar->arrive_and_wait();
+}
 namespace emu {
 // Lanes of a wave execute in lockstep on the hardware, so a wave may write LDS and read other lanes' values back without a
 // barrier; OS threads do not. Kernels that rely on it get this call injected at those points (see the convolution's
@@ -185,23 +197,39 @@ inline void waveSync() { cur->waves[tIdx.x >> 6].bar->arrive_and_wait(); }
 struct VmOp { const void* src; void* dst; int size; };
 struct VmQueue {
   std::vector<VmOp> ops;
-  size_t head = 0;  // ops[head ..) are outstanding, oldest first
+  size_t head = 0;     // ops[head ..) are outstanding, oldest first
+  size_t required = 0;  // mode 2: ops[.. required) must have landed - a wait has said so - and do at the lane's next barrier
 };
 extern thread_local VmQueue vmQueue;  // per lane (a lane is an OS thread here; all lanes of a wave issue and wait alike)
-bool lateDma();
-inline void vmRetireTo(size_t outstanding) {
+// KMX_EMU_LATE_DMA: 0 - a copy lands when it is issued; 1 - when an s_waitcnt vmcnt(N) of its wave forces it (the latest the HARDWARE may
+// complete it); 2 - at the barrier that FOLLOWS that wait (or at the wave's exit): the latest moment ANOTHER wave may legally first see it -
+// what wait + barrier publish. Lanes are OS threads here and a fetching wave reaches its next wait long before a multiplying wave has
+// read anything, so mode 1 can hide a copy that is required one step too late; mode 2 cannot. (Mode 2 is only for kernels in which no
+// wave reads what it fetched itself before a barrier.)
+int lateDmaMode();
+inline bool lateDma() { return lateDmaMode() != 0; }
+inline void vmLandUpTo(size_t end) {  // ops[head .. end) land
   VmQueue& q = vmQueue;
-  while(q.ops.size() - q.head > outstanding) {
+  while(q.head < end) {
     const VmOp& op = q.ops[q.head++];
     if(op.dst != nullptr) memcpy(op.dst, op.src, (size_t)op.size);
   }
   if(q.head == q.ops.size()) {
     q.ops.clear();
     q.head = 0;
+    q.required = 0;
   }
 }
 inline void waitVm(int n) {
-  if(lateDma()) vmRetireTo((size_t)n);
+  const int mode = lateDmaMode();
+  if(mode == 0) return;
+  VmQueue& q = vmQueue;
+  const size_t end = q.ops.size() > (size_t)n ? q.ops.size() - (size_t)n : 0;
+  if(mode == 1) vmLandUpTo(end > q.head ? end : q.head);
+  else if(end > q.required) q.required = end;
+}
+inline void vmAtBarrier() {  // mode 2: what the waits so far have required lands now
+  if(lateDmaMode() == 2 && vmQueue.required > vmQueue.head) vmLandUpTo(vmQueue.required);
 }
 inline void vmNote() {  // a vector-memory request that is not an LDS-DMA copy: it only takes its place in the in-order queue
   if(lateDma()) vmQueue.ops.push_back(VmOp{nullptr, nullptr, 0});

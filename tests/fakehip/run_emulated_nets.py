@@ -154,7 +154,20 @@ def batcher_case(ctx):
     equal2 = (not hung) and bool(all(np.array_equal(base[k][i], got2[i][k]) for k in keys for i in range(n)))
     if not hung:
         b2.close()
+    # a granule below the batch size with growth allowed (KMX_BATCH_QUANTUM=2, KMX_BATCH_GROW_AHEAD=3; batches of up to 6, three in
+    # flight; the default seals at one granule always): a batch is sealed at 2 or 4 rows while a slot is free (fewer than three
+    # launched or queued), at 6 otherwise - every row must come back the same whichever batch it rode in
+    os.environ["KMX_BATCH_QUANTUM"] = "2"
+    os.environ["KMX_BATCH_GROW_AHEAD"] = "3"
+    b3 = nn.Batcher(ctx, model, 6, maxInFlight=3)
+    del os.environ["KMX_BATCH_QUANTUM"], os.environ["KMX_BATCH_GROW_AHEAD"]
+    tickets = [b3.submit(sp[i], gl[i], sym[i], opt[i], True) for i in range(n)]
+    got3 = [b3.wait(t) for t in tickets]
+    rows3, batches3 = b3.stats()
+    b3.close()
+    equal3 = bool(all(np.array_equal(base[k][i], got3[i][k]) for k in keys for i in range(n)))
     return {"equal": equal, "rows": int(rows), "batches": int(batches), "error": err, "many_tickets_equal": equal2,
+            "granule_equal": equal3, "granule_stats": [int(rows3), int(batches3)],
             "after_error_equal": bool(all(np.array_equal(base[k][1], again[k]) for k in ("policy", "value", "score")))}
 
 

@@ -12,12 +12,13 @@ from test_engine_emulated import PW2_CODE, build_emu_full, conv_only, emu_full_l
 
 def test_convolution_waitcnt_logic_with_latest_completion(emu_full_lib):
     """KMX_EMU_LATE_DMA=1: an LDS-DMA copy lands only when an s_waitcnt vmcnt(N) of its wave forces it (requests retire in order) -
-    the latest the hardware may complete it. The convolution's compile-time counts, ring depths and barrier placement must be
+    the latest the hardware may complete it; =2: at the barrier that follows that wait - the latest another wave may first see it
+    (lanes are OS threads here: a wave that only fetches reaches its next wait long before the others have read anything). The convolution's compile-time counts, ring depths and barrier placement must be
     right for the answers to be: 4-wave and 8-wave shapes, 1x1 / 3x3 / 5x5."""
-    (rc, so, se), = run_parallel([conv_only(emu_full_lib, {"KMX_EMU_LATE_DMA": "1"})])
-    assert rc == 0 and "RESULT " in so, (so + se)[-3000:]
-    for k, v in json.loads(so.split("RESULT ")[1]).items():
-        assert v[0] <= 2.0 ** -7 * max(1.0, v[1]) * 1.5, (k, v)
+    for rc, so, se in run_parallel([conv_only(emu_full_lib, {"KMX_EMU_LATE_DMA": mode}) for mode in ("1", "2")]):
+        assert rc == 0 and "RESULT " in so, (so + se)[-3000:]
+        for k, v in json.loads(so.split("RESULT ")[1]).items():
+            assert v[0] <= 2.0 ** -7 * max(1.0, v[1]) * 1.5, (k, v)
 
 
 def test_latest_completion_catches_a_wrong_count(tmp_path):
@@ -32,7 +33,7 @@ def test_latest_completion_catches_a_wrong_count(tmp_path):
         (r"static constexpr int VMCNT_W = \(D - 2\) \* NPW,", "static constexpr int VMCNT_W = 1 + (D - 2) * NPW,", 1),
     ], small_mutations=[
         # the fetching waves of the small-batch shape let one request more stay in flight than slab s + 1 allows
-        (r"if\(\(t \+ NT - 1\) % NT < NPA\) waitVm<2>\(\);\n          else waitVm<1>\(\);", "if((t + NT - 1) % NT < NPA) waitVm<3>();\n          else waitVm<2>();", 1),
+        (r"if\(slabWave\) convk::waitVmSel\(G::vmAt\(t\)\);", "if(slabWave) convk::waitVmSel(G::vmAt(t) + 1);", 1),
     ], pw2_mutations=[
         # the persistent seam kernel: phase 2 of a part lets one request more stay in flight than its loads and stores account for
         (r"waitVmSel\(G::nR\(q\) \+ 2\);", "waitVmSel(G::nR(q) + 2 + 1);", 1),
@@ -47,7 +48,7 @@ def test_latest_completion_catches_a_wrong_count(tmp_path):
     print("late completion, one request too generous:", late)
     assert "conv3_64_32" in wrong and "conv3_96_192" in wrong, late  # the padded 4-wave shape and the 8-wave loader shape
     # the small-batch shape with its fetching waves' wait one request too generous
-    runs = run_parallel([([sys.executable, "-c", CW12_CODE, lib], dict(os.environ, KMX_CONV_LOADERS="1", KMX_EMU_LATE_DMA=late_)) for late_ in ("0", "1")])
+    runs = run_parallel([([sys.executable, "-c", CW12_CODE, lib], dict(os.environ, KMX_CONV_LOADERS="1", KMX_EMU_LATE_DMA=late_)) for late_ in ("0", "2")])
     (rc0, so0, se0), (rc1, so1, se1) = runs
     assert rc0 == 0 and rc1 == 0, (so0 + se0 + so1 + se1)[-3000:]
     c0, c1 = json.loads(so0.split("RESULT ")[1]), json.loads(so1.split("RESULT ")[1])
@@ -89,11 +90,14 @@ print("RESULT " + json.dumps(out))
 
 def test_small_batch_shape_with_fetching_waves(emu_full_lib):
     """cfg 118 (conv_small_kernel.h: four multiplying waves of three cell tiles, four waves that issue every LDS-DMA request): against
-    conv2d with immediate and with the latest legal completion of its requests, and BIT-IDENTICAL to the 4-wave shapes of
+    conv2d with immediate and with the latest legal completion of its requests (at the wait; at the barrier after the wait - the mode
+    that fails round 4's deleted third depth, which the MI355X also did), at both fetch depths (SG<PACK, DEPTH>: slabs 3 / 6 steps
+    ahead, the image 1 / 2 chunks), and BIT-IDENTICAL to the 4-wave shapes of
     conv_kernel.h the same layers take without it (same MFMAs per output in the same K order) - square, rectangular and several
     boards, channel counts that are not multiples of the tile."""
-    runs = run_parallel([([sys.executable, "-c", CW12_CODE, emu_full_lib], dict(os.environ, KMX_CONV_LOADERS=ld, KMX_EMU_LATE_DMA=late))
-                         for ld, late in (("0", "0"), ("1", "0"), ("1", "1"))])
+    runs = run_parallel([([sys.executable, "-c", CW12_CODE, emu_full_lib],
+                          dict(os.environ, KMX_CONV_LOADERS=ld, KMX_CONV_LOADERS_DEPTH=depth, KMX_EMU_LATE_DMA=late))
+                         for ld, depth, late in (("0", "0", "0"), ("1", "0", "0"), ("1", "0", "2"), ("1", "1", "0"), ("1", "1", "1"), ("1", "1", "2"))])
     res = []
     for rc, so, se in runs:
         assert rc == 0 and "RESULT " in so, (so + se)[-3000:]
