@@ -5,8 +5,8 @@ threads (integration/katamx_fibers.cpp) - against the device-resident rate of be
 
 Round 2 measured 22-32 k nnEvals/s through the reference's callers (one blocked OS thread per leaf) beside 37-42 k
 device-resident. The bar here: >= 90 % of the device-resident rate, from a real search - asserted on searches long enough for their
-ramp-up and drain not to dominate (32000 visits), and against the search's own ceiling on boxes whose device outruns it (round 4: the
-device reached 43-44 k evals/s, the reference's search with 1024 threads in one tree tops out at ~40 k descents/s on these hosts)."""
+ramp-up and drain not to dominate (32000 visits; 1024 threads in one tree start on a narrow tree, and the first passes of a search
+hold a handful of rows); the 8000- and 1600-visit rates are reported beside it."""
 import json
 import os
 import re
@@ -64,9 +64,8 @@ def test_search_driven_rate_reaches_the_device_rate(tmp_path):
         with open(os.path.join(keep, "search_driven_rate.txt"), "w") as f:
             f.write("\n".join(lines) + "\n")
     assert c[3] == 63 and c[1] == c[2] and c[1] > 10000, c
-    # Round 4, boxes whose device does 38.5 / 43.3 k evals/s: 32000-visit searches reach 38.7 k (100 %) / 39.5 k (91 %, before the
-    # batcher went back to one granule per batch); 8000-visit searches 35.4 / 37.2 k. The search's own ceiling on these hosts is
-    # ~40 k descents/s (it does not rise with 2048 threads or longer searches), so the bar is 90 % of the device or of that ceiling.
-    assert long_rate >= 0.9 * min(device, 40000.0), lines
-    assert rate >= 0.8 * min(device, 40000.0), lines
+    # Round 4's final kernels and batcher, boxes whose device does 38.5 / 43.6 k evals/s: 32000-visit searches reach 38.7 k (100 %) /
+    # 42.4 k (97 %), 8000-visit searches 35.4 k (92 %) / 40.9 k (94 %), 1600-visit searches 36.3 k (83 %) on the faster box.
+    assert long_rate >= 0.9 * device, lines
+    assert rate >= 0.8 * device, lines
     assert rate >= 0.9 * threads_rate, lines  # (since the batcher seals at the device's granule, 512 OS threads are not far behind)
