@@ -27,7 +27,22 @@ using namespace convk;
 // four multiplying waves of three cell tiles each and four waves that issue every LDS-DMA request: 22.0 -> 17.3 us per 3x3 launch at
 // batch 1 against round 3's shape of twelve cell waves (cfg 111, removed), a pass 2.30 -> 2.00 ms at batch 1, 2.51 -> 2.34 at batch 8
 // (profiles/r04_steps/small_batch). KMX_CONV_LOADERS=0 / 1 overrides the default (0: the 4-wave shapes of conv_kernel.h).
+// 1x1 at small batch, cfg 114 / 115 (round 4): the 4-wave x 32-channel shape of conv_kernel.h with a ring of FOUR (five: 115) steps instead of two. A 1x1
+// step is a whole 32-channel image chunk (23 KB) and two MFMAs per wave; with one step of cover every step waited out a memory round
+// trip - 14.4 us of kernel time for the 12 steps of a 384 -> 192 layer at batch 8 (profiles/r04_steps/call1/trace_pass8_kernel_stats.csv),
+// 37 such launches per pass. One work-group per CU either way (LDS 81 -> 132 / 157 KB). KMX_CONV_DEEP1X1 = 0 | 4 | 5 (0: the two-step ring).
+constexpr int CFG_DEEP1X1_4 = 114, CFG_DEEP1X1_5 = 115;
+constexpr int CFG_DEEP1X1_64 = 124;  // the 4-wave x 64-channel shape with a ring of four (LDS 86 -> 141 KB), for the next 256 work-groups
+int deep1x1() {
+  static const int d = [] {
+    const char* e = getenv("KMX_CONV_DEEP1X1");
+    const int v = e ? atoi(e) : 4;
+    return v == 4 || v == 5 ? v : 0;
+  }();
+  return d;
+}
 constexpr int CFG_LOADERS = 118;
+constexpr int CFG_LOADERS_SPLIT = 117;   // the same with a board's cell tiles over three work-groups (conv_small_kernel.h MTW = 1)
 constexpr int CFG_LOADERS_PACKED = 119;  // the same with two work-groups per CU (conv_small_kernel.h PACK)
 constexpr bool kLoadersDefault = true;
 bool loadersEnabled() {
@@ -51,9 +66,13 @@ template <class TR>
 hipError_t launchT(int ks, int cfg, const ConvArgs& a, hipStream_t stream) {
   if(ks == 3 && cfg == CFG_LOADERS) {
     const int depth = loadersDepth();
-    return depth == 0 ? smallk::launchSmall<TR, false, 0>(a, stream) : smallk::launchSmall<TR, false, 1>(a, stream);
+    return depth == 0 ? smallk::launchSmall<TR, false, 0, 3>(a, stream) : smallk::launchSmall<TR, false, 1, 3>(a, stream);
   }
-  if(ks == 3 && cfg == CFG_LOADERS_PACKED) return smallk::launchSmall<TR, true, 0>(a, stream);
+  if(ks == 3 && cfg == CFG_LOADERS_SPLIT) return smallk::launchSmall<TR, false, 1, 1>(a, stream);
+  if(ks == 3 && cfg == CFG_LOADERS_PACKED) return smallk::launchSmall<TR, true, 0, 3>(a, stream);
+  if(ks == 1 && cfg == CFG_DEEP1X1_4) return launchOne<TR, 1, 1, 1, 4, 0>(a, stream);
+  if(ks == 1 && cfg == CFG_DEEP1X1_5) return launchOne<TR, 1, 1, 1, 5, 0>(a, stream);
+  if(ks == 1 && cfg == CFG_DEEP1X1_64) return launchOne<TR, 1, 2, 1, 4, 0>(a, stream);
 #define KMX_CFG(KS_, WNW_, WN_, D_) \
   if(ks == KS_ && cfg == 10 * WNW_ + WN_) return launchOne<TR, KS_, WN_, WNW_, D_, 0>(a, stream);
   KMX_CFG_LIST(KMX_CFG)
@@ -72,7 +91,8 @@ hipError_t launchConv(int dtype, int ks, int cfg, const ConvArgs& a, hipStream_t
 }
 
 bool convCfgInstantiated(int ks, int cfg) {
-  if(ks == 3 && (cfg == CFG_LOADERS || cfg == CFG_LOADERS_PACKED)) return true;
+  if(ks == 3 && (cfg == CFG_LOADERS || cfg == CFG_LOADERS_SPLIT || cfg == CFG_LOADERS_PACKED)) return true;
+  if(ks == 1 && (cfg == CFG_DEEP1X1_4 || cfg == CFG_DEEP1X1_5 || cfg == CFG_DEEP1X1_64)) return true;
 #define KMX_CFG(KS_, WNW_, WN_, D_) \
   if(ks == KS_ && cfg == 10 * WNW_ + WN_) return true;
   KMX_CFG_LIST(KMX_CFG)
@@ -105,6 +125,12 @@ int chooseConvCfg(int ks, int coutPad, int batch) {
     const char* e = getenv("KMX_CONV_LOADERS_MAX_WGS");
     return e ? atoi(e) : 256;
   }();
+  // ... its cell tiles over three work-groups while even that leaves CUs idle (KMX_CONV_LOADERS_SPLIT=0 | 1)
+  static const bool splitOn = [] {
+    const char* e = getenv("KMX_CONV_LOADERS_SPLIT");
+    return e ? e[0] == '1' : true;
+  }();
+  if(ks == 3 && loadersEnabled() && splitOn && batch * tiles * 3 <= loadersMaxWgs) return CFG_LOADERS_SPLIT;
   if(ks == 3 && loadersEnabled() && batch * tiles <= loadersMaxWgs) return CFG_LOADERS;
   // ... and two per CU up to twice that (KMX_CONV_LOADERS_PACKED_MAX_WGS; 0 = off). Measured on the MI355X, b18c384nbt device-resident:
   // batch 43 2.72 -> 2.43 ms per pass, 48 2.77 -> 2.51, 64 2.86 -> 2.69, 85 3.06 -> 3.05; beyond two per CU it loses (96: 3.89 -> 4.10 ms),
@@ -114,6 +140,13 @@ int chooseConvCfg(int ks, int coutPad, int batch) {
     return e ? atoi(e) : 512;
   }();
   if(ks == 3 && loadersEnabled() && batch * tiles <= packedMaxWgs) return CFG_LOADERS_PACKED;
+  // 1x1 while every work-group has a CU to itself: the deep ring
+  static const int deep32MaxWgs = [] {  // (tests: 0 sends every 1x1 layer with an even tile count to the 64-channel deep shape)
+    const char* e = getenv("KMX_CONV_DEEP1X1_MAX_WGS");
+    return e ? atoi(e) : 256;
+  }();
+  if(ks == 1 && deep1x1() != 0 && batch * tiles <= deep32MaxWgs) return deep1x1() == 5 ? CFG_DEEP1X1_5 : CFG_DEEP1X1_4;
+  if(ks == 1 && deep1x1() != 0 && tiles % 2 == 0 && batch * (tiles / 2) <= 256) return CFG_DEEP1X1_64;
   // 3x3/5x5 narrow shapes keep two work-groups per CU (LDS), 1x1 shapes one
   const int round = ks == 1 ? 200 : 420;
   if(fits(11) && wgs(11) <= round) return 11;

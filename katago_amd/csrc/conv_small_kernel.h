@@ -88,7 +88,7 @@ static_assert(SG<true, 0>::virtualImg() == 1 && SG<false, 1>::virtualImg() == 4,
 
 // PACK (the second instantiation): register allocation capped at 128 per lane so that TWO work-groups share a CU (4 waves per SIMD, 2 x 68 KB
 // of LDS) - for batches whose work-groups outnumber the CUs; the cap costs 48 bytes of scratch per lane outside the loop.
-template <class TR, bool PACK, int DEPTH>
+template <class TR, bool PACK, int DEPTH, int MTW>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ? 4 : 2, PACK ? 4 : 3))) void convSmallKernel(const ConvArgs a) {
   typedef typename TR::T T;
   typedef typename TR::V8 V8;
@@ -228,40 +228,43 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
   unsigned wLane[2];
 #pragma unroll
   for(int kk = 0; kk < 2; kk++) wLane[kk] = bufW + (unsigned)(lane & 31) * ROWB + (((kk * 2 + khalf) ^ wXor) << 4);
-  unsigned aRow4[MT];
-  int cellOfTile[MT];
+  // MTW = 3: the wave's three cell tiles; MTW = 1 (grid z = 3): tile blockIdx.z of them - three work-groups share a board x 32 channels,
+  // each fetches the whole image and slabs and does a third of the matrix work (see launchSmall)
+  const int pt0 = MTW == MT ? 0 : (int)blockIdx.z;
+  unsigned aRow4[MTW];
+  int cellOfTile[MTW];
 #pragma unroll
-  for(int pt = 0; pt < MT; pt++) {
-    int j = wm * (32 * MT) + pt * 32 + myPos;
+  for(int pt = 0; pt < MTW; pt++) {
+    int j = wm * (32 * MT) + (pt0 + pt) * 32 + myPos;
     j = cellOf(j < S ? j : S - 1);
     cellOfTile[pt] = j;
     const int y = j / X, x = j - y * X;
     aRow4[pt] = (unsigned)((y + HALO) * W2 + (x + HALO)) << 2;
   }
   const unsigned c40 = khalf << 4;
-  const bool waveActive = wm * (32 * MT) < S;
+  const bool waveActive = wm * (32 * MT) + pt0 * 32 < S;
   auto ldsV8 = [&](unsigned addr) { return *(const __attribute__((address_space(3))) V8*)addr; };
   auto ldsF4 = [&](unsigned addr) { return *(const __attribute__((address_space(3))) f32x4*)addr; };
   auto ldsF1 = [&](unsigned addr) { return *(const __attribute__((address_space(3))) float*)addr; };
 
-  f32x16 acc[MT];
+  f32x16 acc[MTW];
 #pragma unroll
-  for(int pt = 0; pt < MT; pt++)
+  for(int pt = 0; pt < MTW; pt++)
 #pragma unroll
     for(int r = 0; r < 16; r++) acc[pt][r] = 0.0f;
 
   waitVm<0>();  // this wave's mask and parameter requests
   __builtin_amdgcn_s_barrier();  // slab 0 and image 0 are published
   asm volatile("" ::: "memory");
-  V8 wf[2], af[2][MT];
-  unsigned aAddr[MT];
+  V8 wf[2], af[2][MTW];
+  unsigned aAddr[MTW];
   // fragments of step 0, k half 0
   {
     wf[0] = ldsV8(wLane[0]);
     unsigned sTap = (unsigned)(((0 - HALO) * W2 + (0 - HALO)) * 4) + (ldsBase >> 4);
     asm volatile("" : "+s"(sTap));
 #pragma unroll
-    for(int pt = 0; pt < MT; pt++) {
+    for(int pt = 0; pt < MTW; pt++) {
       const unsigned q4 = aRow4[pt] + sTap;
       aAddr[pt] = (q4 << 4) | ((q4 ^ c40) & 0x30u);
       af[0][pt] = ldsV8(aAddr[pt]);
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
   // first k half: the MFMAs of fragment set 0; behind them, one by one, the reads of set 1 (this step's slab, this tap)
       const unsigned wb1 = wLane[1] + (unsigned)(step % NSW) * W_BYTES;
 #pragma unroll
-      for(int pt = 0; pt < MT; pt++) {
+      for(int pt = 0; pt < MTW; pt++) {
         acc[pt] = TR::mfma(wf[0], af[0][pt], acc[pt]);
         __builtin_amdgcn_sched_barrier(0);
         if(pt == 0) wf[1] = ldsV8(wb1);
@@ -294,13 +297,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
         unsigned sTap = (unsigned)(((tn / 3 - HALO) * W2 + (tn % 3 - HALO)) * 4) + ((ldsBase + (t + 1 < NT ? curA : nextA)) >> 4);
         asm volatile("" : "+s"(sTap));
 #pragma unroll
-        for(int pt = 0; pt < MT; pt++) {
+        for(int pt = 0; pt < MTW; pt++) {
           const unsigned q4 = aRow4[pt] + sTap;
           aAddr[pt] = (q4 << 4) | ((q4 ^ c40) & 0x30u);
         }
       }
 #pragma unroll
-      for(int pt = 0; pt < MT; pt++) {
+      for(int pt = 0; pt < MTW; pt++) {
         acc[pt] = TR::mfma(wf[1], af[1][pt], acc[pt]);
         __builtin_amdgcn_sched_barrier(0);
         if(pt == 0) wf[0] = ldsV8(wb0);
@@ -335,8 +338,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
     };
     if(RESID) loadResid(0, rq[0]);
 #pragma unroll
-    for(int pt = 0; pt < MT; pt++) {
-      const int cellBase = wm * (32 * MT) + pt * 32;
+    for(int pt = 0; pt < MTW; pt++) {
+      const int cellBase = wm * (32 * MT) + (pt0 + pt) * 32;
       if(cellBase >= S) break;  // wave-uniform
       const bool live = cellBase + myPos < S;
       const int cell = cellOfTile[pt];
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
       u32x2 rp[4], op[4];
       u32x2 resP[4];
       if(RESID) {
-        if(pt + 1 < MT) loadResid(pt + 1, rq[(pt + 1) & 1]);
+        if(pt + 1 < MTW) loadResid(pt + 1, rq[(pt + 1) & 1]);
         unpair(rq[pt & 1], resP);
       }
 #pragma unroll
@@ -409,10 +412,15 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
   });
 }
 
-template <class TR, bool PACK, int DEPTH>
+// MTW = 1: the cell tiles of a board x 32 channels over THREE work-groups (grid z) - for batches that leave most CUs idle (batch x
+// channel tiles x 3 <= the CU count). A work-group's time at batch 1 is its 54 steps of six MFMAs and eight fragment reads per wave; with
+// two MFMAs and four reads per step it is shorter, and three times as many CUs work. Every work-group still fetches the whole image
+// and every slab (the fetching waves are unchanged): three times the L2 traffic, which is idle at these sizes. Outputs are computed by
+// the same MFMAs in the same order: bit-identical.
+template <class TR, bool PACK, int DEPTH, int MTW>
 hipError_t launchSmall(const ConvArgs& a, hipStream_t stream) {
   if(a.coutPad % NTILE != 0) return hipErrorInvalidValue;
-  auto kern = convSmallKernel<TR, PACK, DEPTH>;
+  auto kern = convSmallKernel<TR, PACK, DEPTH, MTW>;
   constexpr int LDS_BYTES = SG<PACK, DEPTH>::LDS_BYTES;
   constexpr int MAX_DEVICES = 64;  // the > 64 KiB LDS opt-in is per function AND device (conv_kernel.h launchOne)
   static std::atomic<bool> attrSet[MAX_DEVICES];
@@ -425,7 +433,7 @@ hipError_t launchSmall(const ConvArgs& a, hipStream_t stream) {
     if(e != hipSuccess) return e;
     attrSet[dev].store(true, std::memory_order_release);
   }
-  hipLaunchKernelGGL(kern, dim3(a.coutPad / NTILE, a.N, 1), dim3(NTHREADS), LDS_BYTES, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.coutPad / NTILE, a.N, MT / MTW), dim3(NTHREADS), LDS_BYTES, stream, a);
   return hipGetLastError();
 }
 

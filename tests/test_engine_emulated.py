@@ -175,7 +175,7 @@ def emu_full_lib(tmp_path_factory):
 
 
 CONV_ONLY = r"""
-import sys, json
+import sys, json, hashlib
 sys.path.insert(0, %r)
 import numpy as np, torch
 from katago_amd import capi
@@ -190,7 +190,8 @@ for (ks, cin, cout, X, Y, n) in json.loads(sys.argv[2]):
     xt = torch.from_numpy(x.reshape(n, Y, X, cin).transpose(0, 3, 1, 2)).to(torch.bfloat16).float()
     wt = torch.from_numpy(w).to(torch.bfloat16).float()
     want = torch.nn.functional.conv2d(xt, wt, padding=ks // 2).numpy().transpose(0, 2, 3, 1).reshape(n, Y * X, cout)
-    out["conv%%d_%%d_%%d" %% (ks, cin, cout)] = [float(np.abs(got.reshape(want.shape) - want).max()), float(np.abs(want).max())]
+    out["conv%%d_%%d_%%d" %% (ks, cin, cout)] = [float(np.abs(got.reshape(want.shape) - want).max()), float(np.abs(want).max()),
+                                              hashlib.sha1(np.ascontiguousarray(got).tobytes()).hexdigest()]
 print("RESULT " + json.dumps(out))
 """ % (REPO,)
 # 3x3 on the 4-wave x 32-channel shape (every wave issues weights and image pieces, padded to a constant count), 1x1 (whole images
@@ -198,10 +199,12 @@ print("RESULT " + json.dumps(out))
 LATE_DMA_SHAPES = [(3, 64, 32, 9, 9, 1), (1, 96, 64, 13, 13, 1), (5, 32, 64, 9, 9, 1), (3, 96, 192, 19, 19, 1)]
 
 
-def conv_only(lib, env):
+def conv_only(lib, env, shapes=None):
     # (KMX_CONV_LOADERS=0: the small 3x3 case is to take the padded 4-wave shape of conv_kernel.h here; the shape with fetching waves,
-    # conv_small_kernel.h, has its own tests)
-    return [sys.executable, "-c", CONV_ONLY, lib, json.dumps(LATE_DMA_SHAPES)], dict(os.environ, KMX_MIN_WGS8="1", KMX_CONV_LOADERS="0", **env)
+    # conv_small_kernel.h, has its own tests. The 1x1 case takes the deep-ring shape, cfg 114; the two-step ring and the other deep
+    # shapes are in test_kernels_latest_completion.py::test_deep_ring_1x1_shapes)
+    return ([sys.executable, "-c", CONV_ONLY, lib, json.dumps(shapes or LATE_DMA_SHAPES)],
+            dict(os.environ, KMX_MIN_WGS8="1", KMX_CONV_LOADERS="0", **env))
 
 
 def test_real_convolution_kernel_emulated(emu_full_lib):

@@ -92,12 +92,15 @@ def test_small_batch_shape_with_fetching_waves(emu_full_lib):
     """cfg 118 (conv_small_kernel.h: four multiplying waves of three cell tiles, four waves that issue every LDS-DMA request): against
     conv2d with immediate and with the latest legal completion of its requests (at the wait; at the barrier after the wait - the mode
     that fails round 4's deleted third depth, which the MI355X also did), at both fetch depths (SG<PACK, DEPTH>: slabs 3 / 6 steps
-    ahead, the image 1 / 2 chunks), and BIT-IDENTICAL to the 4-wave shapes of
+    ahead, the image 1 / 2 chunks) and with a board's cell tiles split over three work-groups (cfg 117, MTW = 1), and BIT-IDENTICAL to the 4-wave shapes of
     conv_kernel.h the same layers take without it (same MFMAs per output in the same K order) - square, rectangular and several
     boards, channel counts that are not multiples of the tile."""
+    # (loaders, fetch depth, cell tiles split over three work-groups (cfg 117), completion mode)
+    variants = (("0", "0", "0", "0"), ("1", "0", "0", "0"), ("1", "0", "0", "2"), ("1", "1", "0", "0"), ("1", "1", "0", "1"), ("1", "1", "0", "2"),
+                ("1", "1", "1", "0"), ("1", "1", "1", "2"))
     runs = run_parallel([([sys.executable, "-c", CW12_CODE, emu_full_lib],
-                          dict(os.environ, KMX_CONV_LOADERS=ld, KMX_CONV_LOADERS_DEPTH=depth, KMX_EMU_LATE_DMA=late))
-                         for ld, depth, late in (("0", "0", "0"), ("1", "0", "0"), ("1", "0", "2"), ("1", "1", "0"), ("1", "1", "1"), ("1", "1", "2"))])
+                          dict(os.environ, KMX_CONV_LOADERS=ld, KMX_CONV_LOADERS_DEPTH=depth, KMX_CONV_LOADERS_SPLIT=split, KMX_EMU_LATE_DMA=late))
+                         for ld, depth, split, late in variants])
     res = []
     for rc, so, se in runs:
         assert rc == 0 and "RESULT " in so, (so + se)[-3000:]
@@ -107,3 +110,23 @@ def test_small_batch_shape_with_fetching_waves(emu_full_lib):
             assert v[0] <= 2.0 ** -7 * max(1.0, v[1]) * 1.5, (k, v)
     for k in res[0]:
         assert len({r[k][2] for r in res}) == 1, ("not bit-identical across shapes", k, [r[k] for r in res])
+
+
+def test_deep_ring_1x1_shapes(emu_full_lib):
+    """cfg 114 / 115 / 124 (conv_mfma.hip, round 4): the 1x1 shapes of conv_kernel.h with a ring of four or five steps instead of two -
+    a 1x1 step is a whole image chunk, and at small batch every step of the two-step ring waited out a memory round trip. Layers with
+    fewer steps than the ring is deep (96 channels: 3), with many (384: 12), several boards, a rectangular board; with immediate copies
+    and both latest-completion modes; BIT-IDENTICAL to the two-step ring (same MFMAs per output in the same K order)."""
+    shapes = [(1, 96, 64, 13, 13, 1), (1, 384, 96, 19, 19, 2), (1, 40, 192, 9, 7, 3)]
+    envs = [{"KMX_CONV_DEEP1X1": "0"},
+            {"KMX_CONV_DEEP1X1": "4"}, {"KMX_CONV_DEEP1X1": "4", "KMX_EMU_LATE_DMA": "2"},
+            {"KMX_CONV_DEEP1X1": "5", "KMX_EMU_LATE_DMA": "1"}, {"KMX_CONV_DEEP1X1": "5", "KMX_EMU_LATE_DMA": "2"},
+            {"KMX_CONV_DEEP1X1": "4", "KMX_CONV_DEEP1X1_MAX_WGS": "0", "KMX_EMU_LATE_DMA": "2"}]  # the 64-channel deep shape where tiles are even
+    res = []
+    for env, (rc, so, se) in zip(envs, run_parallel([conv_only(emu_full_lib, env, shapes) for env in envs])):
+        assert rc == 0 and "RESULT " in so, (env, (so + se)[-3000:])
+        res.append(json.loads(so.split("RESULT ")[1]))
+        for k, v in res[-1].items():
+            assert v[0] <= 2.0 ** -7 * max(1.0, v[1]) * 1.5, (env, k, v)
+    for k in res[0]:
+        assert len({r[k][2] for r in res}) == 1, ("not bit-identical across ring depths", k, [r[k] for r in res])
