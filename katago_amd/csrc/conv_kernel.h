@@ -62,6 +62,7 @@ constexpr int MAXLEN = 19;
 enum { ABL_NO_EPILOGUE = 1, ABL_NO_COMPUTE = 2, ABL_NO_DMA = 4, ABL_NO_LDS_READ = 8, ABL_NO_VMWAIT = 16, ABL_NO_W_DMA = 32, ABL_NO_A_DMA = 64,
        ABL_EPI_NOACT = 512, ABL_EPI_NOSTORE = 1024,
        ABL_TIMING = 2048 /* s_memtime stamps between the segments of a step, summed per wave into ConvArgs::dbg */,
+       ABL_SPLIT = 262144 /* NOT an ablation: the cell tiles of a board over three work-groups, see the kernel */,
        ABL_BATCHED = 131072 /* the round-2 form of a step (A/B): the six fragment reads of a half-step as one batch behind its first MFMA, the step's LDS-DMA requests as one batch between the halves */, };
 
 // Four waves along the cell dimension, each owning 3 tiles of 32 cells (4 x 96 = 384 >= 361). (Round 3's small-batch shape of twelve
@@ -190,6 +191,10 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   typedef Geom<KS, WN, WNW, D> G;
   constexpr int HALO = G::HALO, NT = G::NT, NPA = G::NPA, NPW = G::NPW, NWAVES = G::NWAVES;
   constexpr bool SPREAD = G::SPREAD;
+  // ABL_SPLIT (a product shape, not an ablation: conv_mfma.hip cfg 113): the wave's three cell tiles over THREE work-groups (grid z), one
+  // each - every work-group fetches the whole image and every slab and does a third of the matrix work; for batches that leave CUs idle
+  constexpr int MTL = (ABL & ABL_SPLIT) ? 1 : MT;  // cell tiles per wave in THIS work-group
+  const int pt0 = (ABL & ABL_SPLIT) ? (int)blockIdx.z : 0;
 
   const unsigned long long tKernel0 = (ABL & ABL_TIMING) ? __builtin_readcyclecounter() : 0;  // work-group start
   extern __shared__ __attribute__((aligned(256))) char smem[];
@@ -247,8 +252,8 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   // (possible when the image pieces have all been requested before the slab that is waited for at the last tap: LS <= NT + 1 - D)
   constexpr bool ONE = ROLES && SPREAD && G::LS <= NT + 1 - D;
   // the step's fragment reads (and, in the ONE division, its DMA requests) spread over its MFMAs: needs a slot per read in each half
-  constexpr bool SPREAD_STEP = WN * MT >= WN + MT && !(ABL & (ABL_BATCHED | ABL_TIMING));
-  constexpr int SLOTS = WN * MT - (WN + MT);                           // MFMAs of a half-step that carry no fragment read
+  constexpr bool SPREAD_STEP = WN * MTL >= WN + MTL && !(ABL & (ABL_BATCHED | ABL_TIMING));
+  constexpr int SLOTS = WN * MTL - (WN + MTL);                           // MFMAs of a half-step that carry no fragment read
   constexpr bool SPREAD_DMA = SPREAD_STEP && ONE && 2 * SLOTS >= 1 + NPW;  // the image piece(s) of the tap + the slab's instructions
   const bool wLoader = !ROLES || wave < G::NLW;   // wave-uniform
   const bool aLoader = !ROLES || (ONE ? wave < 4 : wave >= G::NLW);
@@ -314,24 +319,24 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
   for(int kk = 0; kk < 2; kk++)
     wLane[kk] = ldsBase + G::NSA * G::ACT_BYTES + (wn * (32 * WN) + (lane & 31)) * ROWB + (((kk * 2 + khalf) ^ wXor) << 4);
-  // activations: 4 x (halo-image row) of this lane's cell in each of its MT tiles; row q lives at byte q*64 and its
+  // activations: 4 x (halo-image row) of this lane's cell in each of its MTL tiles; row q lives at byte q*64 and its
   // logical 16-byte slot c at physical slot c ^ ((q>>2)&3):  address = (4q << 4) | ((4q ^ (c<<4)) & 0x30)
-  unsigned aRow4[MT];
+  unsigned aRow4[MTL];
 #pragma unroll
-  for(int pt = 0; pt < MT; pt++) {
-    int j = wm * (32 * MT) + pt * 32 + myPos;
+  for(int pt = 0; pt < MTL; pt++) {
+    int j = wm * (32 * MT) + (pt0 + pt) * 32 + myPos;
     j = cellOf(j < S ? j : S - 1);  // columns beyond the board recompute the last one; never stored
     int y = j / X;
     int x = j - y * X;
     aRow4[pt] = (unsigned)((y + HALO) * W2 + (x + HALO)) << 2;
   }
   const unsigned c40 = khalf << 4;
-  const bool waveActive = wm * (32 * MT) < S;
+  const bool waveActive = wm * (32 * MT) + pt0 * 32 < S;
 
   // Fragment readers. A step's 16 k-values per MFMA come as two halves kk = 0, 1 (register sets F0, F1).
   V8 wf[2][WN];
-  V8 af[2][MT];
-  unsigned aAddr[MT];  // kk=0 addresses of the tap last prepared; the kk=1 fragments sit 32 bytes away (slot ^ 2)
+  V8 af[2][MTL];
+  unsigned aAddr[MTL];  // kk=0 addresses of the tap last prepared; the kk=1 fragments sit 32 bytes away (slot ^ 2)
   auto ldsV8 = [&](unsigned addr) { return *(const __attribute__((address_space(3))) V8*)addr; };
   auto readW = [&](int kk, int stepIdx) {
     if(ABL & (ABL_NO_LDS_READ | ABL_NO_COMPUTE)) return;
@@ -343,11 +348,11 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   auto readA0 = [&](unsigned imgOff, int t) {
     if(ABL & (ABL_NO_LDS_READ | ABL_NO_COMPUTE)) return;
     // 4 x (row offset of the tap) plus the buffer offset, both wave-uniform; opaque to the optimiser on purpose:
-    // hoisted out of the chunk loop the NT*MT addresses cost more registers than the two-wave-per-SIMD budget has
+    // hoisted out of the chunk loop the NT*MTL addresses cost more registers than the two-wave-per-SIMD budget has
     unsigned sTap = (unsigned)(((t / KS - HALO) * W2 + (t % KS - HALO)) * 4) + ((ldsBase + imgOff) >> 4);
     asm volatile("" : "+s"(sTap));
 #pragma unroll
-    for(int pt = 0; pt < MT; pt++) {
+    for(int pt = 0; pt < MTL; pt++) {
       const unsigned q4 = aRow4[pt] + sTap;
       aAddr[pt] = (q4 << 4) | ((q4 ^ c40) & 0x30u);
       af[0][pt] = ldsV8(aAddr[pt]);
@@ -356,16 +361,16 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   auto readA1 = [&]() {
     if(ABL & (ABL_NO_LDS_READ | ABL_NO_COMPUTE)) return;
 #pragma unroll
-    for(int pt = 0; pt < MT; pt++) af[1][pt] = ldsV8(aAddr[pt] ^ 0x20u);
+    for(int pt = 0; pt < MTL; pt++) af[1][pt] = ldsV8(aAddr[pt] ^ 0x20u);
   };
-  // MFMAs [first, last) of the WN*MT that consume fragment set kk
-  auto mfmaPart = [&](int kk, int first, int last, f32x16 (&acc)[WN][MT]) {
+  // MFMAs [first, last) of the WN*MTL that consume fragment set kk
+  auto mfmaPart = [&](int kk, int first, int last, f32x16 (&acc)[WN][MTL]) {
     if(ABL & ABL_NO_COMPUTE) return;
 #pragma unroll
     for(int ct = 0; ct < WN; ct++)
 #pragma unroll
-      for(int pt = 0; pt < MT; pt++)
-        if(ct * MT + pt >= first && ct * MT + pt < last) acc[ct][pt] = TR::mfma(wf[kk][ct], af[kk][pt], acc[ct][pt]);
+      for(int pt = 0; pt < MTL; pt++)
+        if(ct * MTL + pt >= first && ct * MTL + pt < last) acc[ct][pt] = TR::mfma(wf[kk][ct], af[kk][pt], acc[ct][pt]);
   };
 #pragma unroll
   for(int kk = 0; kk < 2; kk++) {
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
       for(int i = 0; i < 8; i++) wf[kk][ct][i] = (T)(0.001f * (float)(lane + ct));
 #pragma unroll
-    for(int pt = 0; pt < MT; pt++)
+    for(int pt = 0; pt < MTL; pt++)
 #pragma unroll
       for(int i = 0; i < 8; i++) af[kk][pt][i] = (T)(0.002f * (float)(lane + pt));
   }
@@ -443,11 +448,11 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
     }
   }
 
-  f32x16 acc[WN][MT];
+  f32x16 acc[WN][MTL];
 #pragma unroll
   for(int ct = 0; ct < WN; ct++)
 #pragma unroll
-    for(int pt = 0; pt < MT; pt++)
+    for(int pt = 0; pt < MTL; pt++)
 #pragma unroll
       for(int r = 0; r < 16; r++) acc[ct][pt][r] = 0.0f;
 
@@ -577,7 +582,7 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
       // reads is issued right AFTER the first MFMA of the other fragment set: the wait it causes then only covers
       // reads that had eight MFMAs to land.
       if constexpr(SPREAD_STEP) {
-        // Round 3: the WN + MT fragment reads of a half-step ride behind its first MFMAs ONE BY ONE, and (8-wave 3x3 / 5x5 shapes) so
+        // Round 3: the WN + MTL fragment reads of a half-step ride behind its first MFMAs ONE BY ONE, and (8-wave 3x3 / 5x5 shapes) so
         // do the step's LDS-DMA requests behind the later ones. As batches - six ds_read_b128 behind the first MFMA, three or four
         // DMA instructions between the halves - they held the wave's issue stage while its matrix core ran dry: a DMA instruction
         // costs its wave 100-150 cycles of issue, and all eight waves hit the LDS with their batches right after the barrier.
@@ -585,13 +590,13 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
         // Same MFMAs in the same order: results are bit-identical to the batched form (ABL_BATCHED; the cycle stamps use it too).
         const unsigned wb1 = wLane[1] + (unsigned)(step % G::NSW) * G::W_BYTES;
 #pragma unroll
-        for(int idx = 0; idx < WN * MT; idx++) {
+        for(int idx = 0; idx < WN * MTL; idx++) {
           mfmaPart(0, idx, idx + 1, acc);
           __builtin_amdgcn_sched_barrier(0);
           if(idx < WN) wf[1][idx] = ldsV8(wb1 + idx * 32 * ROWB);
-          else if(idx < WN + MT) af[1][idx - WN] = ldsV8(aAddr[idx - WN] ^ 0x20u);
+          else if(idx < WN + MTL) af[1][idx - WN] = ldsV8(aAddr[idx - WN] ^ 0x20u);
           if constexpr(SPREAD_DMA) {
-            if(idx >= WN + MT) issueOneDma(chunk, t, step, idx - (WN + MT));  // requests 0 .. WN*MT - WN - MT - 1
+            if(idx >= WN + MTL) issueOneDma(chunk, t, step, idx - (WN + MTL));  // requests 0 .. WN*MTL - WN - MTL - 1
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -603,19 +608,19 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
           unsigned sTap = (unsigned)(((tn / KS - HALO) * W2 + (tn % KS - HALO)) * 4) + ((ldsBase + (t + 1 < NT ? curA : nextA)) >> 4);
           asm volatile("" : "+s"(sTap));
 #pragma unroll
-          for(int pt = 0; pt < MT; pt++) {
+          for(int pt = 0; pt < MTL; pt++) {
             const unsigned q4 = aRow4[pt] + sTap;
             aAddr[pt] = (q4 << 4) | ((q4 ^ c40) & 0x30u);
           }
         }
 #pragma unroll
-        for(int idx = 0; idx < WN * MT; idx++) {
+        for(int idx = 0; idx < WN * MTL; idx++) {
           mfmaPart(1, idx, idx + 1, acc);
           __builtin_amdgcn_sched_barrier(0);
           if(idx < WN) wf[0][idx] = ldsV8(wb0 + idx * 32 * ROWB);
-          else if(idx < WN + MT) af[0][idx - WN] = ldsV8(aAddr[idx - WN]);
+          else if(idx < WN + MTL) af[0][idx - WN] = ldsV8(aAddr[idx - WN]);
           if constexpr(SPREAD_DMA) {
-            if(idx >= WN + MT) issueOneDma(chunk, t, step, SLOTS + idx - (WN + MT));  // the rest
+            if(idx >= WN + MTL) issueOneDma(chunk, t, step, SLOTS + idx - (WN + MTL));  // the rest
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -626,7 +631,7 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
       readW(1, step);
       readA1();
       __builtin_amdgcn_sched_barrier(0);
-      mfmaPart(0, 1, WN * MT, acc);
+      mfmaPart(0, 1, WN * MTL, acc);
       __builtin_amdgcn_sched_barrier(0);
       stamp(1);
       issueStep(chunk, t, step);  // (placing the image waves' requests at the start of the step instead measured 1-2 % slower)
@@ -637,7 +642,7 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
       readW(0, step + 1);
       readA0(t + 1 < NT ? curA : nextA, t + 1 < NT ? t + 1 : 0);
       __builtin_amdgcn_sched_barrier(0);
-      mfmaPart(1, 1, WN * MT, acc);
+      mfmaPart(1, 1, WN * MTL, acc);
       __builtin_amdgcn_sched_barrier(0);
       stamp(3);
     }
@@ -671,10 +676,10 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   // compiler waits for the residual loads below with s_waitcnt vmcnt(0), i.e. for every store issued before them to be
   // acknowledged by memory, once per tile.
   T* const trash = (T*)((char*)const_cast<void*>(a.zeroPage) + ZERO_PAGE_BYTES) + lane * 8;
-  int cellOfTile[MT];
+  int cellOfTile[MTL];
 #pragma unroll
-  for(int pt = 0; pt < MT; pt++) {
-    const int rc = wm * (32 * MT) + pt * 32 + myPos;
+  for(int pt = 0; pt < MTL; pt++) {
+    const int rc = wm * (32 * MT) + (pt0 + pt) * 32 + myPos;
     cellOfTile[pt] = cellOf(rc < S ? rc : S - 1);
   }
   float keep = 0.0f;  // ABL_NO_EPILOGUE: keeps the accumulators observable
@@ -700,8 +705,8 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
   };
   if(RESID) loadResid(0, 0, rq[0]);
 #pragma unroll
-  for(int pt = 0; pt < MT; pt++) {
-    const int cellBase = wm * (32 * MT) + pt * 32;
+  for(int pt = 0; pt < MTL; pt++) {
+    const int cellBase = wm * (32 * MT) + (pt0 + pt) * 32;
     if(cellBase >= S) break;  // wave-uniform
     if(ABL & ABL_NO_EPILOGUE) {
 #pragma unroll
@@ -730,7 +735,7 @@ __global__ __launch_bounds__(256 * WNW) __attribute__((amdgpu_waves_per_eu(2, 2)
       u32x2 rp[4], op[4];
       u32x2 resP[4];
       if(RESID) {
-        constexpr int NTILES = MT * WN;
+        constexpr int NTILES = MTL * WN;
         const int k = pt * WN + ct;
         // (a tile past the board still requests its pieces - of the last cell - so that the count in flight is a constant)
         if(k + 1 < NTILES) loadResid((k + 1) / WN, (k + 1) % WN, rq[(k + 1) & 1]);
@@ -833,7 +838,7 @@ hipError_t launchOne(const ConvArgs& a, hipStream_t stream) {
     attrSet[dev].store(true, std::memory_order_release);
   }
   if(a.coutPad % G::NTILE != 0) return hipErrorInvalidValue;
-  dim3 grid(a.coutPad / G::NTILE, a.N, 1);
+  dim3 grid(a.coutPad / G::NTILE, a.N, (ABL & ABL_SPLIT) ? MT : 1);
   hipLaunchKernelGGL(kern, grid, dim3(G::NTHREADS), ldsBytes, stream, a);
   return hipGetLastError();
 }

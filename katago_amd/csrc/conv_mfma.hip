@@ -32,6 +32,9 @@ using namespace convk;
 // trip - 14.4 us of kernel time for the 12 steps of a 384 -> 192 layer at batch 8 (profiles/r04_steps/call1/trace_pass8_kernel_stats.csv),
 // 37 such launches per pass. One work-group per CU either way (LDS 81 -> 132 / 157 KB). KMX_CONV_DEEP1X1 = 0 | 4 | 5 (0: the two-step ring).
 constexpr int CFG_DEEP1X1_4 = 114, CFG_DEEP1X1_5 = 115;
+// cfg 114 with a board's cell tiles over three work-groups (conv_kernel.h ABL_SPLIT) while batch x tiles x 3 <= 256: 1x1 launch 14.3 ->
+// 11.5 us at batch 1, a pass 1.53 -> 1.44 ms (1.72 -> 1.67 at batch 8); profiles/r04_steps/small_batch/split1x1_scan.txt
+constexpr int CFG_DEEP1X1_SPLIT = 113;
 constexpr int CFG_DEEP1X1_64 = 124;  // the 4-wave x 64-channel shape with a ring of four (LDS 86 -> 141 KB), for the next 256 work-groups
 int deep1x1() {
   static const int d = [] {
@@ -42,7 +45,9 @@ int deep1x1() {
   return d;
 }
 constexpr int CFG_LOADERS = 118;
-constexpr int CFG_LOADERS_SPLIT = 117;   // the same with a board's cell tiles over three work-groups (conv_small_kernel.h MTW = 1)
+// ... with a board's cell tiles over three work-groups (conv_small_kernel.h MTW = 1) while batch x channel tiles x 3 <= 256: same box,
+// 3x3 launch 16.5 -> 12.4 us at batch 1, 17.6 -> 13.5 at 8; a pass 1.90 -> 1.60 ms / 2.07 -> 1.77 (profiles/r04_steps/small_batch/split_scan.txt)
+constexpr int CFG_LOADERS_SPLIT = 117;
 constexpr int CFG_LOADERS_PACKED = 119;  // the same with two work-groups per CU (conv_small_kernel.h PACK)
 constexpr bool kLoadersDefault = true;
 bool loadersEnabled() {
@@ -73,6 +78,7 @@ hipError_t launchT(int ks, int cfg, const ConvArgs& a, hipStream_t stream) {
   if(ks == 1 && cfg == CFG_DEEP1X1_4) return launchOne<TR, 1, 1, 1, 4, 0>(a, stream);
   if(ks == 1 && cfg == CFG_DEEP1X1_5) return launchOne<TR, 1, 1, 1, 5, 0>(a, stream);
   if(ks == 1 && cfg == CFG_DEEP1X1_64) return launchOne<TR, 1, 2, 1, 4, 0>(a, stream);
+  if(ks == 1 && cfg == CFG_DEEP1X1_SPLIT) return launchOne<TR, 1, 1, 1, 4, ABL_SPLIT>(a, stream);
 #define KMX_CFG(KS_, WNW_, WN_, D_) \
   if(ks == KS_ && cfg == 10 * WNW_ + WN_) return launchOne<TR, KS_, WN_, WNW_, D_, 0>(a, stream);
   KMX_CFG_LIST(KMX_CFG)
@@ -92,7 +98,7 @@ hipError_t launchConv(int dtype, int ks, int cfg, const ConvArgs& a, hipStream_t
 
 bool convCfgInstantiated(int ks, int cfg) {
   if(ks == 3 && (cfg == CFG_LOADERS || cfg == CFG_LOADERS_SPLIT || cfg == CFG_LOADERS_PACKED)) return true;
-  if(ks == 1 && (cfg == CFG_DEEP1X1_4 || cfg == CFG_DEEP1X1_5 || cfg == CFG_DEEP1X1_64)) return true;
+  if(ks == 1 && (cfg == CFG_DEEP1X1_4 || cfg == CFG_DEEP1X1_5 || cfg == CFG_DEEP1X1_64 || cfg == CFG_DEEP1X1_SPLIT)) return true;
 #define KMX_CFG(KS_, WNW_, WN_, D_) \
   if(ks == KS_ && cfg == 10 * WNW_ + WN_) return true;
   KMX_CFG_LIST(KMX_CFG)
@@ -131,6 +137,8 @@ int chooseConvCfg(int ks, int coutPad, int batch) {
     return e ? e[0] == '1' : true;
   }();
   if(ks == 3 && loadersEnabled() && splitOn && batch * tiles * 3 <= loadersMaxWgs) return CFG_LOADERS_SPLIT;
+  // (split AND two work-groups per CU for the next 256 work-groups - 88 registers, 68 KB of LDS - measured within 1 % of the unsplit
+  // shape at batch 16 - 28 and is not kept: profiles/r04_steps/small_batch/split1x1_scan.txt)
   if(ks == 3 && loadersEnabled() && batch * tiles <= loadersMaxWgs) return CFG_LOADERS;
   // ... and two per CU up to twice that (KMX_CONV_LOADERS_PACKED_MAX_WGS; 0 = off). Measured on the MI355X, b18c384nbt device-resident:
   // batch 43 2.72 -> 2.43 ms per pass, 48 2.77 -> 2.51, 64 2.86 -> 2.69, 85 3.06 -> 3.05; beyond two per CU it loses (96: 3.89 -> 4.10 ms),
@@ -145,6 +153,11 @@ int chooseConvCfg(int ks, int coutPad, int batch) {
     const char* e = getenv("KMX_CONV_DEEP1X1_MAX_WGS");
     return e ? atoi(e) : 256;
   }();
+  static const bool split1x1 = [] {  // KMX_CONV_SPLIT1X1 = 0 | 1
+    const char* e = getenv("KMX_CONV_SPLIT1X1");
+    return e ? e[0] == '1' : true;
+  }();
+  if(ks == 1 && deep1x1() != 0 && split1x1 && batch * tiles * 3 <= deep32MaxWgs) return CFG_DEEP1X1_SPLIT;
   if(ks == 1 && deep1x1() != 0 && batch * tiles <= deep32MaxWgs) return deep1x1() == 5 ? CFG_DEEP1X1_5 : CFG_DEEP1X1_4;
   if(ks == 1 && deep1x1() != 0 && tiles % 2 == 0 && batch * (tiles / 2) <= 256) return CFG_DEEP1X1_64;
   // 3x3/5x5 narrow shapes keep two work-groups per CU (LDS), 1x1 shapes one

@@ -122,10 +122,11 @@ def test_transformer_schedule_is_consistent(name, C, H, KVH, QD, VD, F, blocks, 
             assert grid[:2] == (cout_pad // 32, n) and block == 512 and lds <= 160 * 1024
             assert grid[2] == (3 if n * (cout_pad // 32) * 3 <= 256 else 1), (grid, n, cout_pad)
         elif k == "conv":
-            m = re.search(r"ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi0EEE", kname)  # kernel size, WN, WNW, ring depth, ablations
+            # kernel size, WN, WNW, ring depth, flags (0, or 262144 = ABL_SPLIT: a board's cell tiles over three work-groups, cfg 113)
+            m = re.search(r"ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(0|262144)EEE", kname)
             ks, wn, wnw = int(m.group(1)), int(m.group(2)), int(m.group(3))
             cout_pad = int(args[4], 16) & 0xFFFFFFFF
-            assert grid == (cout_pad // (32 * wn * wnw), n, 1) and block == 256 * wnw and lds <= 160 * 1024
+            assert grid == (cout_pad // (32 * wn * wnw), n, 3 if m.group(5) != "0" else 1) and block == 256 * wnw and lds <= 160 * 1024
 
 
 def test_reference_transformer_nets_build_a_schedule(fake_so, tmp_path):
