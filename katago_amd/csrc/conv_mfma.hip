@@ -27,11 +27,12 @@ using namespace convk;
 // four multiplying waves of three cell tiles each and four waves that issue every LDS-DMA request: 22.0 -> 17.3 us per 3x3 launch at
 // batch 1 against round 3's shape of twelve cell waves (cfg 111, removed), a pass 2.30 -> 2.00 ms at batch 1, 2.51 -> 2.34 at batch 8
 // (profiles/r04_steps/small_batch). KMX_CONV_LOADERS=0 / 1 overrides the default (0: the 4-wave shapes of conv_kernel.h).
-// 1x1 at small batch, cfg 114 / 115 (round 4): the 4-wave x 32-channel shape of conv_kernel.h with a ring of FOUR (five: 115) steps instead of two. A 1x1
+// 1x1 at small batch, cfg 114 (round 4): the 4-wave x 32-channel shape of conv_kernel.h with a ring of FOUR steps instead of two. A 1x1
 // step is a whole 32-channel image chunk (23 KB) and two MFMAs per wave; with one step of cover every step waited out a memory round
 // trip - 14.4 us of kernel time for the 12 steps of a 384 -> 192 layer at batch 8 (profiles/r04_steps/call1/trace_pass8_kernel_stats.csv),
-// 37 such launches per pass. One work-group per CU either way (LDS 81 -> 132 / 157 KB). KMX_CONV_DEEP1X1 = 0 | 4 | 5 (0: the two-step ring).
-constexpr int CFG_DEEP1X1_4 = 114, CFG_DEEP1X1_5 = 115;
+// 37 such launches per pass. One work-group per CU either way (LDS 81 -> 132 KB). KMX_CONV_DEEP1X1 = 0 | 1 (0: the two-step ring). A ring of
+// five (157 KB) measured the same as four and is gone (profiles/r04_steps/small_batch/deep1x1_scan.txt).
+constexpr int CFG_DEEP1X1_4 = 114;
 // cfg 114 with a board's cell tiles over three work-groups (conv_kernel.h ABL_SPLIT) while batch x tiles x 3 <= 256: 1x1 launch 14.3 ->
 // 11.5 us at batch 1, a pass 1.53 -> 1.44 ms (1.72 -> 1.67 at batch 8); profiles/r04_steps/small_batch/split1x1_scan.txt
 constexpr int CFG_DEEP1X1_SPLIT = 113;
@@ -39,8 +40,7 @@ constexpr int CFG_DEEP1X1_64 = 124;  // the 4-wave x 64-channel shape with a rin
 int deep1x1() {
   static const int d = [] {
     const char* e = getenv("KMX_CONV_DEEP1X1");
-    const int v = e ? atoi(e) : 4;
-    return v == 4 || v == 5 ? v : 0;
+    return e ? (e[0] != '0' ? 4 : 0) : 4;
   }();
   return d;
 }
@@ -76,7 +76,6 @@ hipError_t launchT(int ks, int cfg, const ConvArgs& a, hipStream_t stream) {
   if(ks == 3 && cfg == CFG_LOADERS_SPLIT) return smallk::launchSmall<TR, false, 1, 1>(a, stream);
   if(ks == 3 && cfg == CFG_LOADERS_PACKED) return smallk::launchSmall<TR, true, 0, 3>(a, stream);
   if(ks == 1 && cfg == CFG_DEEP1X1_4) return launchOne<TR, 1, 1, 1, 4, 0>(a, stream);
-  if(ks == 1 && cfg == CFG_DEEP1X1_5) return launchOne<TR, 1, 1, 1, 5, 0>(a, stream);
   if(ks == 1 && cfg == CFG_DEEP1X1_64) return launchOne<TR, 1, 2, 1, 4, 0>(a, stream);
   if(ks == 1 && cfg == CFG_DEEP1X1_SPLIT) return launchOne<TR, 1, 1, 1, 4, ABL_SPLIT>(a, stream);
 #define KMX_CFG(KS_, WNW_, WN_, D_) \
@@ -98,7 +97,7 @@ hipError_t launchConv(int dtype, int ks, int cfg, const ConvArgs& a, hipStream_t
 
 bool convCfgInstantiated(int ks, int cfg) {
   if(ks == 3 && (cfg == CFG_LOADERS || cfg == CFG_LOADERS_SPLIT || cfg == CFG_LOADERS_PACKED)) return true;
-  if(ks == 1 && (cfg == CFG_DEEP1X1_4 || cfg == CFG_DEEP1X1_5 || cfg == CFG_DEEP1X1_64 || cfg == CFG_DEEP1X1_SPLIT)) return true;
+  if(ks == 1 && (cfg == CFG_DEEP1X1_4 || cfg == CFG_DEEP1X1_64 || cfg == CFG_DEEP1X1_SPLIT)) return true;
 #define KMX_CFG(KS_, WNW_, WN_, D_) \
   if(ks == KS_ && cfg == 10 * WNW_ + WN_) return true;
   KMX_CFG_LIST(KMX_CFG)
@@ -158,7 +157,7 @@ int chooseConvCfg(int ks, int coutPad, int batch) {
     return e ? e[0] == '1' : true;
   }();
   if(ks == 1 && deep1x1() != 0 && split1x1 && batch * tiles * 3 <= deep32MaxWgs) return CFG_DEEP1X1_SPLIT;
-  if(ks == 1 && deep1x1() != 0 && batch * tiles <= deep32MaxWgs) return deep1x1() == 5 ? CFG_DEEP1X1_5 : CFG_DEEP1X1_4;
+  if(ks == 1 && deep1x1() != 0 && batch * tiles <= deep32MaxWgs) return CFG_DEEP1X1_4;
   if(ks == 1 && deep1x1() != 0 && tiles % 2 == 0 && batch * (tiles / 2) <= 256) return CFG_DEEP1X1_64;
   // 3x3/5x5 narrow shapes keep two work-groups per CU (LDS), 1x1 shapes one
   const int round = ks == 1 ? 200 : 420;

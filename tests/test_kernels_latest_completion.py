@@ -113,7 +113,7 @@ def test_small_batch_shape_with_fetching_waves(emu_full_lib):
 
 
 def test_deep_ring_1x1_shapes(emu_full_lib):
-    """cfg 113 / 114 / 115 / 124 (conv_mfma.hip, round 4): the 1x1 shapes of conv_kernel.h with a ring of four or five steps instead of two
+    """cfg 113 / 114 / 124 (conv_mfma.hip, round 4): the 1x1 shapes of conv_kernel.h with a ring of four steps instead of two
     (and, 113, a board's cell tiles over three work-groups: conv_kernel.h ABL_SPLIT) -
     a 1x1 step is a whole image chunk, and at small batch every step of the two-step ring waited out a memory round trip. Layers with
     fewer steps than the ring is deep (96 channels: 3), with many (384: 12), several boards, a rectangular board; with immediate copies
@@ -122,7 +122,7 @@ def test_deep_ring_1x1_shapes(emu_full_lib):
     one = {"KMX_CONV_SPLIT1X1": "0"}  # a board's cell tiles in ONE work-group
     envs = [dict(one, KMX_CONV_DEEP1X1="0"),
             dict(one, KMX_CONV_DEEP1X1="4"), dict(one, KMX_CONV_DEEP1X1="4", KMX_EMU_LATE_DMA="2"),
-            dict(one, KMX_CONV_DEEP1X1="5", KMX_EMU_LATE_DMA="1"), dict(one, KMX_CONV_DEEP1X1="5", KMX_EMU_LATE_DMA="2"),
+            dict(one, KMX_CONV_DEEP1X1="4", KMX_EMU_LATE_DMA="1"),
             dict(one, KMX_CONV_DEEP1X1="4", KMX_CONV_DEEP1X1_MAX_WGS="0", KMX_EMU_LATE_DMA="2"),  # the 64-channel deep shape where tiles are even
             {"KMX_CONV_DEEP1X1": "4"}, {"KMX_CONV_DEEP1X1": "4", "KMX_EMU_LATE_DMA": "2"}]  # cfg 113: the cell tiles over three work-groups
     res = []
