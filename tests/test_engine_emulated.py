@@ -119,9 +119,9 @@ SMALL_REWRITES = [
 ]
 
 
-def build_emu_full(d, conv_mutations=(), pw2_mutations=(), chain_mutations=(), small_mutations=()):
+def build_emu_full(d, conv_mutations=(), pw2_mutations=(), chain_mutations=(), small_mutations=(), extra_flags=(), so_name="libkatamx_emufull.so"):
     """conv_mutations: further (pattern, replacement, count) rewrites of conv_kernel.h - deliberate defects for the tests of the
-    emulator's own teeth."""
+    emulator's own teeth. extra_flags: compile AND link flags (tools/emulated_asan.sh: -fsanitize=address ...)."""
     import re
     import shutil
 
@@ -154,7 +154,7 @@ def build_emu_full(d, conv_mutations=(), pw2_mutations=(), chain_mutations=(), s
     open(os.path.join(d, "pointwise2_kernel.h"), "w").write(src)
     shutil.copy(os.path.join(CSRC, "pointwise.hip"), os.path.join(d, "pointwise.hip"))
     cxx = ["/opt/rocm/lib/llvm/bin/clang++", "-x", "c++", "-std=c++20", "-O2", "-fPIC", "-pthread", "-I" + os.path.join(FAKE, "emul"), "-I" + FAKE,
-           "-I" + CSRC, "-DKMX_EMU_REAL_CONV"]
+           "-I" + CSRC, "-DKMX_EMU_REAL_CONV"] + list(extra_flags)
     procs, objs = [], []
     for src_file in [os.path.join(d, "conv_mfma.hip"), os.path.join(d, "conv_chain.hip"), os.path.join(d, "pointwise.hip")] + SOURCES:
         obj = os.path.join(d, os.path.splitext(os.path.basename(src_file))[0] + ".o")
@@ -163,8 +163,9 @@ def build_emu_full(d, conv_mutations=(), pw2_mutations=(), chain_mutations=(), s
     for src_file, p in procs:
         out, _ = p.communicate()
         assert p.returncode == 0, "%s:\n%s" % (src_file, out[-3000:])
-    so = os.path.join(d, "libkatamx_emufull.so")
-    r = subprocess.run(["/opt/rocm/lib/llvm/bin/clang++", "-shared", "-fPIC", "-pthread", "-o", so] + objs + ["-lz"], capture_output=True, text=True)
+    so = os.path.join(d, so_name)
+    r = subprocess.run(["/opt/rocm/lib/llvm/bin/clang++", "-shared", "-fPIC", "-pthread"] + list(extra_flags) + ["-o", so] + objs + ["-lz"],
+                       capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     return so
 
