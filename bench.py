@@ -215,6 +215,17 @@ def caller_rates(model_path, tmp):
             out["reference_benchmark_nn_evals_per_s"] = float(m[-1][1])
             out["reference_benchmark"] = ("katago benchmark -v 8000 -t 1024 -boardsize 19 (4 positions), unmodified reference search on fibers "
                                           "(16 per OS thread), this repo's NNEvaluator + leaf batcher: %s visits/s, avg device batch %s rows" % (m[-1][0], m[-1][2]))
+        # The same command at BASELINE configs[1]'s OWN setting (`benchmark -v 1600 -t 256 -fixed-batch-size 256`,
+        # cpp/command/benchmark.cpp:206-217; its default 10 positions): 256 descents in one tree and searches of 1600 visits - a search
+        # this short spends much of its time filling and draining its descents, so this is the lower of the two caller rates and is
+        # reported beside the long-search one, not instead of it.
+        r = subprocess.run([hipx, "benchmark", "-model", model_path, "-config", cfg, "-v", "1600", "-t", "256", "-fixed-batch-size", "256",
+                            "-boardsize", "19"], capture_output=True, text=True, timeout=120, env=env, cwd=tmp)
+        m = re.findall(r"visits/s = ([\d.]+) nnEvals/s = ([\d.]+).*avgBatchSize = ([\d.]+)", (r.stdout + r.stderr).replace("\r", "\n"))
+        if r.returncode == 0 and m:
+            out["reference_benchmark_configs1_nn_evals_per_s"] = float(m[-1][1])
+            out["reference_benchmark_configs1"] = ("katago benchmark -v 1600 -t 256 -fixed-batch-size 256 -boardsize 19 (10 positions; BASELINE configs[1] as "
+                                                   "written), same stack: %s visits/s, avg device batch %s rows" % (m[-1][0], m[-1][2]))
     if os.path.exists(hipx):
         # BASELINE configs[2], the second half of the metric: games/hour as the reference defines it (command/selfplay.cpp:388-389) -
         # `selfplay` with 8 parallel games on this GPU, the reference's production settings (tools/selfplay_cfg.py =

@@ -27,10 +27,11 @@ def parse(text):
 def compare(a, b):
     """Statistics of search list `a` against `b` (same positions, same seeds): fraction with the same best move, the
     largest / mean absolute difference of the best move's visit share, the largest root-utility difference (in c, i.e.
-    hundredths), the mean total-variation distance of the child visit distributions."""
+    hundredths), the mean total-variation distance of the child visit distributions; `flips` lists every search whose best move
+    differs, with both candidates' visit counts in both searches (is it a near-tie, or a different opinion?)."""
     n = min(len(a), len(b))
-    same, share, util, tv = 0, [], [], []
-    for x, y in zip(a[:n], b[:n]):
+    same, share, util, tv, flips = 0, [], [], [], []
+    for idx, (x, y) in enumerate(zip(a[:n], b[:n])):
         if x["root_N"] != y["root_N"] or x["root_N"] <= 1:
             continue
         bx, by = x["children"][0], y["children"][0]
@@ -38,10 +39,17 @@ def compare(a, b):
         vy = {c[0]: c[3] for c in y["children"]}
         vx = {c[0]: c[3] for c in x["children"]}
         tot = max(sum(vx.values()), 1), max(sum(vy.values()), 1)
+        if bx[0] != by[0]:
+            # a flipped best move: how far apart the two candidates are in EACH search, as a share of that search's child visits.
+            # gap_b = b's margin of its own best move over a's best move (inside b); gap_a = a's margin the other way (inside a)
+            flips.append(dict(index=idx, root_N=x["root_N"], a_best=bx[0], b_best=by[0],
+                              a_visits=(vx.get(bx[0], 0), vx.get(by[0], 0)), b_visits=(vy.get(bx[0], 0), vy.get(by[0], 0)),
+                              a_top=[(c[0], c[3]) for c in x["children"][:3]], b_top=[(c[0], c[3]) for c in y["children"][:3]],
+                              gap_a=(vx.get(bx[0], 0) - vx.get(by[0], 0)) / tot[0], gap_b=(vy.get(by[0], 0) - vy.get(bx[0], 0)) / tot[1]))
         share.append(abs(vx.get(by[0], 0) / tot[0] - by[3] / tot[1]))
         util.append(abs(x["root_T"] - y["root_T"]))
         keys = set(vx) | set(vy)
         tv.append(0.5 * sum(abs(vx.get(k, 0) / tot[0] - vy.get(k, 0) / tot[1]) for k in keys))
     m = len(share)
     return dict(searches=m, same_best=same / max(m, 1), best_share_max=max(share), best_share_mean=sum(share) / m,
-                root_util_max=max(util), root_util_mean=sum(util) / m, tv_mean=sum(tv) / m, tv_max=max(tv))
+                root_util_max=max(util), root_util_mean=sum(util) / m, tv_mean=sum(tv) / m, tv_max=max(tv), flips=flips)

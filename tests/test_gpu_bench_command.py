@@ -62,6 +62,8 @@ def test_driver_command_exits_zero_with_roofline_and_cpu_baseline():
     assert d["host_rows_through_batcher_per_s"] > 0.5 * d["value"]
     if os.path.exists(os.path.join(REPO, "oracle", "_ref", "katago_hip")):
         assert d["reference_benchmark_nn_evals_per_s"] > 0.5 * d["value"], d
+        # ... and at BASELINE configs[1]'s own setting (-v 1600 -t 256 -fixed-batch-size 256): short searches, 256 descents - lower, reported beside it
+        assert d["reference_benchmark_configs1_nn_evals_per_s"] > 0.3 * d["value"] and "-v 1600 -t 256 -fixed-batch-size 256" in d["reference_benchmark_configs1"], d
         # cut short after 40 s here: NN rows/s at the production settings, and NO games/hour figure (measured or absent, never derived)
         assert d["selfplay_nn_rows_per_s"] > 3000 and "interrupted" in d["selfplay"] and "selfplay_games_per_hour" not in d, d
         # the small-batch leg is monotonic in the batch size (round 3's driver run was not: a mean of 20 passes after 3 warm-ups)

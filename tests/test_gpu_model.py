@@ -310,10 +310,16 @@ def test_packed_input_rows_bit_exact(ctx19, model_dir):
     h.close()
 
 
+@pytest.mark.parametrize("precision,rel,floor", [
+    # 52 (b28) / 80 (b40) convolutions deep. fp16 with the 1/8 range transform (the backend default since round 3): 2 % of the value plus
+    # 0.08; bf16 - the precision configs[3] NAMES - has 8 mantissa bits instead of 11: 5 % + 0.4 (the limits round 2 measured it under)
+    ("fp16", 0.02, 0.08),
+    ("bf16", 0.05, 0.4),
+])
 @pytest.mark.parametrize("arch", ["b28c512nbt", "b40c256"])
-def test_large_nets_of_the_analysis_config(ctx19, model_dir, arch):
-    """BASELINE configs[3]: b28c512nbt / b40c256 (random weights), bf16, batch 512 (cpp/configs/analysis_example.cfg:95-132).
-    (a) 8 rows - full and small boards, symmetries - against the oracle at the 16-bit tolerance of the deep nets;
+def test_large_nets_of_the_analysis_config(ctx19, model_dir, arch, precision, rel, floor):
+    """BASELINE configs[3]: b28c512nbt / b40c256 (random weights), bf16 AND the default fp16, batch 512 (cpp/configs/analysis_example.cfg:95-132).
+    (a) 8 rows - full and small boards, symmetries - against the oracle at the 16-bit tolerance of the deep nets, written per precision;
     (b) a 512-row batch on a handle created for 512 rows (split over two engines, the 8-wave x 128/192-channel convolution
         shapes at full batch) reproduces, bit for bit, the same rows evaluated 16 at a time; counters add up."""
     p = os.path.join(model_dir, "big_%s.bin.gz" % arch)
@@ -326,16 +332,16 @@ def test_large_nets_of_the_analysis_config(ctx19, model_dir, arch):
     sym = rng.integers(0, 8, n).astype(np.int32)
     opt = rng.random(n).astype(np.float32)
     model = nn.loadModelFile(p)
-    h = nn.createComputeHandle(ctx19["fp16"], model, 512)  # fp16 with the 1/8 range transform: the backend default since round 3
+    h = nn.createComputeHandle(ctx19[precision], model, 512)
+    assert h.precision == precision
     big = nn.getOutput(h, sp, gl, sym, opt)
     want = oracle_outputs(("big", arch), p, sp[:8], gl[:8], sym[:8], opt[:8])
     small = {k: v[:8] for k, v in big.items()}
-    # 52 (b28) / 80 (b40) convolutions deep: 2 % of the value plus 0.08 (round 2, bf16: 5 % + 0.4)
-    assert outputs_close(small, want, sp[:8, :, 0] > 0, 0.02, 0.08)
+    assert outputs_close(small, want, sp[:8, :, 0] > 0, rel, floor)
     for i in (0, 16, 240, 496):
         part = nn.getOutput(h, sp[i:i + 16], gl[i:i + 16], sym[i:i + 16], opt[i:i + 16])
         for k in part:
-            assert np.array_equal(part[k], big[k][i:i + 16]), (arch, i, k)
+            assert np.array_equal(part[k], big[k][i:i + 16]), (arch, precision, i, k)
     assert h.stats() == (512 + 64, 5)
     assert all(np.isfinite(v).all() for v in big.values())
     h.close()

@@ -31,12 +31,17 @@ def _gold(name):
         return sg.parse(f.read())
 
 
+# a flipped best move counts as a near-tie when each search's margin between the two candidates is below this share of its child visits
+# (the golden's own fp16-vs-fp32 spread of the best move's share is 2.5 %, so two moves closer than twice that are within its noise)
+NEAR_TIE = 0.06
+
+
 @pytest.mark.parametrize("precision,limits", [
     # same best move | visit share of the best move: max, mean | child visit distribution TV: mean | root utility (c): max, mean
     # measured on MI355X (profiles/r02/search_fixed_seed_*.txt): fp16 0.978 | 0.028, 0.0024 | 0.0045 | 1.8, 0.076 - the spread of the
     # reference's own fp16 golden; bf16 0.976 | 0.89 (one search flips), 0.015 | 0.020 | 9.3, 0.52
-    ("auto", dict(searches=130, same_best=0.97, best_share_max=0.08, best_share_mean=0.01, tv_mean=0.015, root_util_max=4.0, root_util_mean=0.3)),
-    ("fp16", dict(searches=130, same_best=0.97, best_share_max=0.08, best_share_mean=0.01, tv_mean=0.015, root_util_max=4.0, root_util_mean=0.3)),
+    ("auto", dict(searches=130, near_tie=NEAR_TIE, same_best=0.97, best_share_max=0.08, best_share_mean=0.01, tv_mean=0.015, root_util_max=4.0, root_util_mean=0.3)),
+    ("fp16", dict(searches=130, near_tie=NEAR_TIE, same_best=0.97, best_share_max=0.08, best_share_mean=0.01, tv_mean=0.015, root_util_max=4.0, root_util_mean=0.3)),
     ("bf16", dict(searches=115, same_best=0.95, best_share_max=1.0, best_share_mean=0.04, tv_mean=0.06, root_util_max=15.0, root_util_mean=1.5)),
 ])
 def test_fixed_seed_search_visit_counts_match_the_reference_golden(tmp_path, precision, limits):
@@ -50,12 +55,25 @@ def test_fixed_seed_search_visit_counts_match_the_reference_golden(tmp_path, pre
     want = _gold("ref_runSearchTestsV8Bin.txt.gz")
     assert len(got) == len(want) == 165, (len(got), len(want))
     st = sg.compare(got, want)
+    flips = st.pop("flips")
     print("runsearchtestsv8 on HIP (%s) vs the CUDA fp32 golden: %s" % (precision, {k: round(v, 4) for k, v in st.items()}))
+    for fl in flips:
+        print("  flipped best move, search %(index)d (%(root_N)d visits): here %(a_top)s, golden %(b_top)s; the golden's margin over our move "
+              "%(gap_b).4f of its child visits, ours over the golden's %(gap_a).4f" % fl)
     keep = os.path.join(REPO, "gpurun_out")
     if os.path.isdir(keep):
         with open(os.path.join(keep, "search_fixed_seed_%s.txt" % precision), "w") as f:
             f.write(repr(st) + "\n")
+            for fl in flips:
+                f.write("flip " + repr(fl) + "\n")
     assert st["searches"] >= limits["searches"]  # searches whose root visit count equals the golden's (the rest reuse a tree or the NN cache differently)
     assert st["same_best"] >= limits["same_best"], st
+    # Round 5: the reference's own fp16 golden keeps the best move of its fp32 golden in every search
+    # (tests/test_search_golden.py). Here a handful flip, and each flip must be a NEAR-TIE in the golden itself: the golden's best move
+    # leads the move this backend prefers by less than `near_tie` of the child visits (and this backend's margin the other way is as
+    # small). A flip between two moves that the golden separates clearly is a different opinion of the net - a parity failure.
+    if "near_tie" in limits:
+        far = [fl for fl in flips if fl["gap_b"] > limits["near_tie"] or fl["gap_a"] > limits["near_tie"]]
+        assert not far, far
     for k in ("best_share_max", "best_share_mean", "tv_mean", "root_util_max", "root_util_mean"):
         assert st[k] <= limits[k], (k, st)
