@@ -145,7 +145,7 @@ def traffic_totals(csv_of):
     # A "launch" of the bench line's conv3x3 class is one CONVOLUTION: a chained dispatch (conv_chain_kernel.h) holds two or four, so
     # the class's bytes are summed over both kernels' dispatches and divided by the convolutions the passes held (finish_traffic).
     out = {}
-    for name, keys in (("conv3x3", ("KS=3", "convChainKernel")), ("conv1x1_pair", ("pointwisePair",))):
+    for name, keys in (("conv3x3", ("KS=3", "convChainKernel", "convSmallKernel")), ("conv1x1_pair", ("pointwisePair",))):
         f, nf, pf = totals("FETCH_SIZE", keys)
         w, nw, pw = totals("WRITE_SIZE", keys)
         if nf and nw and pf and pw:
@@ -163,7 +163,7 @@ def finish_traffic(t, launches_per_pass):
     return {"hbm_bytes_per_launch": round((2.0 * f + w) * 1024.0), "fetch_kib_raw": round(f, 1), "write_kib_raw": round(w, 1),
             "dispatches": t["dispatches"], "launches_per_pass": launches_per_pass,
             "source": "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 3 --warmup 2`, one stream, summed "
-                      "over the class's dispatches (3x3: convMfmaKernel KS=3 + convChainKernel) and divided by its launches in those passes (a "
+                      "over the class's dispatches (3x3: convMfmaKernel KS=3 + convChainKernel + convSmallKernel) and divided by its launches in those passes (a "
                       "chained dispatch counts as the convolutions it holds); FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE x1"}
 
 

@@ -37,8 +37,14 @@ extern "C" {
  *    accepts a negative value (restore the creation value); the handle stream orders both halves of a split batch.
  *    + kmx_test_pointwise_pair (unit hook of the fused 1x1 -> 1x1 seam kernel); + kmx_batcher_* (persistent leaf
  *    batcher). Additive over 3.
- * 5: + kmx_batcher_submit_packed (a row that was featurised as bit planes is handed over as such). Additive over 4. */
-#define KMX_ABI_VERSION 6
+ * 5: + kmx_batcher_submit_packed (a row that was featurised as bit planes is handed over as such). Additive over 4.
+ * 6: + kmx_test_conv_chain (unit hook of the chained 3x3 convolutions); kmx_batcher_create: a batch is sealed at ONE granule of the
+ *    device (its CU count, 256 on MI355X) whatever max_batch_size asks for beyond it - a batcher created for 1024 rows runs batches of
+ *    at most 256, and its engines and staging are sized for that (see kmx_batcher_create). Additive over 5.
+ * 7: the kernel-tuning entry points (kmx_bench_*, kmx_debug_conv_cfg) left this header: they are instrumentation of this repository's
+ *    tools, declared in katago_amd/csrc/katamx_tuning.h and still exported; + kmx_batcher_effective_batch (the seal size a batcher
+ *    actually got); precision_mode KMX_PREC_FP32 is served (a plain fp32 device path, correctness only). Additive over 6. */
+#define KMX_ABI_VERSION 7
 
 typedef enum kmx_status {
   KMX_OK = 0,
@@ -234,6 +240,9 @@ int kmx_batcher_submit_packed(kmx_batcher* batcher, const uint8_t* row_packed, c
                               float* out_ownership, uint64_t* ticket);
 int kmx_batcher_wait(kmx_batcher* batcher, uint64_t ticket);
 int kmx_batcher_stats(kmx_batcher* batcher, uint64_t* rows, uint64_t* batches);
+/* The largest batch this batcher ever launches: min(max_batch_size, the device's granule) unless KMX_BATCH_GROW_AHEAD / KMX_BATCH_QUANTUM
+ * say otherwise - what an embedder that asked for 1024 rows actually got (ABI 7). 0 for a null batcher. */
+int kmx_batcher_effective_batch(const kmx_batcher* batcher);
 int kmx_batcher_precision(const kmx_batcher* batcher); /* KMX_PREC_FP16 or KMX_PREC_BF16: what its engines compute in (isUsingFP16, nninterface.h:108) */
 
 /* NNEvaluator counters (nneval.cpp:330-347, incremented :712-713): rows = evaluated
@@ -269,33 +278,6 @@ int kmx_handle_set_profiling(kmx_handle* handle, int enabled); /* resets the acc
 int kmx_handle_set_graphs(kmx_handle* handle, int enabled);
 int kmx_handle_graph_stats(const kmx_handle* handle, uint64_t* graph_launches);
 int kmx_handle_get_profile(kmx_handle* handle, kmx_profile_entry* entries, int max_entries, int* n_entries);
-/* Average duration (ms, hipEvents) of one launch of the bf16 convolution kernel on synthetic data: kernel size ks,
- * wn = 32-channel tiles per wave, variant = 0 (product kernel) or depth*1000 + ablation mask (conv_kernel.h),
- * epilogue_mode 0 = BN+act output, 1 = residual + raw + BN+act outputs. Kernel tuning instrumentation. */
-int kmx_bench_conv(int ks, int wn, int variant, int cin, int cout, int batch, int nn_x_len, int nn_y_len,
-                   int epilogue_mode, int iters, double* avg_ms);
-/* The same layer on n_streams streams at once (each its own `batch` boards, `launches` back-to-back launches), stream i
- * started i * delay_us microseconds after stream 0: what a stagger of a FRACTION of a launch between co-resident
- * work-groups buys. total_ms = wall time from the common start to the last stream's end. Kernel tuning instrumentation. */
-int kmx_bench_conv_streams(int ks, int cfg, int cin, int cout, int batch, int n_streams, double delay_us, int launches,
-                           int epilogue_mode, double* total_ms);
-/* Average duration (ms) of one launch of the fused seam kernel (192 -> 384 -> 192, mish, bf16) on `batch` 19x19 boards of
- * synthetic data; timing != 0 runs the instrumented instantiation of the persistent kernel and prints per-wave cycle sums of
- * its phases on stderr. KMX_PW_V2=0 selects the one-tile-per-work-group kernel. Kernel tuning instrumentation. */
-int kmx_bench_seam(int batch, int iters, int timing, double* avg_ms);
-/* n_conv (2 | 4) convolutions 3x3 192 -> 192 on `batch` 19x19 boards, per sequence: chained = 0 one launch each, 2 | 4 chained launches
- * (conv_chain_kernel.h); timing != 0: the chained launches print cycle stamps per phase to stderr. KMX_BENCH_DTYPE=fp16 | bf16 (default). */
-int kmx_bench_conv_chain(int batch, int n_conv, int chained, int iters, int timing, double* avg_ms);
-/* Host-only introspection of the convolution launcher (no device needed): the work-group shape chosen for a kernel size,
- * a padded channel count (multiple of 64) and a batch, and whether a kernel of that shape exists and tiles the channels.
- * tests/test_conv_chooser.py walks every combination the engine can ask for. */
-int kmx_debug_conv_cfg(int ks, int cout_pad, int batch, int* cfg, int* instantiated);
-
-/* MFMA issue-rate microbenchmark (v_mfma_f32_32x32x16_bf16, 18 per step as in the convolution): mode bit 1 adds an
- * s_barrier per step, bit 2 adds the step's 12 ds_read_b128. Reports the rate and the shader clock it ran at: the
- * practical ceiling the convolution is measured against. Kernel tuning instrumentation. */
-int kmx_bench_mfma(int waves_per_wg, int wgs, int mode, int steps, int iters, double* avg_ms, double* tflops, double* core_mhz);
-
 /* ---- layer test hooks -------------------------------------------------------------- */
 /* NeuralNet::testEvaluateConv / BatchNorm / ResidualBlock / GlobalPoolingResidualBlock
  * (nninterface.h:134-180). Raw fp32 NHWC buffers in host memory; weights in the

@@ -124,6 +124,8 @@ struct EvalState {
   // ports exist between spawnServerThreads and killServerThreads
   std::vector<std::unique_ptr<PortSlot>> ports;
   std::atomic<uint32_t> nextPort{0};
+  bool fillFirst = false;  // KATAMX_PORT_POLICY=fill (pickPort)
+  int fillTarget = 256;    // rows in flight at which a port is passed over under that policy
   // rows of the no-neural-net mode are produced under this lock, in arrival order, from one generator
   std::mutex nnlessMutex;
   std::unique_ptr<Rand> nnlessRand;
@@ -460,10 +462,24 @@ bool featurise(EvalState& st, const Board& board, const BoardHistory& history, P
 // the lighter device idles while the heavier one queues a second batch.) Ties go round: the scan starts one port further each time,
 // which with equal loads is exactly the round-robin order. Spreading, not filling one device first: a pass over L/N rows is
 // shorter than a pass over L, so N devices with L/N rows each finish L rows sooner than L/256 devices with full batches.
+// KATAMX_PORT_POLICY = spread (default) | fill (round 5): least-loaded-first hands every device an equal share of
+// the leaves in flight - at 8 GPUs x 8 games each device then sees batches well below its granule, where a pass costs the same for 20
+// rows as for 60. `fill` is the alternative to A/B on a node: ports are taken in their fixed order and a port is passed over only once
+// it holds `fillTarget` rows (one device granule, KATAMX_PORT_FILL_ROWS overrides); when every port is at its target the least loaded
+// takes the row. With one port both policies are the same code path. tests/test_schedule_dryrun.py runs both on eight fake devices.
 PortSlot& pickPort(EvalState& st) {
   const size_t n = st.ports.size();
+  size_t best = 0;
+  if(n > 1 && st.fillFirst) {
+    size_t k = 0;
+    while(k < n && st.ports[k]->rowsInFlight.load(std::memory_order_relaxed) >= st.fillTarget) k++;
+    if(k < n) {
+      st.ports[k]->rowsInFlight.fetch_add(1, std::memory_order_relaxed);
+      return *st.ports[k];
+    }
+  }
   const size_t start = st.nextPort.fetch_add(1, std::memory_order_relaxed) % n;
-  size_t best = start;
+  best = start;
   if(n > 1) {
     int bestLoad = st.ports[start]->rowsInFlight.load(std::memory_order_relaxed);
     for(size_t k = 1; k < n && bestLoad > 0; k++) {
@@ -777,6 +793,20 @@ void NNEvaluator::spawnServerThreads() {
     st->ports.push_back(std::move(slot));
   }
   numServerThreadsEverSpawned += numThreads;
+  {
+    const char* pol = getenv("KATAMX_PORT_POLICY");
+    if(pol != NULL && string(pol) != "spread" && string(pol) != "fill" && string(pol) != "")
+      throw StringError("KATAMX_PORT_POLICY must be spread or fill, not " + string(pol));
+    st->fillFirst = pol != NULL && string(pol) == "fill";
+    st->fillTarget = std::max(1, std::min(maxBatchSize, 256));
+    if(const char* e = getenv("KATAMX_PORT_FILL_ROWS"))
+      st->fillTarget = std::max(1, atoi(e));
+    if(logger != NULL && st->ports.size() > 1)
+      logger->write(
+        "katamx leaf ports: " + Global::intToString((int)st->ports.size()) + " devices, rows go to " +
+        (st->fillFirst ? "the first port below " + Global::intToString(st->fillTarget) + " rows in flight (KATAMX_PORT_POLICY=fill)"
+                       : string("the port with the fewest rows in flight (KATAMX_PORT_POLICY=spread)")));
+  }
   for(int i = 0; i < numThreads; i++)
     for(const auto& slot : st->ports)
       if(slot->gpuIdx == gpuIdxByServerThread[i]) serverThreadsIsUsingFP16[i] = slot->usingFP16 ? 1 : 0;

@@ -114,6 +114,7 @@ SIGNATURES = {
     "kmx_batcher_wait": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64]),
     "kmx_batcher_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "kmx_batcher_precision": (ctypes.c_int, [ctypes.c_void_p]),
+    "kmx_batcher_effective_batch": (ctypes.c_int, [ctypes.c_void_p]),
     "kmx_handle_stream": (ctypes.c_void_p, [ctypes.c_void_p]),
     "kmx_handle_sync": (ctypes.c_int, [ctypes.c_void_p]),
     "kmx_handle_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
@@ -122,12 +123,6 @@ SIGNATURES = {
     "kmx_handle_graph_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]),
     "kmx_handle_get_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ProfileEntry), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "kmx_handle_set_split_min": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
-    "kmx_bench_conv": (ctypes.c_int, [ctypes.c_int] * 10 + [ctypes.POINTER(ctypes.c_double)]),
-    "kmx_bench_conv_streams": (ctypes.c_int, [ctypes.c_int] * 6 + [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
-    "kmx_bench_conv_chain": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_double)]),
-    "kmx_bench_seam": (ctypes.c_int, [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_double)]),
-    "kmx_debug_conv_cfg": (ctypes.c_int, [ctypes.c_int] * 3 + [_IP, _IP]),
-    "kmx_bench_mfma": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_double)] * 3),
     "kmx_test_pointwise_pair": (ctypes.c_int, [ctypes.c_int] * 7 + [_FP, _FP, _FP, _FP, _FP, ctypes.c_int, _FP, _FP, _FP, ctypes.c_int, _FP,
                                                ctypes.c_int, _FP, _FP, _FP]),
     "kmx_test_conv_chain": (ctypes.c_int, [ctypes.c_int] * 5 + [_FP, _FP, _FP, _FP, _FP, ctypes.c_int, _FP, ctypes.c_int, _FP, _FP]),
@@ -138,6 +133,16 @@ SIGNATURES = {
     "kmx_test_rmsnorm": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.c_float, _FP, _FP, ctypes.c_int, ctypes.c_int, _FP, _FP, _FP]),
     "kmx_test_attention": (ctypes.c_int, [ctypes.c_int] * 8 + [_FP, _FP, ctypes.c_int, _FP, _FP, _FP, _FP, _FP]),
     "kmx_test_swiglu": (ctypes.c_int, [ctypes.c_int] * 5 + [_FP, _FP, _FP]),
+}
+
+# kernel-tuning instrumentation (katago_amd/csrc/katamx_tuning.h): exported by the library, not part of include/katamx.h
+TUNING_SIGNATURES = {
+    "kmx_bench_conv": (ctypes.c_int, [ctypes.c_int] * 10 + [ctypes.POINTER(ctypes.c_double)]),
+    "kmx_bench_conv_streams": (ctypes.c_int, [ctypes.c_int] * 6 + [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
+    "kmx_bench_conv_chain": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_double)]),
+    "kmx_bench_seam": (ctypes.c_int, [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_double)]),
+    "kmx_debug_conv_cfg": (ctypes.c_int, [ctypes.c_int] * 3 + [_IP, _IP]),
+    "kmx_bench_mfma": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_double)] * 3),
 }
 
 _lib = None
@@ -159,7 +164,7 @@ def load_library(path=None):
     if not os.path.exists(p):
         raise KatamxError(KMX_ERR_INTERNAL, "%s not found: run `python -m katago_amd.build` (the HIP extension is mandatory)" % p)
     lib = ctypes.CDLL(p)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(TUNING_SIGNATURES.items()):
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args

@@ -38,6 +38,7 @@
 #include "../../include/katamx.h"
 #include "engine.h"
 #include "model_desc.h"
+#include "numa.h"
 
 namespace kmx {
 
@@ -106,6 +107,8 @@ class Batcher {
     if(dispatcher_.joinable()) dispatcher_.join();
     if(completer_.joinable()) completer_.join();
   }
+
+  int maxBatch() const { return maxBatch_; }  // rows per batch at most: the seal size (kmx_batcher_effective_batch)
 
   // exactly one of rowSpatial (fp32 NHWC planes, bit-packed here) and rowPacked (already in the staging layout) is given
   uint64_t submit(const float* rowSpatial, const unsigned char* rowPacked, const float* rowGlobal, const float* rowMeta, int symmetry, float optimism,
@@ -243,7 +246,13 @@ class Batcher {
     cvFree_.notify_all();
   }
 
+  // the helper threads of a device run on its NUMA node (numa.h): they touch every staged row and every result of its batches
+  void bindToDeviceNode(const char* what) {
+    const int dev = slots_[0].eng->device();
+    numa::bindThisThreadToNode(numa::nodeOfDevice(dev), what, dev);
+  }
   void dispatchLoop() {
+    bindToDeviceNode("dispatcher");
     std::unique_lock<std::mutex> l(mu_);
     for(;;) {
       // A FULL batch goes as soon as fewer than max_in_flight are on the device. A partial batch goes only when the device
@@ -324,6 +333,7 @@ class Batcher {
   }
 
   void completeLoop() {
+    bindToDeviceNode("completion");
     std::unique_lock<std::mutex> l(mu_);
     for(;;) {
       // a batch the dispatcher has counted (running_) but not yet handed over is still coming
@@ -475,6 +485,7 @@ int kmx_batcher_wait(kmx_batcher* b, uint64_t ticket) {
   });
 }
 int kmx_batcher_precision(const kmx_batcher* b) { return b ? b->precision : KMX_PREC_AUTO; }
+int kmx_batcher_effective_batch(const kmx_batcher* b) { return b ? b->b->maxBatch() : 0; }
 int kmx_batcher_stats(kmx_batcher* b, uint64_t* rows, uint64_t* batches) {
   if(!b) return apiSetError(KMX_ERR_INVALID_ARG, "kmx_batcher_stats: null batcher");
   b->b->stats(rows, batches);

@@ -88,6 +88,9 @@ struct Geom {
   static constexpr int NPW = (WPIECES + NLW * 64 - 1) / (NLW * 64);  // DMA instructions per weight-loading wave per slab
   static constexpr int W_BYTES = (WPIECES * 16 + 1023) / 1024 * 1024;
   static_assert(D >= 2, "the slab of step s+1 is published at the top of step s: at least two steps of requests in flight");
+  // image requests for chunks past the last one are still issued (into the slack): their sources run up to D chunks of 64 bytes past
+  // the last cell's row, plus the lane's own 16-byte slot
+  static_assert((D + 1) * KCHUNK * 2 <= DEVBUF_TAIL_BYTES, "the image requests' run-ahead must stay inside the readable tail of a DevBuf");
   // 3x3/5x5: the next chunk's image arrives PPS pieces per step during the first LS steps of the current chunk
   // (the fewest pieces per step for which it is complete D steps before the chunk ends); 1x1: whole images per step.
   static constexpr bool SPREAD = NT > 1;

@@ -1,5 +1,8 @@
 // conv_mfma.hip — product instantiations and dispatch of the MFMA convolution (kernel: conv_kernel.h).
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <string>
 
 #include "conv_kernel.h"
 #include "conv_small_kernel.h"
@@ -26,52 +29,78 @@ using namespace convk;
 // The small-batch 3x3 shape with dedicated fetching waves, cfg 118 (conv_small_kernel.h, round 4): a board x 32 channels like cfg 11,
 // four multiplying waves of three cell tiles each and four waves that issue every LDS-DMA request: 22.0 -> 17.3 us per 3x3 launch at
 // batch 1 against round 3's shape of twelve cell waves (cfg 111, removed), a pass 2.30 -> 2.00 ms at batch 1, 2.51 -> 2.34 at batch 8
-// (profiles/r04_steps/small_batch). KMX_CONV_LOADERS=0 / 1 overrides the default (0: the 4-wave shapes of conv_kernel.h).
+// (profiles/r04_steps/small_batch). KMX_CONV_TUNE (below) switches it off for A/B.
 // 1x1 at small batch, cfg 114 (round 4): the 4-wave x 32-channel shape of conv_kernel.h with a ring of FOUR steps instead of two. A 1x1
 // step is a whole 32-channel image chunk (23 KB) and two MFMAs per wave; with one step of cover every step waited out a memory round
 // trip - 14.4 us of kernel time for the 12 steps of a 384 -> 192 layer at batch 8 (profiles/r04_steps/call1/trace_pass8_kernel_stats.csv),
-// 37 such launches per pass. One work-group per CU either way (LDS 81 -> 132 KB). KMX_CONV_DEEP1X1 = 0 | 1 (0: the two-step ring). A ring of
+// 37 such launches per pass. One work-group per CU either way (LDS 81 -> 132 KB). (KMX_CONV_TUNE deep1x1=0: the two-step ring.) A ring of
 // five (157 KB) measured the same as four and is gone (profiles/r04_steps/small_batch/deep1x1_scan.txt).
 constexpr int CFG_DEEP1X1_4 = 114;
 // cfg 114 with a board's cell tiles over three work-groups (conv_kernel.h ABL_SPLIT) while batch x tiles x 3 <= 256: 1x1 launch 14.3 ->
 // 11.5 us at batch 1, a pass 1.53 -> 1.44 ms (1.72 -> 1.67 at batch 8); profiles/r04_steps/small_batch/split1x1_scan.txt
 constexpr int CFG_DEEP1X1_SPLIT = 113;
 constexpr int CFG_DEEP1X1_64 = 124;  // the 4-wave x 64-channel shape with a ring of four (LDS 86 -> 141 KB), for the next 256 work-groups
-int deep1x1() {
-  static const int d = [] {
-    const char* e = getenv("KMX_CONV_DEEP1X1");
-    return e ? (e[0] != '0' ? 4 : 0) : 4;
-  }();
-  return d;
-}
 constexpr int CFG_LOADERS = 118;
 // ... with a board's cell tiles over three work-groups (conv_small_kernel.h MTW = 1) while batch x channel tiles x 3 <= 256: same box,
 // 3x3 launch 16.5 -> 12.4 us at batch 1, 17.6 -> 13.5 at 8; a pass 1.90 -> 1.60 ms / 2.07 -> 1.77 (profiles/r04_steps/small_batch/split_scan.txt)
 constexpr int CFG_LOADERS_SPLIT = 117;
 constexpr int CFG_LOADERS_PACKED = 119;  // the same with two work-groups per CU (conv_small_kernel.h PACK)
-constexpr bool kLoadersDefault = true;
-bool loadersEnabled() {
-  static const bool on = [] {
-    const char* e = getenv("KMX_CONV_LOADERS");
-    return e != nullptr ? e[0] == '1' : kLoadersDefault;
+// ---- ONE debug override for every switch of the shape choice: KMX_CONV_TUNE="key=value,key=value" (read once) ----
+// Defaults are the product; the keys exist for A/B scans (tools/small_batch_scan.py) and for tests that force a shape at a size the
+// chooser would not pick it for (tests/test_kernels_latest_completion.py, tests/test_engine_emulated.py). Unknown keys abort: a typo must
+// not silently measure the default. (Until round 4 these were nine separate environment variables.)
+//   min_wgs8        150  work-groups from which the 8-wave x 192 / x 128 shapes are taken
+//   loaders         1    the small-batch 3x3 shape with fetching waves (0: the 4-wave shapes of conv_kernel.h)
+//   loaders_depth   1    its fetch depth: slabs six steps / images two chunks ahead (0: three / one); 16.94 -> 16.47 us per 3x3 launch at
+//                        batch 1, a pass 1.93 -> 1.88 ms (profiles/r04_steps/small_batch/depth_scan.txt)
+//   loaders_split   1    a board's cell tiles over three work-groups while batch x channel tiles x 3 <= loaders_max_wgs
+//   loaders_max_wgs 256  work-groups up to which the fetching-waves shape is alone on its CU
+//   packed_max_wgs  512  ... and up to which two of them share a CU (0: off)
+//   deep1x1         1    1x1 at small batch on a ring of four steps (0: two)
+//   deep1x1_max_wgs 256  work-groups up to which the 32-channel deep shape is taken (tests: 0 sends even tile counts to the 64-channel one)
+//   split1x1        1    a board's cell tiles over three work-groups for 1x1 layers too
+struct ConvTune {
+  int minWgs8 = 150, loaders = 1, loadersDepth = 1, loadersSplit = 1, loadersMaxWgs = 256, packedMaxWgs = 512, deep1x1 = 1, deep1x1MaxWgs = 256,
+      split1x1 = 1;
+};
+const ConvTune& convTune() {
+  static const ConvTune t = [] {
+    ConvTune t;
+    const char* e = getenv("KMX_CONV_TUNE");
+    if(e == nullptr) return t;
+    const struct { const char* key; int* v; } keys[] = {
+      {"min_wgs8", &t.minWgs8}, {"loaders", &t.loaders}, {"loaders_depth", &t.loadersDepth}, {"loaders_split", &t.loadersSplit},
+      {"loaders_max_wgs", &t.loadersMaxWgs}, {"packed_max_wgs", &t.packedMaxWgs}, {"deep1x1", &t.deep1x1},
+      {"deep1x1_max_wgs", &t.deep1x1MaxWgs}, {"split1x1", &t.split1x1}};
+    std::string s(e);
+    size_t i = 0;
+    while(i < s.size()) {
+      size_t j = s.find(',', i);
+      if(j == std::string::npos) j = s.size();
+      const std::string item = s.substr(i, j - i);
+      i = j + 1;
+      if(item.empty()) continue;
+      const size_t eq = item.find('=');
+      bool known = false;
+      if(eq != std::string::npos)
+        for(const auto& k : keys)
+          if(item.compare(0, eq, k.key) == 0 && strlen(k.key) == eq) {
+            *k.v = atoi(item.c_str() + eq + 1);
+            known = true;
+          }
+      if(!known) {
+        fprintf(stderr, "katamx: KMX_CONV_TUNE: unknown item '%s'\n", item.c_str());
+        abort();
+      }
+    }
+    return t;
   }();
-  return on;
-}
-// how far ahead the fetching waves of the one-per-CU shape run (conv_small_kernel.h SG): KMX_CONV_LOADERS_DEPTH = 0 | 1. Same box, 3x3
-// launch at batch 1: 16.94 -> 16.47 us, a pass 1.93 -> 1.88 ms (profiles/r04_steps/small_batch/depth_scan.txt)
-constexpr int kLoadersDepthDefault = 1;
-int loadersDepth() {
-  static const int d = [] {
-    const char* e = getenv("KMX_CONV_LOADERS_DEPTH");
-    return e != nullptr && e[0] >= '0' && e[0] <= '1' ? e[0] - '0' : kLoadersDepthDefault;
-  }();
-  return d;
+  return t;
 }
 template <class TR>
 hipError_t launchT(int ks, int cfg, const ConvArgs& a, hipStream_t stream) {
   if(ks == 3 && cfg == CFG_LOADERS) {
-    const int depth = loadersDepth();
-    return depth == 0 ? smallk::launchSmall<TR, false, 0, 3>(a, stream) : smallk::launchSmall<TR, false, 1, 3>(a, stream);
+    return convTune().loadersDepth == 0 ? smallk::launchSmall<TR, false, 0, 3>(a, stream) : smallk::launchSmall<TR, false, 1, 3>(a, stream);
   }
   if(ks == 3 && cfg == CFG_LOADERS_SPLIT) return smallk::launchSmall<TR, false, 1, 1>(a, stream);
   if(ks == 3 && cfg == CFG_LOADERS_PACKED) return smallk::launchSmall<TR, true, 0, 3>(a, stream);
@@ -114,51 +143,27 @@ bool convCfgInstantiated(int ks, int cfg) {
 // (one image fetch for 128/192 channels) win when they alone fill most of the 256 CUs.
 int chooseConvCfg(int ks, int coutPad, int batch) {
   const int tiles = coutPad / 32;
-  static const int minWgs8 = [] {  // experiments only: KMX_MIN_WGS8 moves the switch to the 8-wave x 192 shape
-    const char* e = getenv("KMX_MIN_WGS8");
-    return e ? atoi(e) : 150;
-  }();
+  const ConvTune& tn = convTune();
   // a shape is a candidate if it tiles the channels AND exists for this kernel size (5x5 has no 8-wave x 192 shape: its
   // ring would not fit the LDS); 1x1 never uses the 4-wave x 96 shape (measured slower than 4-wave x 64)
   auto fits = [&](int cfg) { return tiles % ((cfg / 10) * (cfg % 10)) == 0 && convCfgInstantiated(ks, cfg) && !(ks == 1 && cfg == 13); };
   auto wgs = [&](int cfg) { return batch * (tiles / ((cfg / 10) * (cfg % 10))); };
   const int widest8 = fits(23) ? 23 : fits(22) ? 22 : 0;
-  if(widest8 && wgs(widest8) >= minWgs8) return widest8;
-  // the fetching-waves shape while it is the only work-group on its CU (134 VGPRs x 8 waves: one work-group per CU;
-  // KMX_CONV_LOADERS_MAX_WGS moves the limit for scans beyond it)
-  static const int loadersMaxWgs = [] {
-    const char* e = getenv("KMX_CONV_LOADERS_MAX_WGS");
-    return e ? atoi(e) : 256;
-  }();
-  // ... its cell tiles over three work-groups while even that leaves CUs idle (KMX_CONV_LOADERS_SPLIT=0 | 1)
-  static const bool splitOn = [] {
-    const char* e = getenv("KMX_CONV_LOADERS_SPLIT");
-    return e ? e[0] == '1' : true;
-  }();
-  if(ks == 3 && loadersEnabled() && splitOn && batch * tiles * 3 <= loadersMaxWgs) return CFG_LOADERS_SPLIT;
+  if(widest8 && wgs(widest8) >= tn.minWgs8) return widest8;
+  // the fetching-waves shape while it is the only work-group on its CU (134 VGPRs x 8 waves: one work-group per CU), its cell tiles over
+  // three work-groups while even that leaves CUs idle
+  if(ks == 3 && tn.loaders && tn.loadersSplit && batch * tiles * 3 <= tn.loadersMaxWgs) return CFG_LOADERS_SPLIT;
   // (split AND two work-groups per CU for the next 256 work-groups - 88 registers, 68 KB of LDS - measured within 1 % of the unsplit
   // shape at batch 16 - 28 and is not kept: profiles/r04_steps/small_batch/split1x1_scan.txt)
-  if(ks == 3 && loadersEnabled() && batch * tiles <= loadersMaxWgs) return CFG_LOADERS;
-  // ... and two per CU up to twice that (KMX_CONV_LOADERS_PACKED_MAX_WGS; 0 = off). Measured on the MI355X, b18c384nbt device-resident:
-  // batch 43 2.72 -> 2.43 ms per pass, 48 2.77 -> 2.51, 64 2.86 -> 2.69, 85 3.06 -> 3.05; beyond two per CU it loses (96: 3.89 -> 4.10 ms),
+  if(ks == 3 && tn.loaders && batch * tiles <= tn.loadersMaxWgs) return CFG_LOADERS;
+  // ... and two per CU up to twice that. Measured on the MI355X, b18c384nbt device-resident: batch 43 2.72 -> 2.43 ms per pass,
+  // 48 2.77 -> 2.51, 64 2.86 -> 2.69, 85 3.06 -> 3.05; beyond two per CU it loses (96: 3.89 -> 4.10 ms),
   // profiles/r04_steps/small_batch/mid_batch_packed.txt
-  static const int packedMaxWgs = [] {
-    const char* e = getenv("KMX_CONV_LOADERS_PACKED_MAX_WGS");
-    return e ? atoi(e) : 512;
-  }();
-  if(ks == 3 && loadersEnabled() && batch * tiles <= packedMaxWgs) return CFG_LOADERS_PACKED;
+  if(ks == 3 && tn.loaders && batch * tiles <= tn.packedMaxWgs) return CFG_LOADERS_PACKED;
   // 1x1 while every work-group has a CU to itself: the deep ring
-  static const int deep32MaxWgs = [] {  // (tests: 0 sends every 1x1 layer with an even tile count to the 64-channel deep shape)
-    const char* e = getenv("KMX_CONV_DEEP1X1_MAX_WGS");
-    return e ? atoi(e) : 256;
-  }();
-  static const bool split1x1 = [] {  // KMX_CONV_SPLIT1X1 = 0 | 1
-    const char* e = getenv("KMX_CONV_SPLIT1X1");
-    return e ? e[0] == '1' : true;
-  }();
-  if(ks == 1 && deep1x1() != 0 && split1x1 && batch * tiles * 3 <= deep32MaxWgs) return CFG_DEEP1X1_SPLIT;
-  if(ks == 1 && deep1x1() != 0 && batch * tiles <= deep32MaxWgs) return CFG_DEEP1X1_4;
-  if(ks == 1 && deep1x1() != 0 && tiles % 2 == 0 && batch * (tiles / 2) <= 256) return CFG_DEEP1X1_64;
+  if(ks == 1 && tn.deep1x1 && tn.split1x1 && batch * tiles * 3 <= tn.deep1x1MaxWgs) return CFG_DEEP1X1_SPLIT;
+  if(ks == 1 && tn.deep1x1 && batch * tiles <= tn.deep1x1MaxWgs) return CFG_DEEP1X1_4;
+  if(ks == 1 && tn.deep1x1 && tiles % 2 == 0 && batch * (tiles / 2) <= 256) return CFG_DEEP1X1_64;
   // 3x3/5x5 narrow shapes keep two work-groups per CU (LDS), 1x1 shapes one
   const int round = ks == 1 ? 200 : 420;
   if(fits(11) && wgs(11) <= round) return 11;

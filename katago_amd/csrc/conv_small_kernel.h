@@ -51,6 +51,7 @@ struct SG {
   static constexpr int NSW = DEPTH == 0 ? 4 : 8;
   static constexpr int NSA = DEPTH == 1 ? 3 : 2;
   static constexpr int DIST = NSA - 1;  // the image of chunk c + DIST is requested while the loop works on chunk c
+  static_assert((DIST + 1) * KCHUNK * 2 <= DEVBUF_TAIL_BYTES, "the image requests' run-ahead must stay inside the readable tail of a DevBuf");
   static constexpr int RING_OFFSET = NSA * ACT_BYTES;
   static constexpr int SLACK_OFFSET = RING_OFFSET + NSW * W_BYTES;
   static constexpr int MASK_OFFSET = SLACK_OFFSET + SLACK_BYTES;

@@ -1,5 +1,6 @@
 // engine.cpp — see engine.h. Compiled with hipcc (host code only; kernels live in the .hip files).
 #include "engine.h"
+#include "numa.h"
 
 #include <algorithm>
 #include <cmath>
@@ -186,6 +187,9 @@ void Engine::construct(const ModelDesc& model) {
   dSpatialIn_ = DevBuf(NS * cin_ * sizeof(float));
   dGlobalIn_ = DevBuf((size_t)maxBatch_ * gin_ * sizeof(float));
   dPackedIn_ = DevBuf((size_t)maxBatch_ * packedRowBytes());
+  // pinned staging on the device's NUMA node (numa.h): the runtime places hipHostMalloc memory next to the current device, and the
+  // allocating thread prefers that node for as long as this scope lasts
+  const numa::PreferDeviceNode stagingNode(device_);
   hipCheck(hipHostMalloc((void**)&hPacked_, (size_t)maxBatch_ * packedRowBytes()), "hipHostMalloc");
   if(min_ > 0) {
     dMetaIn_ = DevBuf((size_t)maxBatch_ * min_ * sizeof(float));
@@ -217,6 +221,16 @@ Engine::~Engine() { destroy(); }
 void Engine::destroy() noexcept {
   // (the thread that frees a handle or a batcher need not be one that ever used it: with one port per GPU in one process the
   // evaluator's owner tears all of them down - found by the dry run on 8 fake devices, tests/test_schedule_dryrun.py)
+  // The caller's current device is put back at the end: tear-down runs on an owner thread that goes on with its own device
+  // (torch in bench.py, another backend in the same process).
+  int callerDevice = -1;
+  if(hipGetDevice(&callerDevice) != hipSuccess) callerDevice = -1;
+  struct RestoreDevice {
+    int dev, mine;
+    ~RestoreDevice() {
+      if(dev >= 0 && dev != mine) (void)hipSetDevice(dev);
+    }
+  } restore{callerDevice, device_};
   (void)hipSetDevice(device_);
   if(stream_) (void)hipStreamSynchronize(stream_);
   dropGraphs();

@@ -28,7 +28,7 @@ struct Error : std::runtime_error {
 };
 void hipCheck(hipError_t e, const char* what);
 
-constexpr size_t DEVBUF_TAIL = 512;
+constexpr size_t DEVBUF_TAIL = DEVBUF_TAIL_BYTES;  // kernels.h: what the kernels' run-ahead is checked against
 constexpr size_t MAX_GRAPHS = 48;  // captured schedules kept per engine (least recently used evicted)
 
 // RAII device allocation

@@ -1,0 +1,44 @@
+/* katamx_tuning.h - kernel-tuning instrumentation exported by libkatamx.so beside the C ABI of include/katamx.h.
+ *
+ * NOT part of the drop-in boundary: nothing a KataGo binding needs is declared here. These entry points time single kernels on
+ * synthetic data, expose the convolution launcher's shape choice to the tests, and measure the matrix cores' issue rate; they are
+ * called by tools/*.py, bench.py's `box` field and tests/test_conv_chooser.py through katago_amd/capi.py (TUNING_SIGNATURES).
+ * (They sat in include/katamx.h until ABI 6.) */
+#ifndef KATAMX_TUNING_H_
+#define KATAMX_TUNING_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Average duration (ms, hipEvents) of one launch of the bf16 convolution kernel on synthetic data: kernel size ks,
+ * wn = 32-channel tiles per wave, variant = 0 (product kernel) or depth*1000 + ablation mask (conv_kernel.h),
+ * epilogue_mode 0 = BN+act output, 1 = residual + raw + BN+act outputs. Kernel tuning instrumentation. */
+int kmx_bench_conv(int ks, int wn, int variant, int cin, int cout, int batch, int nn_x_len, int nn_y_len,
+                   int epilogue_mode, int iters, double* avg_ms);
+/* The same layer on n_streams streams at once (each its own `batch` boards, `launches` back-to-back launches), stream i
+ * started i * delay_us microseconds after stream 0: what a stagger of a FRACTION of a launch between co-resident
+ * work-groups buys. total_ms = wall time from the common start to the last stream's end. Kernel tuning instrumentation. */
+int kmx_bench_conv_streams(int ks, int cfg, int cin, int cout, int batch, int n_streams, double delay_us, int launches,
+                           int epilogue_mode, double* total_ms);
+/* Average duration (ms) of one launch of the fused seam kernel (192 -> 384 -> 192, mish, bf16) on `batch` 19x19 boards of
+ * synthetic data; timing != 0 runs the instrumented instantiation of the persistent kernel and prints per-wave cycle sums of
+ * its phases on stderr. KMX_PW_V2=0 selects the one-tile-per-work-group kernel. Kernel tuning instrumentation. */
+int kmx_bench_seam(int batch, int iters, int timing, double* avg_ms);
+/* n_conv (2 | 4) convolutions 3x3 192 -> 192 on `batch` 19x19 boards, per sequence: chained = 0 one launch each, 2 | 4 chained launches
+ * (conv_chain_kernel.h); timing != 0: the chained launches print cycle stamps per phase to stderr. KMX_BENCH_DTYPE=fp16 | bf16 (default). */
+int kmx_bench_conv_chain(int batch, int n_conv, int chained, int iters, int timing, double* avg_ms);
+/* Host-only introspection of the convolution launcher (no device needed): the work-group shape chosen for a kernel size,
+ * a padded channel count (multiple of 64) and a batch, and whether a kernel of that shape exists and tiles the channels.
+ * tests/test_conv_chooser.py walks every combination the engine can ask for. */
+int kmx_debug_conv_cfg(int ks, int cout_pad, int batch, int* cfg, int* instantiated);
+
+/* MFMA issue-rate microbenchmark (v_mfma_f32_32x32x16_bf16, 18 per step as in the convolution): mode bit 1 adds an
+ * s_barrier per step, bit 2 adds the step's 12 ds_read_b128. Reports the rate and the shader clock it ran at: the
+ * practical ceiling the convolution is measured against. Kernel tuning instrumentation. */
+int kmx_bench_mfma(int waves_per_wg, int wgs, int mode, int steps, int iters, double* avg_ms, double* tflops, double* core_mhz);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KATAMX_TUNING_H_ */

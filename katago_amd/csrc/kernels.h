@@ -21,6 +21,10 @@ constexpr int KCHUNK = 32;      // input channels per K chunk
 constexpr int ZERO_PAGE_BYTES = 16384;  // >= (inC/32 + 4) * 64
 constexpr int TRASH_BYTES = 1024;       // writable scratch BEHIND the zero page: where the convolution's stores that must not land go (16 bytes per lane)
 constexpr int ZERO_PAGE_ALLOC = ZERO_PAGE_BYTES + TRASH_BYTES;
+// readable bytes behind EVERY device allocation (engine.cpp DevBuf): the image requests of the convolution kernels keep advancing their
+// per-lane source pointers 64 bytes per chunk past the last chunk - up to RING DEPTH chunks beyond the last cell's row, destination
+// redirected to a slack area, the read itself still issued. Each kernel family static_asserts its run-ahead against this.
+constexpr int DEVBUF_TAIL_BYTES = 512;
 constexpr int WROW_HALFS = 32;  // halfs per weight/activation LDS row (64 bytes = four 16-byte slots, XOR-swizzled)
 
 // One fused convolution: out = epilogue( conv(in, w) ).

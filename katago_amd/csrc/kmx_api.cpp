@@ -10,6 +10,7 @@
 #include <string>
 
 #include "../../include/katamx.h"
+#include "katamx_tuning.h"
 #include "engine.h"
 #include "model_desc.h"
 

@@ -37,6 +37,10 @@ struct hipDeviceProp_t { char name[256]; char gcnArchName[256]; int multiProcess
 inline const char* hipGetErrorString(hipError_t) { return "emulated HIP"; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipDeviceGetPCIBusId(char* id, int len, int) {  // no PCI device behind the emulation: numa.cpp then leaves placement alone
+  if(len > 0) id[0] = 0;
+  return hipErrorInvalidValue;
+}
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
   memset(p, 0, sizeof(*p));
   strcpy(p->name, "CPU emulation");

@@ -124,6 +124,13 @@ hipError_t hipGetDevicePropertiesR0600(hipDeviceProp_t* prop, int) {  // what hi
   prop->multiProcessorCount = 256;
   return hipSuccess;
 }
+// PCI bus id of fake device d: bus 0x1A + d, upper-case hex as the real runtime prints it (numa.cpp lower-cases it for sysfs); the NUMA
+// tests build a matching tree under KMX_SYSFS_ROOT (tests/test_schedule_dryrun.py)
+hipError_t hipDeviceGetPCIBusId(char* pciBusId, int len, int device) {
+  if(device < 0 || device >= numDevices() || len < 13) return hipErrorInvalidValue;
+  snprintf(pciBusId, (size_t)len, "0000:%02X:00.0", 0x1A + device);
+  return hipSuccess;
+}
 const char* hipGetErrorString(hipError_t) { return "fakehip"; }
 hipError_t hipGetLastError(void) { return hipSuccess; }
 hipError_t hipPeekAtLastError(void) { return hipSuccess; }

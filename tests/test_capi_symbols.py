@@ -8,8 +8,8 @@ from katago_amd import capi
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(REPO, "include", "katamx.h")).read()
+def declared_symbols(header=os.path.join("include", "katamx.h")):
+    text = open(os.path.join(REPO, header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(kmx_[a-z0-9_]+)\s*\(", text)))
 
@@ -21,11 +21,17 @@ def test_header_symbols_exported_and_bound():
     for s in syms:
         assert hasattr(lib, s), "libkatamx.so does not export %s" % s
     assert sorted(capi.SIGNATURES) == syms, "capi.SIGNATURES is out of sync with include/katamx.h"
+    # the public header holds the boundary only: kernel-tuning instrumentation lives in a private header (ABI 7)
+    assert not [s for s in syms if s.startswith(("kmx_bench_", "kmx_debug_"))]
+    tuning = declared_symbols(os.path.join("katago_amd", "csrc", "katamx_tuning.h"))
+    assert sorted(capi.TUNING_SIGNATURES) == tuning and len(tuning) == 6
+    for s in tuning:
+        assert hasattr(lib, s), "libkatamx.so does not export %s" % s
 
 
 def test_abi_version_and_errors_without_gpu():
     lib = capi.load_library()
-    assert lib.kmx_abi_version() == 6
+    assert lib.kmx_abi_version() == 7
     p = ctypes.c_void_p()
     rc = lib.kmx_model_load(b"/nonexistent/model.bin.gz", b"", ctypes.byref(p))
     assert rc == capi.KMX_ERR_IO and b"model.bin.gz" in lib.kmx_last_error()

@@ -20,7 +20,7 @@ from conftest import REPO
 FAKE = os.path.join(REPO, "tests", "fakehip")
 CSRC = os.path.join(REPO, "katago_amd", "csrc")
 SOURCES = [os.path.join(FAKE, "emulate_engine.cpp")] + [os.path.join(CSRC, f) for f in
-                                                          ("misc_kernels.hip", "transformer_kernels.hip", "engine.cpp", "model_desc.cpp", "kmx_api.cpp", "batcher.cpp")]
+                                                          ("misc_kernels.hip", "transformer_kernels.hip", "engine.cpp", "model_desc.cpp", "kmx_api.cpp", "batcher.cpp", "numa.cpp")]
 
 
 @pytest.fixture(scope="module")
@@ -196,16 +196,17 @@ for (ks, cin, cout, X, Y, n) in json.loads(sys.argv[2]):
 print("RESULT " + json.dumps(out))
 """ % (REPO,)
 # 3x3 on the 4-wave x 32-channel shape (every wave issues weights and image pieces, padded to a constant count), 1x1 (whole images
-# ride the ring), 5x5, and 3x3 96 -> 192 which KMX_MIN_WGS8=1 sends to the 8-wave shape whose waves 0-3 issue all requests
+# ride the ring), 5x5, and 3x3 96 -> 192 which KMX_CONV_TUNE min_wgs8=1 sends to the 8-wave shape whose waves 0-3 issue all requests
 LATE_DMA_SHAPES = [(3, 64, 32, 9, 9, 1), (1, 96, 64, 13, 13, 1), (5, 32, 64, 9, 9, 1), (3, 96, 192, 19, 19, 1)]
 
 
 def conv_only(lib, env, shapes=None):
-    # (KMX_CONV_LOADERS=0: the small 3x3 case is to take the padded 4-wave shape of conv_kernel.h here; the shape with fetching waves,
+    # (loaders=0: the small 3x3 case is to take the padded 4-wave shape of conv_kernel.h here; the shape with fetching waves,
     # conv_small_kernel.h, has its own tests. The 1x1 case takes the deep-ring shape, cfg 114; the two-step ring and the other deep
     # shapes are in test_kernels_latest_completion.py::test_deep_ring_1x1_shapes)
-    return ([sys.executable, "-c", CONV_ONLY, lib, json.dumps(shapes or LATE_DMA_SHAPES)],
-            dict(os.environ, KMX_MIN_WGS8="1", KMX_CONV_LOADERS="0", **env))
+    env = dict(env)
+    tune = "min_wgs8=1,loaders=0" + ("," + env.pop("KMX_CONV_TUNE_MORE") if "KMX_CONV_TUNE_MORE" in env else "")
+    return ([sys.executable, "-c", CONV_ONLY, lib, json.dumps(shapes or LATE_DMA_SHAPES)], dict(os.environ, KMX_CONV_TUNE=tune, **env))
 
 
 def test_real_convolution_kernel_emulated(emu_full_lib):
@@ -257,7 +258,7 @@ print("RESULT " + json.dumps(out))
 
 
 def test_eight_wave_shapes_emulated(emu_full_lib):
-    """The product's 8-wave 3x3 shapes forced at a small batch with KMX_MIN_WGS8=1: same answers as conv2d. (The even-tap-barrier
+    """The product's 8-wave 3x3 shapes forced at a small batch with KMX_CONV_TUNE=min_wgs8=1: same answers as conv2d. (The even-tap-barrier
     variant that this test also ran in rounds 2-3 spilled registers on the hardware and is deleted; DESIGN.md 4.8 keeps the record.)"""
     code = r"""
 import sys, json
@@ -278,7 +279,7 @@ for (cin, cout, X, Y, n) in ((64, 192, 19, 19, 1), (96, 128, 13, 9, 1)):
     out["%%d_%%d" %% (cin, cout)] = [float(np.abs(got.reshape(want.shape) - want).max()), float(np.abs(want).max())]
 print("RESULT " + json.dumps(out))
 """ % (REPO,)
-    (rc, so, se), = run_parallel([([sys.executable, "-c", code, emu_full_lib], dict(os.environ, KMX_MIN_WGS8="1"))])
+    (rc, so, se), = run_parallel([([sys.executable, "-c", code, emu_full_lib], dict(os.environ, KMX_CONV_TUNE="min_wgs8=1"))])
     assert rc == 0, (so + se)[-3000:]
     for k, v in json.loads(so.split("RESULT ")[1]).items():
         assert v[0] <= 2.0 ** -7 * max(1.0, v[1]) * 1.5, (k, v)

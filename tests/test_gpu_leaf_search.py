@@ -68,4 +68,7 @@ def test_search_driven_rate_reaches_the_device_rate(tmp_path):
     # 42.4 k (97 %), 8000-visit searches 35.4 k (92 %) / 40.9 k (94 %), 1600-visit searches 36.3 k (83 %) on the faster box.
     assert long_rate >= 0.9 * device, lines
     assert rate >= 0.8 * device, lines
+    # ... and an absolute floor for the short-search regime beside the ratio: 8000-visit searches measured 35.4 k on the
+    # slowest box of round 4 (device 38.5 k), 1600-visit ones 33.8-36.3 k
+    assert rate >= 31000.0 and short >= 28000.0, lines
     assert rate >= 0.9 * threads_rate, lines  # (since the batcher seals at the device's granule, 512 OS threads are not far behind)

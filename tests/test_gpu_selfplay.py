@@ -124,7 +124,10 @@ def test_selfplay_rate_with_leaves_in_flight_per_game(tmp_path):
     if os.path.isdir(keep):
         with open(os.path.join(keep, "selfplay_rate_b18_own_evaluator.txt"), "w") as f:
             f.write("\n".join(lines) + "\n")
-    assert rates["8 leaves per game (fibers), visits of selfplay8mainb18.cfg"] >= 2500.0, lines
+    # absolute floors beside the ratio below (a relaxed ratio must not hide an absolute regression): round 4's last full run
+    # measured 1 207 / 3 639 / 8 883 rows/s on a slow box; the floors are those minus the spread between boxes (~25 %)
+    assert rates["8 leaves per game (fibers), visits of selfplay8mainb18.cfg"] >= 6000.0, lines
+    assert rates["8 leaves per game (fibers)"] >= 2600.0 and rates["1 leaf per game"] >= 850.0, lines
     # (2.9-3.9 x in rounds 3-4; 1.94 x once small passes got faster at the end of round 4 - 2.5 k -> 4.9 k rows/s: a pass over 8 rows
     # fell from 2.07 to 1.65 ms, a pass over ~30 rows did not - both rates rose)
     assert rates["8 leaves per game (fibers)"] >= 1.5 * rates["1 leaf per game"], lines

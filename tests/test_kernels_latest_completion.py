@@ -48,7 +48,7 @@ def test_latest_completion_catches_a_wrong_count(tmp_path):
     print("late completion, one request too generous:", late)
     assert "conv3_64_32" in wrong and "conv3_96_192" in wrong, late  # the padded 4-wave shape and the 8-wave loader shape
     # the small-batch shape with its fetching waves' wait one request too generous
-    runs = run_parallel([([sys.executable, "-c", CW12_CODE, lib], dict(os.environ, KMX_CONV_LOADERS="1", KMX_EMU_LATE_DMA=late_)) for late_ in ("0", "2")])
+    runs = run_parallel([([sys.executable, "-c", CW12_CODE, lib], dict(os.environ, KMX_CONV_TUNE="loaders=1", KMX_EMU_LATE_DMA=late_)) for late_ in ("0", "2")])
     (rc0, so0, se0), (rc1, so1, se1) = runs
     assert rc0 == 0 and rc1 == 0, (so0 + se0 + so1 + se1)[-3000:]
     c0, c1 = json.loads(so0.split("RESULT ")[1]), json.loads(so1.split("RESULT ")[1])
@@ -99,7 +99,7 @@ def test_small_batch_shape_with_fetching_waves(emu_full_lib):
     variants = (("0", "0", "0", "0"), ("1", "0", "0", "0"), ("1", "0", "0", "2"), ("1", "1", "0", "0"), ("1", "1", "0", "1"), ("1", "1", "0", "2"),
                 ("1", "1", "1", "0"), ("1", "1", "1", "2"))
     runs = run_parallel([([sys.executable, "-c", CW12_CODE, emu_full_lib],
-                          dict(os.environ, KMX_CONV_LOADERS=ld, KMX_CONV_LOADERS_DEPTH=depth, KMX_CONV_LOADERS_SPLIT=split, KMX_EMU_LATE_DMA=late))
+                          dict(os.environ, KMX_CONV_TUNE="loaders=%s,loaders_depth=%s,loaders_split=%s" % (ld, depth, split), KMX_EMU_LATE_DMA=late))
                          for ld, depth, split, late in variants])
     res = []
     for rc, so, se in runs:
@@ -119,12 +119,13 @@ def test_deep_ring_1x1_shapes(emu_full_lib):
     fewer steps than the ring is deep (96 channels: 3), with many (384: 12), several boards, a rectangular board; with immediate copies
     and both latest-completion modes; BIT-IDENTICAL to the two-step ring (same MFMAs per output in the same K order)."""
     shapes = [(1, 96, 64, 13, 13, 1), (1, 384, 96, 19, 19, 2), (1, 40, 192, 9, 7, 3)]
-    one = {"KMX_CONV_SPLIT1X1": "0"}  # a board's cell tiles in ONE work-group
-    envs = [dict(one, KMX_CONV_DEEP1X1="0"),
-            dict(one, KMX_CONV_DEEP1X1="4"), dict(one, KMX_CONV_DEEP1X1="4", KMX_EMU_LATE_DMA="2"),
-            dict(one, KMX_CONV_DEEP1X1="4", KMX_EMU_LATE_DMA="1"),
-            dict(one, KMX_CONV_DEEP1X1="4", KMX_CONV_DEEP1X1_MAX_WGS="0", KMX_EMU_LATE_DMA="2"),  # the 64-channel deep shape where tiles are even
-            {"KMX_CONV_DEEP1X1": "4"}, {"KMX_CONV_DEEP1X1": "4", "KMX_EMU_LATE_DMA": "2"}]  # cfg 113: the cell tiles over three work-groups
+    # (conv_only adds min_wgs8=1,loaders=0; KMX_CONV_TUNE_MORE is appended to it)
+    one = "split1x1=0,"  # a board's cell tiles in ONE work-group
+    envs = [{"KMX_CONV_TUNE_MORE": one + "deep1x1=0"},
+            {"KMX_CONV_TUNE_MORE": one + "deep1x1=1"}, {"KMX_CONV_TUNE_MORE": one + "deep1x1=1", "KMX_EMU_LATE_DMA": "2"},
+            {"KMX_CONV_TUNE_MORE": one + "deep1x1=1", "KMX_EMU_LATE_DMA": "1"},
+            {"KMX_CONV_TUNE_MORE": one + "deep1x1=1,deep1x1_max_wgs=0", "KMX_EMU_LATE_DMA": "2"},  # the 64-channel deep shape where tiles are even
+            {"KMX_CONV_TUNE_MORE": "deep1x1=1"}, {"KMX_CONV_TUNE_MORE": "deep1x1=1", "KMX_EMU_LATE_DMA": "2"}]  # cfg 113: the cell tiles over three work-groups
     res = []
     for env, (rc, so, se) in zip(envs, run_parallel([conv_only(emu_full_lib, env, shapes) for env in envs])):
         assert rc == 0 and "RESULT " in so, (env, (so + se)[-3000:])

@@ -175,14 +175,17 @@ def test_two_devices_in_one_process(fake_so, tmp_path):
     assert per_dev[0] > 100 and per_dev[1] > 100, per_dev  # (how the batchers cut their rows into batches depends on timing)
 
 
-def test_eight_devices_selfplay_in_one_process(fake_so, tmp_path):
+@pytest.mark.parametrize("policy", ["spread", "fill"])
+def test_eight_devices_selfplay_in_one_process(fake_so, tmp_path, policy):
     """The 8-GPU recipe without the node: tools/selfplay_8gpu.sh - `katago_hip selfplay` with the reference's production settings, one
     leaf port per device chosen by ...DeviceToUseThread0..7 (program/setup.cpp:174-220) - on EIGHT fake devices. The whole host
     stack runs (search on fibers, this repo's evaluator and featuriser, eight leaf batchers with their dispatcher / completion
     threads, engines, staging copies); kernels are not executed, so the games are random play. Checked: eight ports on eight
     devices, no stream / event / launch touched while another device was current (also at tear-down: the main thread frees all
     eight batchers), every device gets its share of the rows (the evaluator sends a row to the device with the fewest rows in
-    flight), all games finish and the shards hold all three board sizes."""
+    flight; with KATAMX_PORT_POLICY=fill to the first port that holds fewer than a target - the A/B switch for the day a node exists),
+    every port's helper threads bound to the CPUs of its device's NUMA node (a fake two-node sysfs tree), all games finish and the shards
+    hold all three board sizes."""
     import shard_checks
     from katago_amd import modelgen
 
@@ -193,8 +196,25 @@ def test_eight_devices_selfplay_in_one_process(fake_so, tmp_path):
     os.makedirs(os.path.join(d, "models"))
     modelgen.write_model(os.path.join(d, "models", "b2c32nbt-s1-d1.bin.gz"), "b2c32nbt", seed=3)
     log_path = os.path.join(d, "fake.log")
+    # a two-socket node in miniature (numa.h): fake devices 0-3 sit on NUMA node 0, 4-7 on node 1 (sysfs tree under KMX_SYSFS_ROOT; the
+    # fake runtime's PCI ids are 0000:1A:00.0 + device, upper case as the real runtime prints them), the CPUs this process may use are
+    # dealt to the two nodes half and half
+    cpus = sorted(os.sched_getaffinity(0))
+    halves = [cpus[:max(1, len(cpus) // 2)], cpus[len(cpus) // 2:] or cpus]
+    sysfs = os.path.join(d, "sys")
+    for dev in range(8):
+        pci = os.path.join(sysfs, "bus", "pci", "devices", "0000:%02x:00.0" % (0x1A + dev))
+        os.makedirs(pci)
+        with open(os.path.join(pci, "numa_node"), "w") as f:
+            f.write("%d\n" % (dev // 4))
+    for node in range(2):
+        nd = os.path.join(sysfs, "devices", "system", "node", "node%d" % node)
+        os.makedirs(nd)
+        with open(os.path.join(nd, "cpulist"), "w") as f:
+            f.write(",".join(str(c) for c in halves[node]) + "\n")
     env = dict(os.environ, KMX_LAUNCH_PREFIX="env LD_PRELOAD=%s KMX_FAKEHIP_DEVICES=8 KMX_FAKEHIP_QUIET=1 KMX_FAKEHIP_LOG=%s" % (fake_so, log_path),
-               KMX_SELFPLAY_ARGS="-max-games-total 48", KATAMX_LEAVES_PER_THREAD="2")
+               KMX_SELFPLAY_ARGS="-max-games-total 48", KATAMX_LEAVES_PER_THREAD="2", KMX_SYSFS_ROOT=sysfs, KATAMX_NUMA_VERBOSE="1",
+               KATAMX_PORT_POLICY=policy, KATAMX_PORT_FILL_ROWS="8")
     extra = ["nnMaxBatchSize=16", "maxVisits=12", "cheapSearchVisits=6", "reducedVisitsMin=6", "estimateLeadVisits=3", "maxMovesPerGame=24",
              "logGamesEvery=1000", "nnCacheSizePowerOfTwo=14", "nnMutexPoolSizePowerOfTwo=10", "handicapAsymmetricPlayoutProb=0.0",
              "normalAsymmetricPlayoutProb=0.0", "switchNetsMidGame=false", "maxRowsPerTrainFile=100", "firstFileRandMinProp=1.0",
@@ -208,8 +228,28 @@ def test_eight_devices_selfplay_in_one_process(fake_so, tmp_path):
     fake = open(log_path).read().splitlines()
     assert not [l for l in fake if l.startswith("VIOLATION")], [l for l in fake if l.startswith("VIOLATION")][:10]
     per_dev = {int(m.group(1)): int(m.group(2)) for m in (re.match(r"dev (\d+) launches (\d+)", l) for l in fake) if m}
-    assert sorted(per_dev) == list(range(8)) and min(per_dev.values()) > 1000, per_dev
-    assert max(per_dev.values()) < 1.5 * min(per_dev.values()), per_dev  # least rows in flight first: no device is left behind
+    assert sorted(per_dev) == list(range(8)) and (policy == "fill" or min(per_dev.values()) > 1000), per_dev
+    if policy == "spread":
+        assert max(per_dev.values()) < 1.5 * min(per_dev.values()), per_dev  # least rows in flight first: no device is left behind
+        assert "rows go to the port with the fewest rows in flight" in log
+    else:
+        # fill-first: a port is passed over only while it holds KATAMX_PORT_FILL_ROWS rows, so the first devices carry most of the load
+        assert "rows go to the first port below 8 rows in flight (KATAMX_PORT_POLICY=fill)" in log
+        assert per_dev[0] > 2 * per_dev[7], per_dev
+    # NUMA (round 5): every device's dispatcher and completion threads run on the CPUs of ITS node, pinned staging prefers that node
+    def cpulist(text):
+        out = []
+        for part in text.split(","):
+            a, _, b = part.partition("-")
+            out.extend(range(int(a), int(b or a) + 1))
+        return out
+    bound = re.findall(r"\[katamx numa\] device (\d+) -> node (\d+): (dispatcher|completion) thread bound to cpus ([\d,\-]+)", log)
+    seen = {(int(dv), what) for dv, _, what, _ in bound}
+    assert seen == {(dv, what) for dv in range(8) for what in ("dispatcher", "completion")}, sorted(seen)
+    for dv, node, what, cl in bound:
+        assert int(node) == int(dv) // 4 and cpulist(cl) == halves[int(node)], (dv, node, what, cl, halves)
+    staged = {(int(dv), int(node)) for dv, node in re.findall(r"\[katamx numa\] device (\d+) -> node (\d+): pinned staging", log)}
+    assert staged == {(dv, dv // 4) for dv in range(8)}, sorted(staged)
     games = int(log.split("Final games finished: ")[1].split()[0])
     rows = int(log.split("Final data rows: ")[1].split()[0])
     assert games >= 48

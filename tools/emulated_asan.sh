@@ -41,12 +41,12 @@ sp, gl = make_rows(rng, 2, 19, [(19, 19), (9, 13)])
 h = nn.createComputeHandle(ctx, nn.loadModelFile(p), 2)
 assert all(np.isfinite(v).all() for v in nn.getOutput(h, sp, gl, np.array([3, 6], np.int32), np.array([0, 1], np.float32)).values())
 h.close()
-print("clean:", {k: os.environ.get(k) for k in ("KMX_MIN_WGS8", "KMX_CONV_LOADERS", "KMX_CONV_LOADERS_SPLIT", "KMX_CONV_SPLIT1X1", "KMX_CONV_DEEP1X1", "KMX_CONV_LOADERS_MAX_WGS")})
+print("clean:", os.environ.get("KMX_CONV_TUNE"))
 PY
 export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1
 # the default small-batch shapes (cfg 113 / 117: a board's cell tiles over three work-groups; 114), the unsplit ones (114 / 118), the
 # two-per-CU shape (119), the 4-wave shapes of conv_kernel.h, the 8-wave shapes
-for v in "A=1" "KMX_CONV_LOADERS_SPLIT=0 KMX_CONV_SPLIT1X1=0" "KMX_CONV_LOADERS_MAX_WGS=0" "KMX_CONV_LOADERS=0 KMX_CONV_DEEP1X1=0" "KMX_MIN_WGS8=1"; do
+for v in "A=1" "KMX_CONV_TUNE=loaders_split=0,split1x1=0" "KMX_CONV_TUNE=loaders_max_wgs=0" "KMX_CONV_TUNE=loaders=0,deep1x1=0" "KMX_CONV_TUNE=min_wgs8=1"; do
   env LD_PRELOAD="$ASAN" $v python3 run.py
 done
 echo "emulated ASAN run: clean"

@@ -49,16 +49,16 @@ cd "$D"
 $CXX -c conv_mfma.hip -o conv_mfma.o &
 (cd control && $CXX -c conv_mfma.hip -o conv_mfma.o) &
 $CXX -c "$REPO/tests/fakehip/emulate_engine.cpp" -o ee.o &
-for f in misc_kernels.hip transformer_kernels.hip engine.cpp model_desc.cpp kmx_api.cpp; do $CXX -c "$REPO/katago_amd/csrc/$f" -o "${f%.*}.o" & done
+for f in misc_kernels.hip transformer_kernels.hip engine.cpp model_desc.cpp kmx_api.cpp numa.cpp; do $CXX -c "$REPO/katago_amd/csrc/$f" -o "${f%.*}.o" & done
 $CXX -c driver.cpp -o driver.o &
 wait
-OBJS="driver.o ee.o misc_kernels.o transformer_kernels.o engine.o model_desc.o kmx_api.o"
+OBJS="driver.o ee.o misc_kernels.o transformer_kernels.o engine.o model_desc.o kmx_api.o numa.o"
 $CLANG -pthread -fsanitize=thread -o driver $OBJS conv_mfma.o -lz
 $CLANG -pthread -fsanitize=thread -o control/driver $OBJS control/conv_mfma.o -lz
 export TSAN_OPTIONS=halt_on_error=0
 count() { grep -c "WARNING: ThreadSanitizer" "$1" || true; }
-KMX_MIN_WGS8=1 ./driver 3 96 192 19 19 2 > run.log 2>&1 || true
+KMX_CONV_TUNE=min_wgs8=1 ./driver 3 96 192 19 19 2 > run.log 2>&1 || true
 echo "8-wave 3x3 96->192: $(count run.log) reports"
-KMX_MIN_WGS8=1 control/driver 3 96 192 9 9 1 > control.log 2>&1 || true
+KMX_CONV_TUNE=min_wgs8=1 control/driver 3 96 192 9 9 1 > control.log 2>&1 || true
 echo "control (the kernel with its loop barriers removed): $(count control.log) reports (must be > 0)"
 rm -rf "$D"

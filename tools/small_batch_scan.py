@@ -1,6 +1,6 @@
 """Small batches on the MI355X: ms per pass of b18c384nbt 19x19 through kmx_eval (host rows) at batch 1 ... 64, the 3x3
 convolution's time per launch at batch 1 / 8 (hipEvents), and a digest of the outputs of fixed rows - the same rows must give the
-same bits at every batch size and with either work-group shape (KMX_CONV_LOADERS=0 / 1; run once each, compare the digests)."""
+same bits at every batch size and with either work-group shape (KMX_CONV_TUNE=loaders=0 / 1; run once each, compare the digests)."""
 import ctypes
 import hashlib
 import json
@@ -28,7 +28,7 @@ def main():
     sym = (np.arange(64) % 8).astype(np.int32)
     h = nn.createComputeHandle(ctx, model, 256)
     lib = h._lib
-    out = {"loaders": os.environ.get("KMX_CONV_LOADERS", "default"), "precision": h.precision, "ms_per_pass": {}, "rows_per_s": {}}
+    out = {"tune": os.environ.get("KMX_CONV_TUNE", "default"), "precision": h.precision, "ms_per_pass": {}, "rows_per_s": {}}
     ref = nn.getOutput(h, sp, gl, sym)  # 64 rows: the 4-wave shapes
     same = True
     for n in (1, 2, 8, 16, 42):
