@@ -306,7 +306,9 @@ double benchConvStreams(int ks, int cfg, int cin, int cout, int batch, int nStre
 // ---- the seam kernel alone (192 -> 384 -> 192, mish, bf16) on `batch` boards of 19x19 ----------------------------------------
 // timing != 0 runs the instrumented instantiation of the persistent kernel and prints work-group 0's per-wave phase sums.
 double benchSeam(int batch, int iters, int timing) {
-  const int dtype = DT_BF16, S = 361, C1 = 192, C2 = 384, C3 = 192;
+  const char* dtEnv = getenv("KMX_BENCH_DTYPE");  // fp16 | bf16 (default)
+  const int dtype = dtEnv != nullptr && strcmp(dtEnv, "fp16") == 0 ? DT_F16 : DT_BF16;
+  const int S = 361, C1 = 192, C2 = 384, C3 = 192;
   const size_t cells = (size_t)batch * S;
   uint32_t rng = 4711;
   auto rnd = [&]() {
@@ -331,8 +333,8 @@ double benchSeam(int batch, int iters, int timing) {
   const BnDesc bn1 = bnOf(C2), bn2 = bnOf(C3);
   FusedConv f1 = buildFusedConv(dtype, {{&cd1, &bn1}}, nullptr), f2 = buildFusedConv(dtype, {{&cd2, &bn2}}, nullptr);
   std::vector<uint16_t> hx(cells * C1), hr(cells * C2);
-  for(uint16_t& v : hx) v = floatToBf16Bits(rnd());
-  for(uint16_t& v : hr) v = floatToBf16Bits(rnd());
+  for(uint16_t& v : hx) v = floatToTBits(dtype, rnd());
+  for(uint16_t& v : hr) v = floatToTBits(dtype, rnd());
   DevBuf x(hx.size() * 2, false), trunk(hr.size() * 2, false), midRaw(cells * C3 * 2), midAct(cells * C3 * 2), zero(ZERO_PAGE_ALLOC);
   x.upload(hx.data(), hx.size() * 2);
   trunk.upload(hr.data(), hr.size() * 2);
@@ -368,6 +370,14 @@ double benchSeam(int batch, int iters, int timing) {
   if(timing) {
     unsigned long long h[72];
     hipCheck(hipMemcpy(h, dbg.get(), sizeof(h), hipMemcpyDeviceToHost), "copy timing");
+    const char* k = getenv("KMX_PW_KERNEL");
+    if(k == nullptr || atoi(k) == 3) {
+      for(int w = 0; w < 4; w++)  // pointwise3_kernel.h: four waves, six segments
+        fprintf(stderr, "[seam timing, resident weights] wave %d: top (requests, wait X, B1) %llu | gemm 1 %llu | epilogue 1 %llu | B2 %llu | gemm 2 %llu | "
+                        "epilogue 2 %llu | kernel %llu cycles\n",
+                w, h[w * 9 + 0], h[w * 9 + 1], h[w * 9 + 2], h[w * 9 + 3], h[w * 9 + 4], h[w * 9 + 5], h[w * 9 + 8]);
+    }
+    else
     for(int w = 0; w < 8; w++)
       fprintf(stderr, "[seam timing] wave %d: top %llu | gemm1(0) %llu | P1 wait+barrier %llu | gemm1 next %llu | epilogue 1 %llu | P2/P3 wait+barrier %llu "
                       "| gemm2 steps %llu | epilogue 2 %llu | kernel %llu cycles\n",

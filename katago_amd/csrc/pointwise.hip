@@ -4,6 +4,7 @@
 
 #include "pointwise_kernel.h"
 #include "pointwise2_kernel.h"
+#include "pointwise3_kernel.h"
 
 namespace kmx {
 
@@ -61,11 +62,35 @@ int numComputeUnits() {  // per device: one persistent work-group per CU (KMX_PW
   return n;
 }
 
+// Which seam kernel (KMX_PW_KERNEL = 3 | 2 | 1, default 3):
+//   3  pointwise3_kernel.h (round 5): weights resident on the CU (AGPRs + LDS), one wave per SIMD, 64-cell tiles;
+//   2  pointwise2_kernel.h (round 3): persistent, software-pipelined, weights re-fetched per 128-cell tile;
+//   1  pointwise_kernel.h: one tile per work-group.
+// 3 and 2 are persistent work-groups that own their CU (150 KB of LDS): taken when the launch has the chip to itself or holds at least
+// two tiles of 128 cells per CU (PwPairArgs::alone, kernels.h); a smaller launch beside another stream's kernels takes kernel 1.
+// (KMX_PW_V2 = 0 | 2 of rounds 3-4 still reads as "never" / "always" persistent.)
+int pwKernel() {
+  static const int k = [] {
+    const char* e = getenv("KMX_PW_KERNEL");
+    const int v = e ? atoi(e) : 3;
+    return v >= 1 && v <= 3 ? v : 3;
+  }();
+  return k;
+}
+
 template <class TR>
 hipError_t launchT(int c1, int c2, int c3, const PwPairArgs& a, hipStream_t stream) {
-  if(c1 == 192 && c2 == 384 && c3 == 192 && a.actOut == nullptr && a.actKind1 == a.actKind2 && pwWaves() == 8 && persistentWanted() &&
+  if(c1 == 192 && c2 == 384 && c3 == 192 && a.actOut == nullptr && a.actKind1 == a.actKind2 && pwWaves() == 8 && persistentWanted() && pwKernel() >= 2 &&
      (a.alone != 0 || (a.cells + pw2::TM - 1) / pw2::TM >= 2LL * numComputeUnits() || persistentForced()))
   {
+    if(pwKernel() == 3) {
+      if(a.actKind1 == KMX_ACT_MISH) {
+        if(a.dbg != nullptr) return pw3::launchResident<TR, 6, 12, 6, KMX_ACT_MISH, KMX_ACT_MISH, true>(a, numComputeUnits(), stream);
+        return pw3::launchResident<TR, 6, 12, 6, KMX_ACT_MISH, KMX_ACT_MISH>(a, numComputeUnits(), stream);
+      }
+      if(a.actKind1 == KMX_ACT_MISH_SCALE8 && a.dbg == nullptr)
+        return pw3::launchResident<TR, 6, 12, 6, KMX_ACT_MISH_SCALE8, KMX_ACT_MISH_SCALE8>(a, numComputeUnits(), stream);
+    }
     if(a.actKind1 == KMX_ACT_MISH) {
       if(a.dbg != nullptr) return pw2::launchPersistent<TR, 6, 12, 3, KMX_ACT_MISH, KMX_ACT_MISH, true>(a, numComputeUnits(), stream);
       return pw2::launchPersistent<TR, 6, 12, 3, KMX_ACT_MISH, KMX_ACT_MISH>(a, numComputeUnits(), stream);

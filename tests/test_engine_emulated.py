@@ -95,6 +95,27 @@ PW2_REWRITES = [
 ]
 
 
+# pointwise3_kernel.h (round 5: the seam with its weights resident in AGPRs + LDS, one wave per SIMD). Its inline-asm MFMAs are guarded
+# by __AMDGCN__ in the header itself (the emulator's MFMA stand-in runs instead); what is rewritten are the waits, the opaque-register
+# statements, the LDS declaration, the LDS-DMA builtin and the plain loads / stores that take their place in the in-order queue.
+PW3_REWRITES = [
+    (r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\(N\) : "memory"\);', "emu::waitVm(N);", 1),
+    (r'asm volatile\("s_waitcnt lgkmcnt\(0\)" ::: "memory"\);', ";", 1),
+    (r'for\(int i = 0; i < 2; i\+\+\) rq\[s\]\[j\]\[i\] = \*\(const GLOBAL u32x4\*\)\(rrow \+ 32 \* j \+ 16 \* i\);',
+     "for(int i = 0; i < 2; i++) { rq[s][j][i] = *(const GLOBAL u32x4*)(rrow + 32 * j + 16 * i); emu::vmNote(); }", 1),
+    (r'for\(int i = 0; i < 2; i\+\+\) \*\(GLOBAL u32x4\*\)\(rawRow \+ 32 \* j \+ 16 \* i\) = rawQ\[i\];',
+     "for(int i = 0; i < 2; i++) { *(GLOBAL u32x4*)(rawRow + 32 * j + 16 * i) = rawQ[i]; emu::vmNote(); }", 1),
+    (r'\*\(GLOBAL u32x4\*\)\(rawRow2 \+ 16 \* i\) = rawQ\[i\];', "*(GLOBAL u32x4*)(rawRow2 + 16 * i) = rawQ[i]; emu::vmNote();", 1),
+    (r'\*\(GLOBAL u32x4\*\)\(actRow2 \+ 16 \* i\) = oq\[i\];', "*(GLOBAL u32x4*)(actRow2 + 16 * i) = oq[i]; emu::vmNote();", 1),
+    (r'w1f\[j\]\[c\]\[kk\] = (\*\(const V8\*\)[^;]*;)', r"{ w1f[j][c][kk] = \1 emu::vmNote(); }", 1),
+    (r'w2f\[c\]\[kk\] = (\*\(const V8\*\)[^;]*;)', r"{ w2f[c][kk] = \1 emu::vmNote(); }", 1),
+    (r'asm volatile\("" : "\+v"\([^;]*\);', ";", 6),
+    (r'extern __shared__ __attribute__\(\(aligned\(256\)\)\) char smemPw3\[\];', "char* const smemPw3 = (char*)emu::dynLds();", 1),
+    (r'__builtin_amdgcn_global_load_lds\(', "emu::globalLoadLds(", 2),
+    (r'__attribute__\(\(amdgpu_waves_per_eu\(1, 1\)\)\)', "", 1),
+]
+
+
 # conv_chain_kernel.h (2 or 4 chained 3x3 convolutions, the activated image handed over in LDS)
 CHAIN_REWRITES = [
     (r'asm volatile\("" : "\+s"\(sTap\)\);', ";", 2),
@@ -119,7 +140,7 @@ SMALL_REWRITES = [
 ]
 
 
-def build_emu_full(d, conv_mutations=(), pw2_mutations=(), chain_mutations=(), small_mutations=(), extra_flags=(), so_name="libkatamx_emufull.so"):
+def build_emu_full(d, conv_mutations=(), pw2_mutations=(), chain_mutations=(), small_mutations=(), extra_flags=(), so_name="libkatamx_emufull.so", pw3_mutations=()):
     """conv_mutations: further (pattern, replacement, count) rewrites of conv_kernel.h - deliberate defects for the tests of the
     emulator's own teeth. extra_flags: compile AND link flags (tools/emulated_asan.sh: -fsanitize=address ...)."""
     import re
@@ -152,6 +173,11 @@ def build_emu_full(d, conv_mutations=(), pw2_mutations=(), chain_mutations=(), s
         src, k = re.subn(pat, rep, src)
         assert k == count, "pointwise2_kernel.h changed: %r matched %d times, expected %d" % (pat, k, count)
     open(os.path.join(d, "pointwise2_kernel.h"), "w").write(src)
+    src = open(os.path.join(CSRC, "pointwise3_kernel.h")).read()
+    for pat, rep, count in list(PW3_REWRITES) + list(pw3_mutations):
+        src, k = re.subn(pat, rep, src)
+        assert k == count, "pointwise3_kernel.h changed: %r matched %d times, expected %d" % (pat, k, count)
+    open(os.path.join(d, "pointwise3_kernel.h"), "w").write(src)
     shutil.copy(os.path.join(CSRC, "pointwise.hip"), os.path.join(d, "pointwise.hip"))
     cxx = ["/opt/rocm/lib/llvm/bin/clang++", "-x", "c++", "-std=c++20", "-O2", "-fPIC", "-pthread", "-I" + os.path.join(FAKE, "emul"), "-I" + FAKE,
            "-I" + CSRC, "-DKMX_EMU_REAL_CONV"] + list(extra_flags)
@@ -442,9 +468,11 @@ x, resid, w1, s1, b1, w2, s2, b2, m = ref.make_case(rng, batch * L * L, 192, 384
 fused = nn.testEvaluatePointwisePair(batch, L, L, "bf16", x, resid, w1, s1, b1, 2, w2, s2, b2, 2, m, True)
 plain = nn.testEvaluatePointwisePair(batch, L, L, "bf16", x, resid, w1, s1, b1, 2, w2, s2, b2, 2, m, False)
 want = ref.seam(x, resid, w1, s1, b1, 2, w2, s2, b2, 2, m, "bf16")
+import hashlib
 print("RESULT " + json.dumps({"same": [bool(np.array_equal(f, p)) for f, p in zip(fused, plain)],
                               "err": [float(np.abs(f - w).max()) for f, w in zip(fused, want)], "scale": [float(np.abs(w).max()) for w in want],
-                              "off_board_zero": bool((fused[2][m != 1.0] == 0).all())}))
+                              "off_board_zero": bool((fused[2][m != 1.0] == 0).all()),
+                              "digest": hashlib.sha1(b"".join(np.ascontiguousarray(f).tobytes() for f in fused)).hexdigest()}))
 """ % (REPO, os.path.join(REPO, "tests"))
 
 
@@ -455,8 +483,9 @@ def test_persistent_seam_kernel_emulated(emu_full_lib):
     LATEST completion the kernel's s_waitcnt counts allow (a count that is too generous leaves a slab or an X tile stale); bit for
     bit against the one-tile-per-group kernel (KMX_PW_V2=0) and the two emulated convolution launches."""
     code = PW2_CODE
-    envs = ({"KMX_PW_GRID": "1"}, {"KMX_PW_GRID": "2"}, {"KMX_PW_V2": "0"},
-            {"KMX_PW_GRID": "1", "KMX_EMU_LATE_DMA": "1"}, {"KMX_PW_GRID": "2", "KMX_EMU_LATE_DMA": "2"})  # ... and with the latest legal completion (at the wait / at the barrier after it)
+    k2 = {"KMX_PW_KERNEL": "2"}  # (the default is pointwise3_kernel.h since round 5: its test follows)
+    envs = (dict(k2, KMX_PW_GRID="1"), dict(k2, KMX_PW_GRID="2"), {"KMX_PW_V2": "0"},
+            dict(k2, KMX_PW_GRID="1", KMX_EMU_LATE_DMA="1"), dict(k2, KMX_PW_GRID="2", KMX_EMU_LATE_DMA="2"))  # ... and with the latest legal completion (at the wait / at the barrier after it)
     runs = run_parallel([([sys.executable, "-c", code, emu_full_lib], dict(os.environ, **env)) for env in envs])
     for env, (rc, so, se) in zip(envs, runs):
         assert rc == 0 and "RESULT " in so, (so + se)[-3000:]
@@ -465,6 +494,27 @@ def test_persistent_seam_kernel_emulated(emu_full_lib):
         assert all(r["same"]) and r["off_board_zero"], (env, r)
         for e, sc, k in zip(r["err"], r["scale"], (1, 4, 4)):
             assert e <= 2 * 2.0 ** -7 * max(sc, 1.0) * k, (env, r)
+
+
+def test_resident_weights_seam_kernel_emulated(emu_full_lib):
+    """pointwise3_kernel.h (round 5: W1 and W2 resident on the CU, one wave per SIMD, 64-cell tiles) on the CPU: a work-group that walks
+    all six tiles of the case (five full, a tail of 18 cells; KMX_PW_GRID=1), two and three work-groups that share them - X double
+    buffering, the prefetch one tile ahead, the once-only fetch of the shared W2 rows, the A2 image reuse across tiles - with IMMEDIATE
+    copies and with the LATEST completion its one s_waitcnt count allows (at the wait / at the barrier after it); bit for bit against
+    the round-3 persistent kernel, the one-tile-per-group kernel and the two emulated convolution launches."""
+    envs = ({"KMX_PW_KERNEL": "3", "KMX_PW_GRID": "1"}, {"KMX_PW_KERNEL": "3", "KMX_PW_GRID": "2"}, {"KMX_PW_KERNEL": "3", "KMX_PW_GRID": "3", "KMX_EMU_LATE_DMA": "1"},
+            {"KMX_PW_KERNEL": "3", "KMX_PW_GRID": "1", "KMX_EMU_LATE_DMA": "2"}, {"KMX_PW_KERNEL": "2", "KMX_PW_GRID": "1"}, {"KMX_PW_KERNEL": "1"})
+    runs = run_parallel([([sys.executable, "-c", PW2_CODE, emu_full_lib], dict(os.environ, **env)) for env in envs])
+    digests = []
+    for env, (rc, so, se) in zip(envs, runs):
+        assert rc == 0 and "RESULT " in so, (env, (so + se)[-3000:])
+        r = json.loads(so.split("RESULT ")[1])
+        print(env, r)
+        assert all(r["same"]) and r["off_board_zero"], (env, r)
+        for e, sc, k in zip(r["err"], r["scale"], (1, 4, 4)):
+            assert e <= 2 * 2.0 ** -7 * max(sc, 1.0) * k, (env, r)
+        digests.append(r["digest"])
+    assert len(set(digests)) == 1, digests  # the three kernels agree bit for bit
 
 
 def test_bench_small_batch_block_emulated(emu_lib):

@@ -1,0 +1,43 @@
+#!/bin/bash
+# Round-5 GPU calls, by section (one gpurun call runs one or more sections; everything lands under gpurun_out/r05/<section>):
+#   tools/gpu_r05.sh seam        the resident-weights seam kernel: parity on hardware, launch time and cycle stamps against round 3's kernel, whole-net A/B
+#   tools/gpu_r05.sh parity      the round's changed tests (configs[3] in bf16 + fp16, fixed-seed search with the flip list, bench command)
+#   tools/gpu_r05.sh small       small / mid batch scan
+set -u
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+b() { local out=$1; shift; local name=$1; shift; local envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
+  local v=$(env "${envs[@]}" timeout 200 python3 bench.py --no-cpu-baseline --no-callers "$@" 2>>"$out/err.txt" | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"frac": [0-9.]*\|"avg_launch_ms": [0-9.]*' | tr '\n' ' ')
+  echo "$name | $v" | tee -a "$out/scan.txt"; }
+for section in "$@"; do
+OUT=gpurun_out/r05/$section
+rm -rf $OUT; mkdir -p $OUT
+case $section in
+seam)
+  timeout 600 python -m pytest tests/test_gpu_pointwise.py -m gpu -x -q -p no:cacheprovider 2>&1 | tail -3 | tee $OUT/parity.log
+  for k in 3 2; do for dt in fp16 bf16; do
+    echo "== KMX_PW_KERNEL=$k $dt" | tee -a $OUT/seam_timing.txt
+    KMX_PW_KERNEL=$k KMX_BENCH_DTYPE=$dt timeout 120 python tools/seam_timing.py 256 2>&1 | tee -a $OUT/seam_timing.txt
+    KMX_PW_KERNEL=$k KMX_BENCH_DTYPE=$dt timeout 120 python tools/seam_timing.py 128 2>&1 | grep -v "timing\]" | tee -a $OUT/seam_timing.txt
+  done; done
+  for rep in 1 2; do
+    b $OUT "b18 default, seam kernel 3 (resident weights)" KMX_PW_KERNEL=3 -- --steps 40 --warmup 5
+    b $OUT "b18 default, seam kernel 2 (round 3)" KMX_PW_KERNEL=2 -- --steps 40 --warmup 5
+  done
+  b $OUT "b18 one stream, seam kernel 3" KMX_PW_KERNEL=3 KMX_SPLIT_MIN=0 -- --steps 40 --warmup 5 --no-profile
+  b $OUT "b18 one stream, seam kernel 2" KMX_PW_KERNEL=2 KMX_SPLIT_MIN=0 -- --steps 40 --warmup 5 --no-profile
+  b $OUT "b18 bf16, seam kernel 3" KMX_PW_KERNEL=3 -- --dtype bf16 --steps 40 --warmup 5
+  b $OUT "b18 bf16, seam kernel 2" KMX_PW_KERNEL=2 -- --dtype bf16 --steps 40 --warmup 5
+  ;;
+parity)
+  timeout 1500 python -m pytest "tests/test_gpu_model.py::test_large_nets_of_the_analysis_config" "tests/test_gpu_search_fixed_seed.py" tests/test_gpu_layers.py -m gpu -q -p no:cacheprovider -s 2>&1 | grep -v "^$" | tail -60 | tee $OUT/pytest.log
+  cp gpurun_out/search_fixed_seed_*.txt $OUT/ 2>/dev/null
+  KMX_BENCH_SELFPLAY_TIMEOUT=0 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
+  tail -c 3000 $OUT/bench.json
+  ;;
+small)
+  timeout 300 python tools/small_batch_scan.py 2>&1 | grep SCAN | tee $OUT/small_batch_scan.txt
+  for n in 1 8 16 24 32 42 64; do b $OUT "b18 device-resident batch $n" A=1 -- --batch $n --steps 60 --warmup 10 --no-profile; done
+  ;;
+esac
+done
