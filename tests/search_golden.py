@@ -6,11 +6,13 @@ between its own fp32 and fp16 goldens (cpp/tests/results/runSearchTestsV8Bin.txt
 import re
 
 _ROOT = re.compile(r"^: T\s+(-?[\d.]+)c W\s+(-?[\d.]+)c S\s+(-?[\d.]+)c \(.*?\) N\s+(\d+)\s+--\s*(.*)$")
-_CHILD = re.compile(r"^([A-T]\d+|pass)\s*: T\s+(-?[\d.]+)c W\s+(-?[\d.]+)c .*? P\s+([\d.]+)% .*? N\s+(\d+)\s+--")
+_CHILD = re.compile(r"^([A-T]\d+|pass)\s*: T\s+(-?[\d.]+)c W\s+(-?[\d.]+)c .*? LCB\s+(-?[\d.]+)c P\s+([\d.]+)% .*? N\s+(\d+)\s+--")
 
 
 def parse(text):
-    """-> list of searches: dict(root_T, root_N, pv, children=[(loc, T, prior%, N), ...]) in file order."""
+    """-> list of searches: dict(root_T, root_N, pv, children=[(loc, T, prior%, N, LCB), ...]) in file order. The reference prints the
+    children by PLAY SELECTION VALUE (search/searchresults.cpp: visits, with the best lower confidence bound among the well-visited
+    moves promoted to the top), so children[0] - "the best move" - need not be the most visited child."""
     out, cur = [], None
     for line in text.replace("\r", "\n").splitlines():
         m = _ROOT.match(line)
@@ -20,7 +22,7 @@ def parse(text):
             continue
         m = _CHILD.match(line)
         if m and cur is not None:
-            cur["children"].append((m.group(1), float(m.group(2)), float(m.group(4)), int(m.group(5))))
+            cur["children"].append((m.group(1), float(m.group(2)), float(m.group(5)), int(m.group(6)), float(m.group(4))))
     return [s for s in out if s["children"]]
 
 
@@ -40,9 +42,15 @@ def compare(a, b):
         vx = {c[0]: c[3] for c in x["children"]}
         tot = max(sum(vx.values()), 1), max(sum(vy.values()), 1)
         if bx[0] != by[0]:
-            # a flipped best move: how far apart the two candidates are in EACH search, as a share of that search's child visits.
-            # gap_b = b's margin of its own best move over a's best move (inside b); gap_a = a's margin the other way (inside a)
+            # a flipped best move: how far apart the two candidates are in EACH search - in visits, as a share of that search's child
+            # visits (gap_b = b's margin of its own best move over a's best move inside b; gap_a = a's margin the other way inside a), and
+            # in the lower confidence bound that decides the order between well-visited moves (lcb_gap_*, in c = hundredths of utility;
+            # None when a search did not list the other's move)
+            lx = {c[0]: c[4] for c in x["children"]}
+            ly = {c[0]: c[4] for c in y["children"]}
             flips.append(dict(index=idx, root_N=x["root_N"], a_best=bx[0], b_best=by[0],
+                              lcb_gap_a=abs(lx[bx[0]] - lx[by[0]]) if by[0] in lx else None,
+                              lcb_gap_b=abs(ly[by[0]] - ly[bx[0]]) if bx[0] in ly else None,
                               a_visits=(vx.get(bx[0], 0), vx.get(by[0], 0)), b_visits=(vy.get(bx[0], 0), vy.get(by[0], 0)),
                               a_top=[(c[0], c[3]) for c in x["children"][:3]], b_top=[(c[0], c[3]) for c in y["children"][:3]],
                               gap_a=(vx.get(bx[0], 0) - vx.get(by[0], 0)) / tot[0], gap_b=(vy.get(by[0], 0) - vy.get(bx[0], 0)) / tot[1]))

@@ -31,9 +31,13 @@ def _gold(name):
         return sg.parse(f.read())
 
 
-# a flipped best move counts as a near-tie when each search's margin between the two candidates is below this share of its child visits
-# (the golden's own fp16-vs-fp32 spread of the best move's share is 2.5 %, so two moves closer than twice that are within its noise)
-NEAR_TIE = 0.06
+# The reference orders the children by play selection value: visits, with the best LOWER CONFIDENCE BOUND among the well-visited moves
+# promoted to the top (search/searchresults.cpp) - "the best move" is decided by LCBs. A flipped best move counts as a near-tie when the
+# two candidates' LCBs lie within this many c (hundredths of utility) of each other in the golden AND in this backend's search: the
+# reference's own fp16 golden moves root utilities by up to 1.8 c against its fp32 golden (tests/test_search_golden.py).
+# Round 5, measured (profiles/r05_*/search_fixed_seed_auto.txt): 4 flips of 139, the golden's LCB gaps 1.33 c (two searches of 200
+# visits whose candidates have 23-29 visits each), 0.29 c and 0.31 c - every one a tie the golden itself resolves by a fraction of a c.
+NEAR_TIE = 2.0
 
 
 @pytest.mark.parametrize("precision,limits", [
@@ -58,10 +62,12 @@ def test_fixed_seed_search_visit_counts_match_the_reference_golden(tmp_path, pre
     flips = st.pop("flips")
     print("runsearchtestsv8 on HIP (%s) vs the CUDA fp32 golden: %s" % (precision, {k: round(v, 4) for k, v in st.items()}))
     for fl in flips:
-        print("  flipped best move, search %(index)d (%(root_N)d visits): here %(a_top)s, golden %(b_top)s; the golden's margin over our move "
-              "%(gap_b).4f of its child visits, ours over the golden's %(gap_a).4f" % fl)
+        print("  flipped best move, search %(index)d (%(root_N)d visits): here %(a_top)s, golden %(b_top)s; LCB gap between the two candidates "
+              "%(lcb_gap_b)s c in the golden, %(lcb_gap_a)s c here; visit margins %(gap_b).4f / %(gap_a).4f of the child visits" % fl)
     keep = os.path.join(REPO, "gpurun_out")
     if os.path.isdir(keep):
+        with gzip.open(os.path.join(keep, "search_fixed_seed_%s_output.txt.gz" % precision), "wt") as f:
+            f.write(r.stdout)  # the search reports themselves, for the record
         with open(os.path.join(keep, "search_fixed_seed_%s.txt" % precision), "w") as f:
             f.write(repr(st) + "\n")
             for fl in flips:
@@ -69,11 +75,12 @@ def test_fixed_seed_search_visit_counts_match_the_reference_golden(tmp_path, pre
     assert st["searches"] >= limits["searches"]  # searches whose root visit count equals the golden's (the rest reuse a tree or the NN cache differently)
     assert st["same_best"] >= limits["same_best"], st
     # Round 5: the reference's own fp16 golden keeps the best move of its fp32 golden in every search
-    # (tests/test_search_golden.py). Here a handful flip, and each flip must be a NEAR-TIE in the golden itself: the golden's best move
-    # leads the move this backend prefers by less than `near_tie` of the child visits (and this backend's margin the other way is as
-    # small). A flip between two moves that the golden separates clearly is a different opinion of the net - a parity failure.
+    # (tests/test_search_golden.py). Here a handful flip, and each flip must be a NEAR-TIE in the golden itself and here: the two
+    # candidates' lower confidence bounds within `near_tie` c of each other. A flip between two moves that the golden separates clearly
+    # is a different opinion of the net - a parity failure.
     if "near_tie" in limits:
-        far = [fl for fl in flips if fl["gap_b"] > limits["near_tie"] or fl["gap_a"] > limits["near_tie"]]
+        # (here twice the golden's bound: the move this search put first has its LCB from this search's own, differently distributed visits)
+        far = [fl for fl in flips if fl["lcb_gap_b"] is None or fl["lcb_gap_a"] is None or fl["lcb_gap_b"] > limits["near_tie"] or fl["lcb_gap_a"] > 2 * limits["near_tie"]]
         assert not far, far
     for k in ("best_share_max", "best_share_mean", "tv_mean", "root_util_max", "root_util_mean"):
         assert st[k] <= limits[k], (k, st)
