@@ -372,10 +372,10 @@ double benchSeam(int batch, int iters, int timing) {
     hipCheck(hipMemcpy(h, dbg.get(), sizeof(h), hipMemcpyDeviceToHost), "copy timing");
     const char* k = getenv("KMX_PW_KERNEL");
     if(k == nullptr || atoi(k) == 3) {
-      for(int w = 0; w < 4; w++)  // pointwise3_kernel.h: four waves, six segments
-        fprintf(stderr, "[seam timing, resident weights] wave %d: top (requests, wait X, B1) %llu | gemm 1 %llu | epilogue 1 %llu | B2 %llu | gemm 2 %llu | "
-                        "epilogue 2 %llu | kernel %llu cycles\n",
-                w, h[w * 9 + 0], h[w * 9 + 1], h[w * 9 + 2], h[w * 9 + 3], h[w * 9 + 4], h[w * 9 + 5], h[w * 9 + 8]);
+      for(int w = 0; w < 4; w++)  // pointwise3_kernel.h: four waves; a block = matrix micro-steps of one GEMM half beside the values of an epilogue half
+        fprintf(stderr, "[seam timing, resident weights] wave %d: top (requests, wait X, BX) %llu | gemm1(0)+epi2'(1) %llu | gemm1(1)+epi1(0) %llu | BA0 %llu | "
+                        "gemm2(0)+epi1(1) %llu | BA1 %llu | gemm2(1)+epi2(0) %llu | tail epi2(1) %llu | kernel %llu cycles\n",
+                w, h[w * 9 + 0], h[w * 9 + 1], h[w * 9 + 2], h[w * 9 + 3], h[w * 9 + 4], h[w * 9 + 5], h[w * 9 + 6], h[w * 9 + 7], h[w * 9 + 8]);
     }
     else
     for(int w = 0; w < 8; w++)

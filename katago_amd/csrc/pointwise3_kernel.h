@@ -36,6 +36,7 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <utility>
 
 #include "device_common.h"
 
@@ -70,14 +71,21 @@ struct Geom {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
   static_assert(TM * 4 == NTHREADS, "one request round of the work-group fills exactly one chunk of the X tile");
   static_assert(WL_CHUNK == NWAVES * 1024, "one request round of the work-group fetches one chunk of the shared W2 rows");
-  // vector-memory operations per wave and tile, in program order
-  static constexpr int N_X = 1 + K1;              // mask + one request per chunk of X
-  static constexpr int N_R = NSUB * T1 * 2;       // residual loads (16 bytes per lane each)
-  static constexpr int N_S1 = NSUB * T1 * 2;      // stores of epilogue 1 (raw trunk)
-  static constexpr int N_S2 = (NSUB + 1) * 2 * 2; // stores of epilogue 2: (own tile on both sub-tiles + the shared one) x (raw, act) x 2 pieces
-  // at the wait for X(t): everything issued after its requests - the previous tile's residual loads and stores, then this tile's
-  // requests and residual loads
-  static constexpr int VM_AFTER_X = N_R + N_S1 + N_S2 + N_X + N_R;
+  // vector-memory operations per wave and tile, in program order (the kernel's blocks):
+  //   block 1  N_X requests for the next tile's X | N_RS residual loads of sub-tile 0 | (the wait for this tile's X) | the previous tile's
+  //            second epilogue of sub-tile 1: N_E2 stores, twice that on the waves whose shared mid tile sits on sub-tile 1, none in a
+  //            work-group's first tile
+  //   block 2  N_RS residual loads of sub-tile 1 | N_S1S raw-trunk stores of sub-tile 0      block 3  N_S1S raw-trunk stores of sub-tile 1
+  //   block 4  second epilogue of sub-tile 0: N_E2 stores, twice that on the waves whose shared mid tile sits on sub-tile 0
+  static constexpr int N_X = 1 + K1;     // mask + one request per chunk of X
+  static constexpr int N_RS = T1 * 2;    // residual loads of a sub-tile (16 bytes per lane each)
+  static constexpr int N_S1S = T1 * 2;   // stores of epilogue 1 per sub-tile
+  static constexpr int N_E2 = 2 * 2;     // stores of the second epilogue of one mid tile: (raw, act) x 2 pieces
+  // At the wait for X(t) (top of tile t; requested at the top of tile t - 1): the FEWEST operations that can have been issued after its
+  // requests - tile t - 1's residual loads and stores with a single N_E2 (a first tile on a wave whose shared tile sits on sub-tile 1),
+  // then this tile's requests and first residual loads. Waiting for more than necessary in the other cases costs nothing: the extra
+  // operations are the oldest of a whole tile ago.
+  static constexpr int VM_AFTER_X = N_RS + N_RS + N_S1S + N_S1S + N_E2 + N_X + N_RS;
   static_assert(VM_AFTER_X <= 63, "s_waitcnt vmcnt has six bits");
 };
 
@@ -155,8 +163,31 @@ __device__ __forceinline__ void mfmaSettle(f32x16& a0, f32x16& a1, f32x16& a2) {
 #endif
 }
 
-// TIMING (conv_bench.hip only): s_memtime stamps between the phases, summed per wave over the tiles of work-group 0 into a.dbg:
-// [0] tile top (requests, wait for X, barrier B1)  [1] GEMM 1  [2] epilogue 1  [3] barrier B2  [4] GEMM 2  [5] epilogue 2  [8] total
+// compile-time loops: f(integral_constant<int, 0>) .. f(integral_constant<int, N - 1>) - every index a constant expression, so register
+// arrays are indexed statically and `if constexpr` can pick a step's instructions
+template <int... I, class F>
+__device__ __forceinline__ void staticForImpl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>()), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void staticFor(F&& f) {
+  staticForImpl(std::make_integer_sequence<int, N>(), f);
+}
+// NM matrix micro-steps spread evenly over NV pieces of vector work, in source order [steps of piece 0] piece 0 [steps of piece 1] ...:
+// one wave per SIMD has nobody else to fill the matrix pipe while it does epilogue arithmetic, or the vector ALU while it multiplies -
+// an MFMA runs for 32 cycles after its issue slot, and the independent vector instructions behind it issue meanwhile
+template <int NM, int NV, class FM, class FV>
+__device__ __forceinline__ void interleave(FM&& fm, FV&& fv) {
+  staticFor<NV>([&](auto v) {
+    constexpr int V = decltype(v)::value, M0 = NM * V / NV, M1 = NM * (V + 1) / NV;
+    staticFor<M1 - M0>([&](auto m) { fm(std::integral_constant<int, M0 + decltype(m)::value>()); });
+    fv(v);
+  });
+}
+
+// TIMING (conv_bench.hip only): s_memtime stamps between the blocks, summed per wave over the tiles of work-group 0 into a.dbg:
+// [0] tile top (requests, wait for X, barrier BX)  [1] block 1  [2] block 2  [3] barrier BA0  [4] block 3  [5] barrier BA1  [6] block 4
+// [7] the last tile's trailing epilogue  [8] total
 template <class TR, int K1, int K2, int NT3, int KIND1, int KIND2, bool TIMING = false>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void pointwisePairResidentKernel(const PwPairArgs a) {
   typedef typename TR::T T;
@@ -178,7 +209,6 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
   T* const trash0 = (T*)((char*)const_cast<void*>(a.zeroPage) + ZERO_PAGE_BYTES);  // TRASH_BYTES of writable scratch
   const unsigned slack = ldsBase + G::SLACK_OFF;
   auto ldsV8 = [&](unsigned addr) { return *(const __attribute__((address_space(3))) V8*)(size_t)addr; };
-  auto ldsF4 = [&](unsigned addr) { return *(const __attribute__((address_space(3))) f32x4*)(size_t)addr; };
   auto ldsF1 = [&](unsigned addr) { return *(const __attribute__((address_space(3))) float*)(size_t)addr; };
 
   const long long numTiles = (a.cells + TM - 1) / TM;
@@ -262,7 +292,6 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
   unsigned p2Own = ldsBase + G::PARAM_OFF + 2 * G::C2 * 4 + (unsigned)(32 * wave + 4 * khalf) * 4u;
   unsigned p2Sh = ldsBase + G::PARAM_OFF + 2 * G::C2 * 4 + (unsigned)(32 * (NWAVES + (wave >> 1)) + 4 * khalf) * 4u;
   asm volatile("" : "+v"(p1Lane), "+v"(p2Own), "+v"(p2Sh));
-  const int shSub = wave & 1;  // the cell sub-tile on which this wave multiplies its shared mid tile (uniform)
 
   unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tPrev = TIMING ? __builtin_readcyclecounter() : 0;
@@ -274,179 +303,121 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
     tPrev = now;
   };
 
-  for(; tile < numTiles; tile += stride) {
-    const long long cell0 = tile * TM;
-    const bool hasNext = tile + stride < numTiles;  // uniform
-    const unsigned maskA = ldsBase + G::MASK_OFF + (unsigned)parity * (TM * 4);
-
-    // ---- top: the next tile's X into the other buffer (last read in GEMM 1 of the previous tile, before its barrier B2) ----
-    issueX(tile + stride, parity ^ 1, hasNext);
-    // residual pieces of this tile: 16 bytes per lane and request, the lane pair (c, c + 32) of sub-tile s loads channels
-    // 32 (T1 w + j) + 16 i + 8 h + [0, 8) of its cell; dead cells read the zero page
-    bool live[NSUB];
+  // The whole tile loop is instantiated for SH = 0 and 1 (the sub-tile on which this wave multiplies its shared mid tile) under ONE
+  // uniform branch: which MFMAs and which epilogue groups a block holds is then known at compile time.
+  auto run = [&](auto shTag) {
+    constexpr int SH = decltype(shTag)::value;
+    constexpr int NE2_0 = SH == 0 ? 32 : 16, NE2_1 = SH == 1 ? 32 : 16;  // second-epilogue values per lane of sub-tile 0 / 1: own mid tile (+ the shared one)
+    constexpr int NM1 = 2 * K1 * T1;                                    // MFMAs of GEMM 1 on one sub-tile
+    constexpr int NM2_0 = SH == 0 ? 4 * K2 : 2 * K2, NM2_1 = SH == 1 ? 4 * K2 : 2 * K2;  // ... of GEMM 2 on sub-tile 0 / 1
+    constexpr int NE1 = 16 * T1;                                        // first-epilogue values per lane of one sub-tile
+    f32x16 acc1[NSUB][T1], acc2[NSUB], accS;
     u32x4 rq[NSUB][T1][2];
-#pragma unroll
-    for(int s = 0; s < NSUB; s++) {
-      live[s] = cell0 + 32 * s + myPos < a.cells;  // the same for both lanes of a pair
-      const T* rrow = live[s] ? (const T*)a.resid + (size_t)(cell0 + 32 * s + myPos) * a.trunkC + 32 * T1 * wave + 8 * khalf : (const T*)zero;
-      asm volatile("" : "+v"(rrow));
-#pragma unroll
-      for(int j = 0; j < T1; j++)
-#pragma unroll
-        for(int i = 0; i < 2; i++) rq[s][j][i] = *(const GLOBAL u32x4*)(rrow + 32 * j + 16 * i);
-    }
-    // X(t), its mask (and, first tile, the shared W2 rows) have landed: in flight at most what was issued after them
-    waitVm<G::VM_AFTER_X>();
-    wgBarrier();  // B1: ... for every wave; and every wave is done with the previous tile's A2 image
-    unsigned onBits[NSUB];  // off-board cells of activated images are zero
-#pragma unroll
-    for(int s = 0; s < NSUB; s++) onBits[s] = ldsF1(maskA + (32 * s + myPos) * 4) == 1.0f ? 0xffffffffu : 0u;
-    stamp(0);
+    bool live[NSUB] = {false, false};
+    unsigned onBits[NSUB] = {0u, 0u};
+    // sub-tile 1 of the PREVIOUS tile: its second epilogue runs beside the first GEMM block of this tile
+    bool havePrev = false, prevLive1 = false;
+    unsigned prevOn1 = 0u;
+    long long prevCell0 = 0;
+    V8 xfA, wlF;  // the fragments of the next k-step (activations; the shared tile's weights), read one step ahead
+    u32x2 rp[4], op[4], resP[4];  // an epilogue tile in progress: its sixteen values fill them, the last regroups and stores
 
-    // ---- GEMM 1: this wave's T1 trunk tiles on both sub-tiles, K = C1 from X[parity]; weights from AGPRs ----
-    f32x16 acc1[NSUB][T1];
-    {
-      const unsigned xb = (unsigned)(G::X_OFF + parity * G::X_BUF);
-      V8 xf = ldsV8(xLane[0][0] + xb);
-#pragma unroll
-      for(int s = 0; s < NSUB; s++)
-#pragma unroll
-        for(int c = 0; c < K1; c++)
-#pragma unroll
-          for(int kk = 0; kk < 2; kk++) {
-            // the next fragment is read behind the first MFMA of this one (hipcc drains every LDS read before an asm that uses one)
-            const int nkk = kk ^ 1, nc = kk == 1 ? c + 1 : c, ns = nc == K1 ? s + 1 : s;
-            const bool more = ns < NSUB;
-            if(c == 0 && kk == 0) mfmaFirst<TR>(acc1[s][0], w1f[0][c][kk], xf);
-            else mfmaAcc<TR>(acc1[s][0], w1f[0][c][kk], xf);
-            V8 xn = xf;
-            if(more) xn = ldsV8(xLane[ns][nkk] + xb + (unsigned)((nc % K1) * G::CHUNK_BYTES));
-#pragma unroll
-            for(int j = 1; j < T1; j++) {
-              if(c == 0 && kk == 0) mfmaFirst<TR>(acc1[s][j], w1f[j][c][kk], xf);
-              else mfmaAcc<TR>(acc1[s][j], w1f[j][c][kk], xf);
-            }
-            xf = xn;
-          }
-    }
-    stamp(1);
-
-    // ---- epilogue 1: + residual, raw trunk -> HBM, activated -> the LDS image of GEMM 2 ----
-#pragma unroll
-    for(int s = 0; s < NSUB; s++) {
-      mfmaSettle(acc1[s][0], acc1[s][1], acc1[s][T1 - 1]);
-      T* rawRow = live[s] ? (T*)a.rawOut + (size_t)(cell0 + 32 * s + myPos) * a.trunkC + 32 * T1 * wave + 8 * khalf : trash0;
-      asm volatile("" : "+v"(rawRow));
-#pragma unroll
-      for(int j = 0; j < T1; j++) {
-        u32x2 rp[4], op[4], resP[4];
-        unpair(rq[s][j], resP);
-#pragma unroll
-        for(int g = 0; g < 4; g++) {
-          const f32x4 sc = ldsF4(p1Lane + (unsigned)((32 * j + 8 * g) * 4));
-          const f32x4 bi = ldsF4(p1Lane + (unsigned)(G::C2 * 4 + (32 * j + 8 * g) * 4));
-          V4 r, o;
-          const V4 rr = __builtin_bit_cast(V4, resP[g]);
-#pragma unroll
-          for(int i = 0; i < 4; i += 2) {
-            const float v0 = acc1[s][j][4 * g + i] + TR::toFloat(rr[i]), v1 = acc1[s][j][4 * g + i + 1] + TR::toFloat(rr[i + 1]);
-            r[i] = TR::fromFloat(v0);
-            r[i + 1] = TR::fromFloat(v1);
-            f32x2 x;
-            x[0] = v0 * sc[i] + bi[i];
-            x[1] = v1 * sc[i + 1] + bi[i + 1];
-            const f32x2 y = actK2<KIND1>(x);
-            o[i] = TR::fromFloat(y[0]);
-            o[i + 1] = TR::fromFloat(y[1]);
-          }
-          rp[g] = __builtin_bit_cast(u32x2, r);
-          op[g] = __builtin_bit_cast(u32x2, o);
-          op[g][0] &= onBits[s];
-          op[g][1] &= onBits[s];
+    // ---- matrix micro-steps: ONE MFMA each (a k-step I = 2 chunk + k half is T1 of them in GEMM 1, one or two in GEMM 2); the fragment
+    // of the next k-step is read behind the first MFMA of this one (hipcc drains every LDS read before an asm that uses one) ----
+    V8 xfN, wlN;
+    auto g1Micro = [&](auto sTag, auto mTag, unsigned xb) {  // GEMM 1 on sub-tile S: this wave's T1 trunk tiles, weights from AGPRs
+      constexpr int S = decltype(sTag)::value, M = decltype(mTag)::value, I = M / T1, J = M % T1, C = I >> 1, KK = I & 1;
+      if constexpr(I == 0) mfmaFirst<TR>(acc1[S][J], w1f[J][C][KK], xfA);
+      else mfmaAcc<TR>(acc1[S][J], w1f[J][C][KK], xfA);
+      if constexpr(J == 0) {
+        xfN = xfA;
+        if constexpr(I + 1 < 2 * K1) xfN = ldsV8(xLane[S][(I + 1) & 1] + xb + (unsigned)(((I + 1) >> 1) * G::CHUNK_BYTES));
+      }
+      if constexpr(J == T1 - 1) xfA = xfN;
+    };
+    // GEMM 2 on sub-tile S: the own mid tile (AGPRs) and, on sub-tile SH, the shared one (LDS): NM2(S) micro-steps
+    auto g2Micro = [&](auto sTag, auto mTag) {
+      constexpr int S = decltype(sTag)::value, M = decltype(mTag)::value;
+      constexpr bool BOTH = S == SH;
+      constexpr int I = BOTH ? M / 2 : M, PART = BOTH ? M % 2 : 0, C = I >> 1, KK = I & 1;
+      if constexpr(PART == 0) {
+        if constexpr(I == 0) mfmaFirst<TR>(acc2[S], w2f[C][KK], xfA);
+        else mfmaAcc<TR>(acc2[S], w2f[C][KK], xfA);
+        xfN = xfA;
+        wlN = wlF;
+        if constexpr(I + 1 < 2 * K2) {
+          xfN = ldsV8(xLane[S][(I + 1) & 1] + (unsigned)(G::A2_OFF + ((I + 1) >> 1) * G::CHUNK_BYTES));
+          if constexpr(BOTH) wlN = ldsV8(wlLane[(I + 1) & 1] + (unsigned)(((I + 1) >> 1) * G::WL_CHUNK));
         }
+        if constexpr(!BOTH) xfA = xfN;
+      }
+      else {
+        if constexpr(I == 0) mfmaFirstV<TR>(accS, wlF, xfA);
+        else mfmaAccV<TR>(accS, wlF, xfA);
+        xfA = xfN;
+        wlF = wlN;
+      }
+    };
+    // ---- vector pieces: ONE value per lane each (group GR = four consecutive channels of the lane's cell, value I of it; values 2 H and
+    // 2 H + 1 share dword H of the group's packed 16-bit results, and their parameters come as one 8-byte LDS read) ----
+    auto ldsF2 = [&](unsigned addr) { return *(const __attribute__((address_space(3))) f32x2*)(size_t)addr; };
+    auto pack2 = [&](T lo, T hi) {
+      V4 t;
+      t[0] = lo; t[1] = hi; t[2] = lo; t[3] = hi;
+      return __builtin_bit_cast(u32x2, t)[0];
+    };
+    f32x2 sc2, bi2;   // parameters of the value pair in progress
+    T pendR, pendO;   // the pair's low value, waiting for its partner
+    // epilogue 1, value Q = 16 j + 4 g + i of sub-tile S: + residual, raw trunk -> HBM, activated -> the LDS image of GEMM 2
+    auto e1Val = [&](auto sTag, auto qTag, T* rawRow) {
+      constexpr int S = decltype(sTag)::value, Q = decltype(qTag)::value, J = Q >> 4, GR = (Q >> 2) & 3, I = Q & 3, H = I >> 1;
+      if constexpr((Q & 15) == 0) unpair(rq[S][J], resP);
+      if constexpr((I & 1) == 0) {
+        sc2 = ldsF2(p1Lane + (unsigned)((32 * J + 8 * GR + I) * 4));
+        bi2 = ldsF2(p1Lane + (unsigned)(G::C2 * 4 + (32 * J + 8 * GR + I) * 4));
+      }
+      const V4 rr = __builtin_bit_cast(V4, resP[GR]);
+      const float v = acc1[S][J][4 * GR + I] + TR::toFloat(rr[I]);
+      const float x = v * sc2[I & 1] + bi2[I & 1];
+      const T r = TR::fromFloat(v), o = TR::fromFloat(actK<KIND1>(x));
+      if constexpr((I & 1) == 0) {
+        pendR = r;
+        pendO = o;
+      }
+      else {
+        rp[GR][H] = pack2(pendR, r);
+        op[GR][H] = pack2(pendO, o) & onBits[S];
+      }
+      if constexpr((Q & 15) == 15) {
         u32x4 rawQ[2], oq[2];
-        pairUp(rp, rawQ);  // this lane now holds channels 32 (T1 w + j) + 16 i + 8 h + [0, 8)
+        pairUp(rp, rawQ);  // this lane now holds channels 32 (T1 w + J) + 16 i + 8 h + [0, 8)
         pairUp(op, oq);
 #pragma unroll
-        for(int i = 0; i < 2; i++) *(GLOBAL u32x4*)(rawRow + 32 * j + 16 * i) = rawQ[i];
+        for(int i = 0; i < 2; i++) *(GLOBAL u32x4*)(rawRow + 32 * J + 16 * i) = rawQ[i];
 #pragma unroll
-        for(int i = 0; i < 2; i++)  // image layout: chunk T1 w + j, this lane's row, logical 16-byte slot 2 i + h
-          *(__attribute__((address_space(3))) u32x4*)(size_t)(a2wLane[s][i] + (unsigned)((T1 * wave + j) * G::CHUNK_BYTES)) = oq[i];
+        for(int i = 0; i < 2; i++)  // image layout: chunk T1 w + J, this lane's row, logical 16-byte slot 2 i + h
+          *(__attribute__((address_space(3))) u32x4*)(size_t)(a2wLane[S][i] + (unsigned)((T1 * wave + J) * G::CHUNK_BYTES)) = oq[i];
       }
-    }
-    stamp(2);
-    waitLds();    // the image is read by the other waves after the barrier
-    wgBarrier();  // B2: the activated image is whole; every wave is done with X[parity]
-    stamp(3);
-
-    // ---- GEMM 2: own mid tile (weights in AGPRs) on both sub-tiles, the shared tile (weights in LDS) on sub-tile SH; K = C2 ----
-    // ---- epilogue 2: mid raw and activated -> HBM (N_S2 unconditional stores) ----
-    // (instantiated for SH = 0 and 1 under a uniform branch: the fragment the shared tile multiplies is then a register the step has
-    // anyway - no select on the vector ALU in front of an MFMA, no second LDS read)
-    auto phase2 = [&](auto shTag) {
-      constexpr int SH = decltype(shTag)::value;
-      f32x16 acc2[NSUB], accS;
-      {
-        V8 xf[NSUB], wl;
-#pragma unroll
-        for(int s = 0; s < NSUB; s++) xf[s] = ldsV8(xLane[s][0] + (unsigned)G::A2_OFF);
-        wl = ldsV8(wlLane[0]);
-#pragma unroll
-        for(int c = 0; c < K2; c++)
-#pragma unroll
-          for(int kk = 0; kk < 2; kk++) {
-            const int nkk = kk ^ 1, nc = kk == 1 ? c + 1 : c;
-            const bool more = nc < K2;
-            const bool first = c == 0 && kk == 0;
-            if(first) mfmaFirst<TR>(acc2[0], w2f[c][kk], xf[0]);
-            else mfmaAcc<TR>(acc2[0], w2f[c][kk], xf[0]);
-            // the next step's fragments are read behind the first MFMA of this one (hipcc drains every LDS read before an asm that uses one)
-            V8 xn[NSUB], wn = wl;
-#pragma unroll
-            for(int s = 0; s < NSUB; s++) xn[s] = xf[s];
-            if(more) {
-#pragma unroll
-              for(int s = 0; s < NSUB; s++) xn[s] = ldsV8(xLane[s][nkk] + (unsigned)(G::A2_OFF + nc * G::CHUNK_BYTES));
-              wn = ldsV8(wlLane[nkk] + (unsigned)(nc * G::WL_CHUNK));
-            }
-            if(first) mfmaFirst<TR>(acc2[1], w2f[c][kk], xf[1]);
-            else mfmaAcc<TR>(acc2[1], w2f[c][kk], xf[1]);
-            if(first) mfmaFirstV<TR>(accS, wl, xf[SH]);
-            else mfmaAccV<TR>(accS, wl, xf[SH]);
-#pragma unroll
-            for(int s = 0; s < NSUB; s++) xf[s] = xn[s];
-            wl = wn;
-          }
+    };
+    // epilogue 2, value Q = 4 g + i of one mid tile: mid raw and activated -> HBM
+    auto e2Val = [&](const f32x16& acc, unsigned pLane, T* rawRow2, T* actRow2, unsigned on, auto qTag) {
+      constexpr int Q = decltype(qTag)::value, GR = Q >> 2, I = Q & 3, H = I >> 1;
+      if constexpr((I & 1) == 0) {
+        sc2 = ldsF2(pLane + (unsigned)((8 * GR + I) * 4));
+        bi2 = ldsF2(pLane + (unsigned)(G::C3 * 4 + (8 * GR + I) * 4));
       }
-      stamp(4);
-      mfmaSettle(acc2[0], acc2[1], accS);
-      auto epi2 = [&](const f32x16& acc, unsigned pLane, int s, int chOff) {
-        T* rawRow2 = live[s] ? (T*)a.rawOut2 + (size_t)(cell0 + 32 * s + myPos) * a.midC + chOff + 8 * khalf : trash0;
-        T* actRow2 = live[s] ? (T*)a.actOut2 + (size_t)(cell0 + 32 * s + myPos) * a.midC + chOff + 8 * khalf : trash0;
-        asm volatile("" : "+v"(rawRow2), "+v"(actRow2));
-        u32x2 rp[4], op[4];
-#pragma unroll
-        for(int g = 0; g < 4; g++) {
-          const f32x4 sc = ldsF4(pLane + (unsigned)(8 * g * 4));
-          const f32x4 bi = ldsF4(pLane + (unsigned)(G::C3 * 4 + 8 * g * 4));
-          V4 r, o;
-#pragma unroll
-          for(int i = 0; i < 4; i += 2) {
-            const float v0 = acc[4 * g + i], v1 = acc[4 * g + i + 1];
-            r[i] = TR::fromFloat(v0);
-            r[i + 1] = TR::fromFloat(v1);
-            f32x2 x;
-            x[0] = v0 * sc[i] + bi[i];
-            x[1] = v1 * sc[i + 1] + bi[i + 1];
-            const f32x2 y = actK2<KIND2>(x);
-            o[i] = TR::fromFloat(y[0]);
-            o[i + 1] = TR::fromFloat(y[1]);
-          }
-          rp[g] = __builtin_bit_cast(u32x2, r);
-          op[g] = __builtin_bit_cast(u32x2, o);
-          op[g][0] &= onBits[s];
-          op[g][1] &= onBits[s];
-        }
+      const float v = acc[4 * GR + I];
+      const float x = v * sc2[I & 1] + bi2[I & 1];
+      const T r = TR::fromFloat(v), o = TR::fromFloat(actK<KIND2>(x));
+      if constexpr((I & 1) == 0) {
+        pendR = r;
+        pendO = o;
+      }
+      else {
+        rp[GR][H] = pack2(pendR, r);
+        op[GR][H] = pack2(pendO, o) & on;
+      }
+      if constexpr(Q == 15) {
         u32x4 rawQ[2], oq[2];
         pairUp(rp, rawQ);
         pairUp(op, oq);
@@ -455,16 +426,119 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
           *(GLOBAL u32x4*)(rawRow2 + 16 * i) = rawQ[i];
           *(GLOBAL u32x4*)(actRow2 + 16 * i) = oq[i];
         }
-      };
-#pragma unroll
-      for(int s = 0; s < NSUB; s++) epi2(acc2[s], p2Own, s, 32 * wave);
-      epi2(accS, p2Sh, SH, 32 * (NWAVES + (wave >> 1)));
+      }
     };
-    if(shSub) phase2(ActKindTag<1>());
-    else phase2(ActKindTag<0>());
-    stamp(5);
-    parity ^= 1;
-  }
+    // the values of sub-tile S's second epilogue: 0..15 the own mid tile, 16..31 the shared one (sub-tile SH only)
+    auto e2Step = [&](auto sTag, auto vTag, T* rawOwn, T* actOwn, T* rawSh, T* actSh, unsigned on) {
+      constexpr int S = decltype(sTag)::value, V = decltype(vTag)::value;
+      if constexpr(V < 16) e2Val(acc2[S], p2Own, rawOwn, actOwn, on, std::integral_constant<int, V>());
+      else e2Val(accS, p2Sh, rawSh, actSh, on, std::integral_constant<int, V - 16>());
+    };
+    auto rows2 = [&](bool liveS, long long cellBase, int s, T*& rawOwn, T*& actOwn, T*& rawSh, T*& actSh) {
+      const size_t row = (size_t)(cellBase + 32 * s + myPos) * a.midC + 8 * khalf;
+      rawOwn = liveS ? (T*)a.rawOut2 + row + 32 * wave : trash0;
+      actOwn = liveS ? (T*)a.actOut2 + row + 32 * wave : trash0;
+      rawSh = liveS ? (T*)a.rawOut2 + row + 32 * (NWAVES + (wave >> 1)) : trash0;
+      actSh = liveS ? (T*)a.actOut2 + row + 32 * (NWAVES + (wave >> 1)) : trash0;
+      asm volatile("" : "+v"(rawOwn), "+v"(actOwn), "+v"(rawSh), "+v"(actSh));
+    };
+    auto loadResid = [&](auto sTag, long long cell0) {
+      constexpr int S = decltype(sTag)::value;
+      // 16 bytes per lane and request: the lane pair (c, c + 32) of sub-tile S loads channels 32 (T1 w + j) + 16 i + 8 h + [0, 8) of its
+      // cell; dead cells read the zero page
+      const T* rrow = live[S] ? (const T*)a.resid + (size_t)(cell0 + 32 * S + myPos) * a.trunkC + 32 * T1 * wave + 8 * khalf : (const T*)zero;
+      asm volatile("" : "+v"(rrow));
+#pragma unroll
+      for(int j = 0; j < T1; j++)
+#pragma unroll
+        for(int i = 0; i < 2; i++) rq[S][j][i] = *(const GLOBAL u32x4*)(rrow + 32 * j + 16 * i);
+    };
+    constexpr std::integral_constant<int, 0> S0{};
+    constexpr std::integral_constant<int, 1> S1{};
+
+    for(; tile < numTiles; tile += stride) {
+      const long long cell0 = tile * TM;
+      const bool hasNext = tile + stride < numTiles;  // uniform
+      const unsigned maskA = ldsBase + G::MASK_OFF + (unsigned)parity * (TM * 4);
+      const unsigned xb = (unsigned)(G::X_OFF + parity * G::X_BUF);
+
+      // ---- block 1: GEMM 1 of sub-tile 0 | the previous tile's second epilogue of sub-tile 1 ----
+      // the next tile's X into the other buffer (last read in GEMM 1 of the previous tile, before that tile's barriers)
+      issueX(tile + stride, parity ^ 1, hasNext);
+#pragma unroll
+      for(int s = 0; s < NSUB; s++) live[s] = cell0 + 32 * s + myPos < a.cells;  // the same for both lanes of a pair
+      loadResid(S0, cell0);
+      // X(t), its mask (first tile: the shared W2 rows too) have landed: in flight at most what was issued after them (VM_AFTER_X)
+      waitVm<G::VM_AFTER_X>();
+      wgBarrier();  // BX: ... for every wave
+#pragma unroll
+      for(int s = 0; s < NSUB; s++) onBits[s] = ldsF1(maskA + (32 * s + myPos) * 4) == 1.0f ? 0xffffffffu : 0u;  // off-board cells of activated images are zero
+      stamp(0);
+      xfA = ldsV8(xLane[0][0] + xb);
+      if(havePrev) {
+        T *rawOwn, *actOwn, *rawSh, *actSh;
+        rows2(prevLive1, prevCell0, 1, rawOwn, actOwn, rawSh, actSh);
+        mfmaSettle(acc2[1], accS, accS);
+        interleave<NM1, NE2_1>([&](auto m) { g1Micro(S0, m, xb); }, [&](auto v) { e2Step(S1, v, rawOwn, actOwn, rawSh, actSh, prevOn1); });
+      }
+      else staticFor<NM1>([&](auto m) { g1Micro(S0, m, xb); });
+      stamp(1);
+
+      // ---- block 2: GEMM 1 of sub-tile 1 | epilogue 1 of sub-tile 0 ----
+      loadResid(S1, cell0);
+      {
+        T* rawRow = live[0] ? (T*)a.rawOut + (size_t)(cell0 + myPos) * a.trunkC + 32 * T1 * wave + 8 * khalf : trash0;
+        asm volatile("" : "+v"(rawRow));
+        mfmaSettle(acc1[0][0], acc1[0][1], acc1[0][2]);
+        xfA = ldsV8(xLane[1][0] + xb);
+        interleave<NM1, NE1>([&](auto m) { g1Micro(S1, m, xb); }, [&](auto v) { e1Val(S0, v, rawRow); });
+      }
+      stamp(2);
+      waitLds();    // the image rows are read by the other waves after the barrier
+      wgBarrier();  // BA0: the activated image of sub-tile 0 is whole; every wave is done with X[parity]
+      stamp(3);
+
+      // ---- block 3: GEMM 2 of sub-tile 0 | epilogue 1 of sub-tile 1 ----
+      {
+        T* rawRow = live[1] ? (T*)a.rawOut + (size_t)(cell0 + 32 + myPos) * a.trunkC + 32 * T1 * wave + 8 * khalf : trash0;
+        asm volatile("" : "+v"(rawRow));
+        mfmaSettle(acc1[1][0], acc1[1][1], acc1[1][2]);
+        xfA = ldsV8(xLane[0][0] + (unsigned)G::A2_OFF);
+        if constexpr(SH == 0) wlF = ldsV8(wlLane[0]);
+        interleave<NM2_0, NE1>([&](auto m) { g2Micro(S0, m); }, [&](auto v) { e1Val(S1, v, rawRow); });
+      }
+      stamp(4);
+      waitLds();
+      wgBarrier();  // BA1: ... of sub-tile 1
+      stamp(5);
+
+      // ---- block 4: GEMM 2 of sub-tile 1 | epilogue 2 of sub-tile 0 ----
+      {
+        T *rawOwn, *actOwn, *rawSh, *actSh;
+        rows2(live[0], cell0, 0, rawOwn, actOwn, rawSh, actSh);
+        mfmaSettle(acc2[0], accS, accS);
+        xfA = ldsV8(xLane[1][0] + (unsigned)G::A2_OFF);
+        if constexpr(SH == 1) wlF = ldsV8(wlLane[0]);
+        interleave<NM2_1, NE2_0>([&](auto m) { g2Micro(S1, m); }, [&](auto v) { e2Step(S0, v, rawOwn, actOwn, rawSh, actSh, onBits[0]); });
+      }
+      stamp(6);
+      havePrev = true;
+      prevLive1 = live[1];
+      prevOn1 = onBits[1];
+      prevCell0 = cell0;
+      parity ^= 1;
+    }
+    // the last tile's second epilogue of sub-tile 1
+    if(havePrev) {
+      T *rawOwn, *actOwn, *rawSh, *actSh;
+      rows2(prevLive1, prevCell0, 1, rawOwn, actOwn, rawSh, actSh);
+      mfmaSettle(acc2[1], accS, accS);
+      staticFor<NE2_1>([&](auto v) { e2Step(S1, v, rawOwn, actOwn, rawSh, actSh, prevOn1); });
+    }
+    stamp(7);
+  };
+  if(wave & 1) run(std::integral_constant<int, 1>());
+  else run(std::integral_constant<int, 0>());
   waitVm<0>();  // trailing requests into the slack area must land before the LDS is released
   if(TIMING && a.dbg != nullptr && lane == 0 && blockIdx.x == 0) {
     for(int i = 0; i < 8; i++) a.dbg[wave * 9 + i] = seg[i];

@@ -101,15 +101,15 @@ PW2_REWRITES = [
 PW3_REWRITES = [
     (r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\(N\) : "memory"\);', "emu::waitVm(N);", 1),
     (r'asm volatile\("s_waitcnt lgkmcnt\(0\)" ::: "memory"\);', ";", 1),
-    (r'for\(int i = 0; i < 2; i\+\+\) rq\[s\]\[j\]\[i\] = \*\(const GLOBAL u32x4\*\)\(rrow \+ 32 \* j \+ 16 \* i\);',
-     "for(int i = 0; i < 2; i++) { rq[s][j][i] = *(const GLOBAL u32x4*)(rrow + 32 * j + 16 * i); emu::vmNote(); }", 1),
-    (r'for\(int i = 0; i < 2; i\+\+\) \*\(GLOBAL u32x4\*\)\(rawRow \+ 32 \* j \+ 16 \* i\) = rawQ\[i\];',
-     "for(int i = 0; i < 2; i++) { *(GLOBAL u32x4*)(rawRow + 32 * j + 16 * i) = rawQ[i]; emu::vmNote(); }", 1),
+    (r'for\(int i = 0; i < 2; i\+\+\) rq\[S\]\[j\]\[i\] = \*\(const GLOBAL u32x4\*\)\(rrow \+ 32 \* j \+ 16 \* i\);',
+     "for(int i = 0; i < 2; i++) { rq[S][j][i] = *(const GLOBAL u32x4*)(rrow + 32 * j + 16 * i); emu::vmNote(); }", 1),
+    (r'for\(int i = 0; i < 2; i\+\+\) \*\(GLOBAL u32x4\*\)\(rawRow \+ 32 \* J \+ 16 \* i\) = rawQ\[i\];',
+     "for(int i = 0; i < 2; i++) { *(GLOBAL u32x4*)(rawRow + 32 * J + 16 * i) = rawQ[i]; emu::vmNote(); }", 1),
     (r'\*\(GLOBAL u32x4\*\)\(rawRow2 \+ 16 \* i\) = rawQ\[i\];', "*(GLOBAL u32x4*)(rawRow2 + 16 * i) = rawQ[i]; emu::vmNote();", 1),
     (r'\*\(GLOBAL u32x4\*\)\(actRow2 \+ 16 \* i\) = oq\[i\];', "*(GLOBAL u32x4*)(actRow2 + 16 * i) = oq[i]; emu::vmNote();", 1),
     (r'w1f\[j\]\[c\]\[kk\] = (\*\(const V8\*\)[^;]*;)', r"{ w1f[j][c][kk] = \1 emu::vmNote(); }", 1),
     (r'w2f\[c\]\[kk\] = (\*\(const V8\*\)[^;]*;)', r"{ w2f[c][kk] = \1 emu::vmNote(); }", 1),
-    (r'asm volatile\("" : "\+v"\([^;]*\);', ";", 6),
+    (r'asm volatile\("" : "\+v"\([^;]*\);', ";", 7),
     (r'extern __shared__ __attribute__\(\(aligned\(256\)\)\) char smemPw3\[\];', "char* const smemPw3 = (char*)emu::dynLds();", 1),
     (r'__builtin_amdgcn_global_load_lds\(', "emu::globalLoadLds(", 2),
     (r'__attribute__\(\(amdgpu_waves_per_eu\(1, 1\)\)\)', "", 1),

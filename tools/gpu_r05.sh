@@ -35,6 +35,10 @@ parity)
   KMX_BENCH_SELFPLAY_TIMEOUT=0 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
   tail -c 3000 $OUT/bench.json
   ;;
+search)
+  timeout 900 python -m pytest "tests/test_gpu_search_fixed_seed.py" -m gpu -q -p no:cacheprovider -s 2>&1 | grep -v "^$" | tail -30 | tee $OUT/pytest.log
+  cp gpurun_out/search_fixed_seed_*.txt gpurun_out/search_fixed_seed_*_output.txt.gz $OUT/ 2>/dev/null
+  ;;
 small)
   timeout 300 python tools/small_batch_scan.py 2>&1 | grep SCAN | tee $OUT/small_batch_scan.txt
   for n in 1 8 16 24 32 42 64; do b $OUT "b18 device-resident batch $n" A=1 -- --batch $n --steps 60 --warmup 10 --no-profile; done
