@@ -182,6 +182,7 @@ __device__ __forceinline__ void interleave(FM&& fm, FV&& fv) {
     constexpr int V = decltype(v)::value, M0 = NM * V / NV, M1 = NM * (V + 1) / NV;
     staticFor<M1 - M0>([&](auto m) { fm(std::integral_constant<int, M0 + decltype(m)::value>()); });
     fv(v);
+    __builtin_amdgcn_sched_barrier(0);  // pieces stay in source order: the scheduler would otherwise cluster the matrix steps
   });
 }
 
@@ -334,6 +335,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
         if constexpr(I + 1 < 2 * K1) xfN = ldsV8(xLane[S][(I + 1) & 1] + xb + (unsigned)(((I + 1) >> 1) * G::CHUNK_BYTES));
       }
       if constexpr(J == T1 - 1) xfA = xfN;
+      __builtin_amdgcn_sched_barrier(0);  // the read stays HERE, a k-step ahead of its use (left alone, hipcc sinks it to just before that MFMA)
     };
     // GEMM 2 on sub-tile S: the own mid tile (AGPRs) and, on sub-tile SH, the shared one (LDS): NM2(S) micro-steps
     auto g2Micro = [&](auto sTag, auto mTag) {
@@ -357,6 +359,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
         xfA = xfN;
         wlF = wlN;
       }
+      __builtin_amdgcn_sched_barrier(0);
     };
     // ---- vector pieces: ONE value per lane each (group GR = four consecutive channels of the lane's cell, value I of it; values 2 H and
     // 2 H + 1 share dword H of the group's packed 16-bit results, and their parameters come as one 8-byte LDS read) ----
@@ -367,14 +370,21 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
       return __builtin_bit_cast(u32x2, t)[0];
     };
     f32x2 sc2, bi2;   // parameters of the value pair in progress
+    f32x2 scN, biN;   // ... of the next pair: read a pair ahead (one wave per SIMD has nobody to cover an LDS round trip)
     T pendR, pendO;   // the pair's low value, waiting for its partner
+    constexpr auto e1ParamOff = [](int q) { return (32 * (q >> 4) + 8 * ((q >> 2) & 3) + (q & 3)) * 4; };
     // epilogue 1, value Q = 16 j + 4 g + i of sub-tile S: + residual, raw trunk -> HBM, activated -> the LDS image of GEMM 2
     auto e1Val = [&](auto sTag, auto qTag, T* rawRow) {
       constexpr int S = decltype(sTag)::value, Q = decltype(qTag)::value, J = Q >> 4, GR = (Q >> 2) & 3, I = Q & 3, H = I >> 1;
       if constexpr((Q & 15) == 0) unpair(rq[S][J], resP);
       if constexpr((I & 1) == 0) {
-        sc2 = ldsF2(p1Lane + (unsigned)((32 * J + 8 * GR + I) * 4));
-        bi2 = ldsF2(p1Lane + (unsigned)(G::C2 * 4 + (32 * J + 8 * GR + I) * 4));
+        sc2 = scN;
+        bi2 = biN;
+        if constexpr(Q + 2 < 16 * T1) {
+          scN = ldsF2(p1Lane + (unsigned)e1ParamOff(Q + 2));
+          biN = ldsF2(p1Lane + (unsigned)(G::C2 * 4 + e1ParamOff(Q + 2)));
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
       const V4 rr = __builtin_bit_cast(V4, resP[GR]);
       const float v = acc1[S][J][4 * GR + I] + TR::toFloat(rr[I]);
@@ -399,14 +409,24 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
           *(__attribute__((address_space(3))) u32x4*)(size_t)(a2wLane[S][i] + (unsigned)((T1 * wave + J) * G::CHUNK_BYTES)) = oq[i];
       }
     };
-    // epilogue 2, value Q = 4 g + i of one mid tile: mid raw and activated -> HBM
-    auto e2Val = [&](const f32x16& acc, unsigned pLane, T* rawRow2, T* actRow2, unsigned on, auto qTag) {
-      constexpr int Q = decltype(qTag)::value, GR = Q >> 2, I = Q & 3, H = I >> 1;
+    // epilogue 2, value V of sub-tile S: values 0..15 the own mid tile, 16..31 the shared one (sub-tile SH only): mid raw and activated -> HBM
+    auto e2Step = [&](auto sTag, auto vTag, T* rawOwn, T* actOwn, T* rawSh, T* actSh, unsigned on) {
+      constexpr int S = decltype(sTag)::value, V = decltype(vTag)::value, NV = S == 0 ? NE2_0 : NE2_1;
+      constexpr int TILE = V >> 4, Q = V & 15, GR = Q >> 2, I = Q & 3, H = I >> 1;
       if constexpr((I & 1) == 0) {
-        sc2 = ldsF2(pLane + (unsigned)((8 * GR + I) * 4));
-        bi2 = ldsF2(pLane + (unsigned)(G::C3 * 4 + (8 * GR + I) * 4));
+        sc2 = scN;
+        bi2 = biN;
+        if constexpr(V + 2 < NV) {
+          constexpr int Q2 = (V + 2) & 15;
+          const unsigned pl = ((V + 2) >> 4) ? p2Sh : p2Own;
+          scN = ldsF2(pl + (unsigned)((8 * (Q2 >> 2) + (Q2 & 3)) * 4));
+          biN = ldsF2(pl + (unsigned)(G::C3 * 4 + (8 * (Q2 >> 2) + (Q2 & 3)) * 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      const float v = acc[4 * GR + I];
+      float v;
+      if constexpr(TILE == 0) v = acc2[S][4 * GR + I];
+      else v = accS[4 * GR + I];
       const float x = v * sc2[I & 1] + bi2[I & 1];
       const T r = TR::fromFloat(v), o = TR::fromFloat(actK<KIND2>(x));
       if constexpr((I & 1) == 0) {
@@ -418,6 +438,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
         op[GR][H] = pack2(pendO, o) & on;
       }
       if constexpr(Q == 15) {
+        T* const rawRow2 = TILE ? rawSh : rawOwn;
+        T* const actRow2 = TILE ? actSh : actOwn;
         u32x4 rawQ[2], oq[2];
         pairUp(rp, rawQ);
         pairUp(op, oq);
@@ -428,11 +450,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
         }
       }
     };
-    // the values of sub-tile S's second epilogue: 0..15 the own mid tile, 16..31 the shared one (sub-tile SH only)
-    auto e2Step = [&](auto sTag, auto vTag, T* rawOwn, T* actOwn, T* rawSh, T* actSh, unsigned on) {
-      constexpr int S = decltype(sTag)::value, V = decltype(vTag)::value;
-      if constexpr(V < 16) e2Val(acc2[S], p2Own, rawOwn, actOwn, on, std::integral_constant<int, V>());
-      else e2Val(accS, p2Sh, rawSh, actSh, on, std::integral_constant<int, V - 16>());
+    auto e2Params = [&]() {  // the first pair's parameters, ahead of a second-epilogue block
+      scN = ldsF2(p2Own);
+      biN = ldsF2(p2Own + (unsigned)(G::C3 * 4));
+    };
+    auto e1Params = [&]() {
+      scN = ldsF2(p1Lane);
+      biN = ldsF2(p1Lane + (unsigned)(G::C2 * 4));
     };
     auto rows2 = [&](bool liveS, long long cellBase, int s, T*& rawOwn, T*& actOwn, T*& rawSh, T*& actSh) {
       const size_t row = (size_t)(cellBase + 32 * s + myPos) * a.midC + 8 * khalf;
@@ -479,6 +503,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
         T *rawOwn, *actOwn, *rawSh, *actSh;
         rows2(prevLive1, prevCell0, 1, rawOwn, actOwn, rawSh, actSh);
         mfmaSettle(acc2[1], accS, accS);
+        e2Params();
         interleave<NM1, NE2_1>([&](auto m) { g1Micro(S0, m, xb); }, [&](auto v) { e2Step(S1, v, rawOwn, actOwn, rawSh, actSh, prevOn1); });
       }
       else staticFor<NM1>([&](auto m) { g1Micro(S0, m, xb); });
@@ -491,6 +516,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
         asm volatile("" : "+v"(rawRow));
         mfmaSettle(acc1[0][0], acc1[0][1], acc1[0][2]);
         xfA = ldsV8(xLane[1][0] + xb);
+        e1Params();
         interleave<NM1, NE1>([&](auto m) { g1Micro(S1, m, xb); }, [&](auto v) { e1Val(S0, v, rawRow); });
       }
       stamp(2);
@@ -505,6 +531,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
         mfmaSettle(acc1[1][0], acc1[1][1], acc1[1][2]);
         xfA = ldsV8(xLane[0][0] + (unsigned)G::A2_OFF);
         if constexpr(SH == 0) wlF = ldsV8(wlLane[0]);
+        e1Params();
         interleave<NM2_0, NE1>([&](auto m) { g2Micro(S0, m); }, [&](auto v) { e1Val(S1, v, rawRow); });
       }
       stamp(4);
@@ -519,6 +546,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
         mfmaSettle(acc2[0], accS, accS);
         xfA = ldsV8(xLane[1][0] + (unsigned)G::A2_OFF);
         if constexpr(SH == 1) wlF = ldsV8(wlLane[0]);
+        e2Params();
         interleave<NM2_1, NE2_0>([&](auto m) { g2Micro(S1, m); }, [&](auto v) { e2Step(S0, v, rawOwn, actOwn, rawSh, actSh, onBits[0]); });
       }
       stamp(6);
@@ -533,6 +561,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
       T *rawOwn, *actOwn, *rawSh, *actSh;
       rows2(prevLive1, prevCell0, 1, rawOwn, actOwn, rawSh, actSh);
       mfmaSettle(acc2[1], accS, accS);
+      e2Params();
       staticFor<NE2_1>([&](auto v) { e2Step(S1, v, rawOwn, actOwn, rawSh, actSh, prevOn1); });
     }
     stamp(7);
