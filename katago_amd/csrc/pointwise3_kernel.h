@@ -72,20 +72,21 @@ struct Geom {
   static_assert(TM * 4 == NTHREADS, "one request round of the work-group fills exactly one chunk of the X tile");
   static_assert(WL_CHUNK == NWAVES * 1024, "one request round of the work-group fetches one chunk of the shared W2 rows");
   // vector-memory operations per wave and tile, in program order (the kernel's blocks):
-  //   block 1  N_X requests for the next tile's X | N_RS residual loads of sub-tile 0 | (the wait for this tile's X) | the previous tile's
-  //            second epilogue of sub-tile 1: N_E2 stores, twice that on the waves whose shared mid tile sits on sub-tile 1, none in a
-  //            work-group's first tile
+  //   block 1  N_RS residual loads of sub-tile 0 | the previous tile's second epilogue of sub-tile 1: N_E2 stores, twice that on the waves
+  //            whose shared mid tile sits on sub-tile 1, none in a work-group's first tile
   //   block 2  N_RS residual loads of sub-tile 1 | N_S1S raw-trunk stores of sub-tile 0      block 3  N_S1S raw-trunk stores of sub-tile 1
-  //   block 4  second epilogue of sub-tile 0: N_E2 stores, twice that on the waves whose shared mid tile sits on sub-tile 0
+  //            | (the wait for the NEXT tile's X, then barrier BA1)
+  //   block 4  N_X requests for the X of the tile after next | second epilogue of sub-tile 0: N_E2 stores, twice that on the waves whose
+  //            shared mid tile sits on sub-tile 0
   static constexpr int N_X = 1 + K1;     // mask + one request per chunk of X
   static constexpr int N_RS = T1 * 2;    // residual loads of a sub-tile (16 bytes per lane each)
   static constexpr int N_S1S = T1 * 2;   // stores of epilogue 1 per sub-tile
   static constexpr int N_E2 = 2 * 2;     // stores of the second epilogue of one mid tile: (raw, act) x 2 pieces
-  // At the wait for X(t) (top of tile t; requested at the top of tile t - 1): the FEWEST operations that can have been issued after its
-  // requests - tile t - 1's residual loads and stores with a single N_E2 (a first tile on a wave whose shared tile sits on sub-tile 1),
-  // then this tile's requests and first residual loads. Waiting for more than necessary in the other cases costs nothing: the extra
-  // operations are the oldest of a whole tile ago.
-  static constexpr int VM_AFTER_X = N_RS + N_RS + N_S1S + N_S1S + N_E2 + N_X + N_RS;
+  // At the wait for X(t + 1) (end of block 3 of tile t; requested in block 4 of tile t - 1, or by the prologue): the FEWEST operations
+  // that can have been issued after its requests - a work-group's first tile: the residual loads and raw-trunk stores of blocks 1-3 and
+  // nothing else. In the steady state the 3 N_E2 stores of the two second epilogues in between are waited for as well: the oldest
+  // operations of most of a tile ago.
+  static constexpr int VM_AFTER_X = N_RS + N_RS + N_S1S + N_S1S;
   static_assert(VM_AFTER_X <= 63, "s_waitcnt vmcnt has six bits");
 };
 
@@ -163,6 +164,9 @@ __device__ __forceinline__ void mfmaSettle(f32x16& a0, f32x16& a1, f32x16& a2) {
 #endif
 }
 
+// __builtin_amdgcn_sched_barrier mask: which instructions MAY cross - vector ALU (2), scalar ALU (4), transcendental (0x400); memory, LDS
+// and inline-asm (the MFMAs) may not
+constexpr int SCHED_ALU_ONLY = 0x2 | 0x4 | 0x400;
 // compile-time loops: f(integral_constant<int, 0>) .. f(integral_constant<int, N - 1>) - every index a constant expression, so register
 // arrays are indexed statically and `if constexpr` can pick a step's instructions
 template <int... I, class F>
@@ -182,7 +186,11 @@ __device__ __forceinline__ void interleave(FM&& fm, FV&& fv) {
     constexpr int V = decltype(v)::value, M0 = NM * V / NV, M1 = NM * (V + 1) / NV;
     staticFor<M1 - M0>([&](auto m) { fm(std::integral_constant<int, M0 + decltype(m)::value>()); });
     fv(v);
-    __builtin_amdgcn_sched_barrier(0);  // pieces stay in source order: the scheduler would otherwise cluster the matrix steps
+    // pieces stay in source order (the scheduler would otherwise cluster the matrix steps) - but the two values of a PAIR may overlap:
+    // a value is one dependent chain of ~12 vector instructions, two of them transcendental, and one wave per SIMD has only its own
+    // instruction-level parallelism to cover their latencies. SCHED_ALU_ONLY lets vector / scalar ALU instructions cross, nothing else.
+    if constexpr(V % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+    else __builtin_amdgcn_sched_barrier(SCHED_ALU_ONLY);
   });
 }
 
@@ -269,7 +277,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
     dma16((const char*)a.w2 + ((size_t)c * G::C3 + 32 * NWAVES) * ROWB + wave * 1024 + lane * 16, ldsBase + G::WL_OFF + c * G::WL_CHUNK + wave * 1024);
   long long tile = blockIdx.x;
   issueX(tile, 0, true);
-  waitVm<0>();
+  issueX(tile + stride, 1, tile + stride < numTiles);
+  waitVm<G::N_X>();  // all but the second tile's requests: weights, the shared W2 rows, the first tile's X and mask
+  wgBarrier();       // ... for every wave (the parameters above are published too)
   int parity = 0;
 
   // per-lane LDS addresses (opaque, so that every use is "this register + a constant the instruction carries")
@@ -335,7 +345,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
         if constexpr(I + 1 < 2 * K1) xfN = ldsV8(xLane[S][(I + 1) & 1] + xb + (unsigned)(((I + 1) >> 1) * G::CHUNK_BYTES));
       }
       if constexpr(J == T1 - 1) xfA = xfN;
-      __builtin_amdgcn_sched_barrier(0);  // the read stays HERE, a k-step ahead of its use (left alone, hipcc sinks it to just before that MFMA)
+      __builtin_amdgcn_sched_barrier(SCHED_ALU_ONLY);  // the read stays HERE, a k-step ahead of its use (left alone, hipcc sinks it to just before that MFMA)
     };
     // GEMM 2 on sub-tile S: the own mid tile (AGPRs) and, on sub-tile SH, the shared one (LDS): NM2(S) micro-steps
     auto g2Micro = [&](auto sTag, auto mTag) {
@@ -359,7 +369,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
         xfA = xfN;
         wlF = wlN;
       }
-      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(SCHED_ALU_ONLY);
     };
     // ---- vector pieces: ONE value per lane each (group GR = four consecutive channels of the lane's cell, value I of it; values 2 H and
     // 2 H + 1 share dword H of the group's packed 16-bit results, and their parameters come as one 8-byte LDS read) ----
@@ -482,19 +492,14 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
 
     for(; tile < numTiles; tile += stride) {
       const long long cell0 = tile * TM;
-      const bool hasNext = tile + stride < numTiles;  // uniform
       const unsigned maskA = ldsBase + G::MASK_OFF + (unsigned)parity * (TM * 4);
       const unsigned xb = (unsigned)(G::X_OFF + parity * G::X_BUF);
 
       // ---- block 1: GEMM 1 of sub-tile 0 | the previous tile's second epilogue of sub-tile 1 ----
-      // the next tile's X into the other buffer (last read in GEMM 1 of the previous tile, before that tile's barriers)
-      issueX(tile + stride, parity ^ 1, hasNext);
+      // (X(t) and its mask were published by the previous tile's barrier BA1 - the prologue's for the first tile)
 #pragma unroll
       for(int s = 0; s < NSUB; s++) live[s] = cell0 + 32 * s + myPos < a.cells;  // the same for both lanes of a pair
       loadResid(S0, cell0);
-      // X(t), its mask (first tile: the shared W2 rows too) have landed: in flight at most what was issued after them (VM_AFTER_X)
-      waitVm<G::VM_AFTER_X>();
-      wgBarrier();  // BX: ... for every wave
 #pragma unroll
       for(int s = 0; s < NSUB; s++) onBits[s] = ldsF1(maskA + (32 * s + myPos) * 4) == 1.0f ? 0xffffffffu : 0u;  // off-board cells of activated images are zero
       stamp(0);
@@ -536,10 +541,15 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
       }
       stamp(4);
       waitLds();
-      wgBarrier();  // BA1: ... of sub-tile 1
+      // the NEXT tile's X and mask (requested a tile ago, in block 4 of the previous tile or by the prologue) have landed: in flight at
+      // most what was issued after them (VM_AFTER_X)
+      waitVm<G::VM_AFTER_X>();
+      wgBarrier();  // BA1: the activated image of sub-tile 1 is whole; the next tile's X is there for every wave
       stamp(5);
 
       // ---- block 4: GEMM 2 of sub-tile 1 | epilogue 2 of sub-tile 0 ----
+      // the X of the tile after next into THIS tile's buffer (last read in block 2, before BA0) and mask slot (read at the top of the tile)
+      issueX(tile + 2 * stride, parity, tile + 2 * stride < numTiles);
       {
         T *rawOwn, *actOwn, *rawSh, *actSh;
         rows2(live[0], cell0, 0, rawOwn, actOwn, rawSh, actSh);

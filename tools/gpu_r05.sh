@@ -28,6 +28,14 @@ seam)
   b $OUT "b18 one stream, seam kernel 2" KMX_PW_KERNEL=2 KMX_SPLIT_MIN=0 -- --steps 40 --warmup 5 --no-profile
   b $OUT "b18 bf16, seam kernel 3" KMX_PW_KERNEL=3 -- --dtype bf16 --steps 40 --warmup 5
   b $OUT "b18 bf16, seam kernel 2" KMX_PW_KERNEL=2 -- --dtype bf16 --steps 40 --warmup 5
+  # the kernels' own durations inside the net (rocprofv3 kernel trace, one stream), both seam kernels
+  for k in 3 2; do
+    KMX_PW_KERNEL=$k KMX_SPLIT_MIN=0 timeout 150 rocprofv3 --kernel-trace --stats -d $OUT/trace_k$k -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-callers --no-profile > $OUT/trace_k$k.log 2>&1
+    f=$(find $OUT/trace_k$k -name "*kernel_stats.csv" | head -1)
+    [ -n "$f" ] && { echo "== in-net kernel stats, seam kernel $k"; head -8 "$f" | cut -c1-200; } | tee -a $OUT/in_net_kernel_stats.txt
+    [ -n "$f" ] && cp "$f" $OUT/trace_k${k}_kernel_stats.csv
+    rm -rf $OUT/trace_k$k
+  done
   ;;
 parity)
   timeout 1500 python -m pytest "tests/test_gpu_model.py::test_large_nets_of_the_analysis_config" "tests/test_gpu_search_fixed_seed.py" tests/test_gpu_layers.py -m gpu -q -p no:cacheprovider -s 2>&1 | grep -v "^$" | tail -60 | tee $OUT/pytest.log
