@@ -174,7 +174,8 @@ ComputeContext* NeuralNet::createComputeContext(
     string p = e;
     if(p == "fp16") precisionMode = KMX_PREC_FP16;
     else if(p == "bf16") precisionMode = KMX_PREC_BF16;
-    else if(p != "auto" && p != "") throw StringError("KATAMX_PRECISION must be one of fp16, bf16, auto");
+    else if(p == "fp32") precisionMode = KMX_PREC_FP32;
+    else if(p != "auto" && p != "") throw StringError("KATAMX_PRECISION must be one of fp16, bf16, fp32, auto");
   }
   context->precisionMode = precisionMode;
   if(cfg.contains("katamxBatcher")) context->useBatcher = cfg.getBool("katamxBatcher");

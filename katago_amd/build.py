@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libkatamx.so")
 
-SOURCES = ["conv_mfma.hip", "conv_chain.hip", "pointwise.hip", "conv_bench.hip", "misc_kernels.hip", "transformer_kernels.hip", "engine.cpp", "model_desc.cpp", "kmx_api.cpp", "batcher.cpp", "numa.cpp"]
+SOURCES = ["conv_mfma.hip", "conv_chain.hip", "pointwise.hip", "conv_bench.hip", "conv_f32.hip", "misc_kernels.hip", "transformer_kernels.hip", "engine.cpp", "model_desc.cpp", "kmx_api.cpp", "batcher.cpp", "numa.cpp"]
 HEADERS = ["kernels.h", "device_common.h", "conv_kernel.h", "conv_chain_kernel.h", "conv_small_kernel.h", "pointwise_kernel.h", "pointwise2_kernel.h", "pointwise3_kernel.h", "engine.h", "model_desc.h", "katamx_tuning.h", "numa.h", os.path.join("..", "..", "include", "katamx.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize: left on, the SLP vectoriser packs adjacent fp32 epilogue arithmetic into v_pk_*_f32 instructions - which

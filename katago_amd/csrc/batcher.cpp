@@ -455,7 +455,7 @@ int kmx_batcher_create(kmx_context* ctx, const kmx_model* model, int max_batch_s
     std::unique_ptr<kmx_batcher> h(new kmx_batcher());
     // staging sets: the ones on the device, one filling, one being collected by its waiters
     const int dtype = apiDtypeFor(ctx, model);
-    h->precision = dtype == DT_F16 ? KMX_PREC_FP16 : KMX_PREC_BF16;
+    h->precision = dtype == DT_F16 ? KMX_PREC_FP16 : dtype == DT_F32 ? KMX_PREC_FP32 : KMX_PREC_BF16;
     h->b.reset(new Batcher(apiModelDesc(model), x, y, max_batch_size, dtype, dev, max_in_flight, max_in_flight + 2));
     *out = h.release();
   });

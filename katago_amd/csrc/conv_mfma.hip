@@ -119,6 +119,7 @@ hipError_t launchT(int ks, int cfg, const ConvArgs& a, hipStream_t stream) {
 hipError_t launchConv(int dtype, int ks, int cfg, const ConvArgs& a, hipStream_t stream) {
   if(a.X < 2 || a.Y < 2 || a.X > MAXLEN || a.Y > MAXLEN || a.N <= 0) return hipErrorInvalidValue;
   if(a.inC % 8 != 0 || a.coutPad % 32 != 0 || (a.nChunks + 4) * 64 > ZERO_PAGE_BYTES) return hipErrorInvalidValue;
+  if(dtype == DT_F32) return launchConvF32(ks, a, stream);
   if(dtype == DT_F16) return launchT<TraitsF16>(ks, cfg, a, stream);
   if(dtype == DT_BF16) return launchT<TraitsBF16>(ks, cfg, a, stream);
   return hipErrorInvalidValue;

@@ -40,6 +40,17 @@ struct TraitsBF16 {
   static __device__ __forceinline__ T fromFloat(float x) { return (T)x; }
 };
 
+// fp32 storage (DT_F32, kernels.h): the small kernels' element type in the verification mode; no matrix-core form
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+struct TraitsF32 {
+  typedef float T;
+  typedef f32x8 V8;
+  typedef float V4 __attribute__((ext_vector_type(4)));
+  static constexpr int DT = DT_F32;
+  static __device__ __forceinline__ float toFloat(T x) { return x; }
+  static __device__ __forceinline__ T fromFloat(float x) { return x; }
+};
+
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 

@@ -72,7 +72,10 @@ FusedConv buildFusedConv(int dtype, const std::vector<ConvSegment>& segs, std::v
   fc.coutPad = roundUp(cout, 64);  // every work-group shape (32..192 channels) that divides it is launchable
   fc.nChunks = (fc.cin + KCHUNK - 1) / KCHUNK;
   const int nt = fc.ks * fc.ks;
-  std::vector<uint16_t> w((size_t)fc.nChunks * nt * fc.coutPad * WROW_HALFS, 0);
+  // (DT_F32: the same layout with four-byte values)
+  const bool f32 = dtype == DT_F32;
+  std::vector<uint16_t> w(f32 ? 0 : (size_t)fc.nChunks * nt * fc.coutPad * WROW_HALFS, 0);
+  std::vector<float> wf(f32 ? (size_t)fc.nChunks * nt * fc.coutPad * WROW_HALFS : 0, 0.0f);
   std::vector<float> scale(fc.coutPad, 0.0f), bias(fc.coutPad, 0.0f);
   for(size_t si = 0; si < segs.size(); si++) {
     const ConvDesc& c = *segs[si].conv;
@@ -84,11 +87,13 @@ FusedConv buildFusedConv(int dtype, const std::vector<ConvSegment>& segs, std::v
         if(ky < 0 || ky >= c.ky || kx < 0 || kx >= c.kx) continue;  // zero tap of an embedded smaller kernel
         for(int oc = 0; oc < c.outC; oc++) {
           const int co = offs[si] + oc;
-          uint16_t* row = &w[(((size_t)chunk * nt + t) * fc.coutPad + co) * WROW_HALFS];
+          const size_t row = (((size_t)chunk * nt + t) * fc.coutPad + co) * WROW_HALFS;
           for(int k = 0; k < KCHUNK; k++) {
             const int ic = chunk * KCHUNK + k;
             const int slot = (k >> 3) ^ ((co >> 2) & 3);  // the kernel's LDS swizzle, applied here so the DMA copy is linear
-            if(ic < c.inC) row[slot * 8 + (k & 7)] = floatToTBits(dtype, c.at(ky, kx, ic, oc));
+            if(ic >= c.inC) continue;
+            if(f32) wf[row + slot * 8 + (k & 7)] = c.at(ky, kx, ic, oc);
+            else w[row + slot * 8 + (k & 7)] = floatToTBits(dtype, c.at(ky, kx, ic, oc));
           }
         }
       }
@@ -101,8 +106,14 @@ FusedConv buildFusedConv(int dtype, const std::vector<ConvSegment>& segs, std::v
       }
     }
   }
-  fc.w = DevBuf(w.size() * sizeof(uint16_t), false);
-  fc.w.upload(w.data(), w.size() * sizeof(uint16_t));
+  if(f32) {
+    fc.w = DevBuf(wf.size() * sizeof(float), false);
+    fc.w.upload(wf.data(), wf.size() * sizeof(float));
+  }
+  else {
+    fc.w = DevBuf(w.size() * sizeof(uint16_t), false);
+    fc.w.upload(w.data(), w.size() * sizeof(uint16_t));
+  }
   fc.scale = DevBuf(scale.size() * sizeof(float), false);
   fc.scale.upload(scale.data(), scale.size() * sizeof(float));
   fc.bias = DevBuf(bias.size() * sizeof(float), false);
@@ -144,7 +155,9 @@ Engine::Engine(const ModelDesc& model, int nnXLen, int nnYLen, int maxBatch, int
   if(nnXLen < 2 || nnYLen < 2 || nnXLen > 19 || nnYLen > 19)
     throw Error(KMX_ERR_INVALID_ARG, "nnXLen/nnYLen must be in 2..19");
   if(maxBatch < 1 || maxBatch > 65535) throw Error(KMX_ERR_INVALID_ARG, "maxBatchSize must be in 1..65535");
-  if(dtype != DT_F16 && dtype != DT_BF16) throw Error(KMX_ERR_UNSUPPORTED, "unsupported device precision");
+  if(dtype != DT_F16 && dtype != DT_BF16 && dtype != DT_F32) throw Error(KMX_ERR_UNSUPPORTED, "unsupported device precision");
+  if(dtype == DT_F32 && (model.hasTransformerBlocks || model.trunkNormKind != 0))
+    throw Error(KMX_ERR_UNSUPPORTED, "fp32 device arithmetic (the verification mode) covers convolutional nets; transformer / RMSNorm nets run in fp16");
   // A constructor that throws does not run the destructor: release the stream, events and pinned buffers acquired so far
   // (an unsupported layer, or a device out of memory half-way through, must not leak them).
   try {
@@ -173,12 +186,16 @@ void Engine::construct(const ModelDesc& model) {
   if(const char* e = getenv("KMX_PACK_INPUTS")) packInputs_ = atoi(e) != 0;
   if(const char* e = getenv("KMX_FUSE_MIN_ROWS")) fuseMinRows_ = std::max(1, atoi(e));
   if(const char* e = getenv("KMX_CONV_CHAIN")) maxChain_ = atoi(e) >= 4 ? 4 : atoi(e) >= 2 ? 2 : 0;
+  if(dtype_ == DT_F32) {  // the fp32 verification mode: one plain launch per convolution (kernels.h DT_F32)
+    fuseSeams_ = false;
+    maxChain_ = 0;
+  }
   cin_ = model.numInputChannels;
   gin_ = model.numInputGlobalChannels;
   min_ = model.metaEncoderVersion > 0 ? model.numInputMetaChannels : 0;
   const size_t NS = (size_t)maxBatch_ * S_;
   zeroPage_ = DevBuf(ZERO_PAGE_ALLOC);
-  inputT_ = DevBuf(NS * KCHUNK * 2);
+  inputT_ = DevBuf(NS * KCHUNK * dtSize(dtype_));
   mask_ = DevBuf(NS * sizeof(float));
   maskSum_ = DevBuf((size_t)maxBatch_ * sizeof(float));
   ncBias_ = DevBuf((size_t)maxBatch_ * roundUp(model.trunkC, 64) * sizeof(float));
@@ -683,11 +700,11 @@ void Engine::buildSchedule(const ModelDesc& m) {
   std::vector<int> levelStride(1, roundUp(m.trunkC, 32));
   int tmpStride = 32, gStride = 32;
   scanStack(m.blocks, 0, levelStride, tmpStride, gStride);
-  acts_.emplace_back(new DevBuf(NS * tmpStride * 2));
-  acts_.emplace_back(new DevBuf(NS * gStride * 2));
+  acts_.emplace_back(new DevBuf(NS * tmpStride * dtSize(dtype_)));
+  acts_.emplace_back(new DevBuf(NS * gStride * dtSize(dtype_)));
   for(size_t d = 0; d < levelStride.size(); d++) {
-    acts_.emplace_back(new DevBuf(NS * std::max(levelStride[d], 32) * 2));
-    acts_.emplace_back(new DevBuf(NS * std::max(levelStride[d], 32) * 2));
+    acts_.emplace_back(new DevBuf(NS * std::max(levelStride[d], 32) * dtSize(dtype_)));
+    acts_.emplace_back(new DevBuf(NS * std::max(levelStride[d], 32) * dtSize(dtype_)));
   }
   Stream trunk;
   trunk.raw = acts_[2]->get();
@@ -760,9 +777,9 @@ void Engine::buildSchedule(const ModelDesc& m) {
   const int headRawStride = roundUp(P1, 32);
   const int headActC = heads->cout - offs[1];
   const int headActStride = roundUp(headActC, 32);
-  acts_.emplace_back(new DevBuf(NS * headRawStride * 2));
+  acts_.emplace_back(new DevBuf(NS * headRawStride * dtSize(dtype_)));
   void* headRaw = acts_.back()->get();
-  acts_.emplace_back(new DevBuf(NS * headActStride * 2));
+  acts_.emplace_back(new DevBuf(NS * headActStride * dtSize(dtype_)));
   void* headAct = acts_.back()->get();
   addConv(heads, trunk.act, trunk.stride, nullptr, 0, nullptr, 0, headRaw, headRawStride, 0, offs[1], headAct, headActStride,
           offs[1], heads->cout, m.g1BN.act);
@@ -771,7 +788,7 @@ void Engine::buildSchedule(const ModelDesc& m) {
   if(!fuseV) {
     const FusedConv* vconv = newConv({{&m.v1Conv, &m.v1BN}});
     vStride = roundUp(V1, 32);
-    acts_.emplace_back(new DevBuf(NS * vStride * 2));
+    acts_.emplace_back(new DevBuf(NS * vStride * dtSize(dtype_)));
     vAct = acts_.back()->get();
     addConv(vconv, trunk.act, trunk.stride, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, vAct, vStride, 0, vconv->coutPad, m.v1BN.act);
   }
@@ -1183,7 +1200,7 @@ struct HookCtx {
     DevBuf f(cells * C * sizeof(float), false);
     f.upload(host, cells * C * sizeof(float));
     *stride = roundUp(C, 32);
-    DevBuf t(cells * (*stride) * 2);
+    DevBuf t(cells * (*stride) * dtSize(dtype));
     hipCheck(launchFloatToT(dtype, f.as<float>(), C, t.get(), *stride, cells, st), "floatToT");
     hipCheck(hipStreamSynchronize(st), "sync");
     return t;
@@ -1258,7 +1275,7 @@ void testConv(int dtype, const kmx_conv_desc* d, int batch, int X, int Y, const 
   FusedConv fc = buildFusedConv(dtype, {{&c, nullptr}}, nullptr);
   int inStride, outStride = roundUp(c.outC, 32);
   DevBuf x = h.toDevice(in, c.inC, &inStride);
-  DevBuf y((size_t)batch * h.S * outStride * 2);
+  DevBuf y((size_t)batch * h.S * outStride * dtSize(h.dtype));
   h.conv(fc, x.get(), inStride, nullptr, 0, y.get(), outStride, 0, roundUp(c.outC, 8), nullptr, 0, 0, 0, KMX_ACT_IDENTITY);
   h.toHost(y, outStride, c.outC, out);
 }
@@ -1282,10 +1299,10 @@ void testResBlock(int dtype, const kmx_resblock_desc* d, int batch, int X, int Y
   const int C = preBN.c;
   int stride;
   DevBuf raw = h.toDevice(in, C, &stride);
-  DevBuf act((size_t)batch * h.S * stride * 2);
+  DevBuf act((size_t)batch * h.S * stride * dtSize(h.dtype));
   runBnAct(h, preBN, raw, act, stride);
   const int midStride = roundUp(c1.outC, 32);
-  DevBuf mid((size_t)batch * h.S * midStride * 2);
+  DevBuf mid((size_t)batch * h.S * midStride * dtSize(h.dtype));
   h.conv(f1, act.get(), stride, nullptr, 0, nullptr, 0, 0, 0, mid.get(), midStride, 0, f1.coutPad, midBN.act);
   h.conv(f2, mid.get(), midStride, raw.get(), stride, raw.get(), stride, 0, roundUp(C, 8), nullptr, 0, 0, 0, KMX_ACT_IDENTITY);
   h.toHost(raw, stride, C, out);
@@ -1304,10 +1321,10 @@ void testGPoolBlock(int dtype, const kmx_gpoolblock_desc* d, int batch, int X, i
   const int C = preBN.c, R = cr.outC, G = cg.outC;
   int stride;
   DevBuf raw = h.toDevice(in, C, &stride);
-  DevBuf act((size_t)batch * h.S * stride * 2);
+  DevBuf act((size_t)batch * h.S * stride * dtSize(h.dtype));
   runBnAct(h, preBN, raw, act, stride);
   const int rStride = roundUp(R, 32), gStride = roundUp(G, 32);
-  DevBuf r((size_t)batch * h.S * rStride * 2), g((size_t)batch * h.S * gStride * 2);
+  DevBuf r((size_t)batch * h.S * rStride * dtSize(h.dtype)), g((size_t)batch * h.S * gStride * dtSize(h.dtype));
   h.conv(f1, act.get(), stride, nullptr, 0, r.get(), rStride, 0, offs[1], g.get(), gStride, offs[1], f1.coutPad, gBN.act);
   // mask sums on the host (computeMaskSum, eigenbackend.cpp:124-134)
   std::vector<float> ms(batch, 0.0f);
@@ -1335,7 +1352,8 @@ void testPointwisePair(int dtype, int batch, int X, int Y, int c1, int c2, int c
                        int act2, const float* mask, bool fused, float* outTrunkRaw, float* outMidRaw, float* outMidAct) {
   if(!in || !resid || !w1 || !w2 || !scale1 || !bias1 || !scale2 || !bias2 || !outTrunkRaw || !outMidRaw || !outMidAct)
     throw Error(KMX_ERR_INVALID_ARG, "test pointwise pair: null argument");
-  if(fused && !pointwisePairSupported(c1, c2, c3)) throw Error(KMX_ERR_UNSUPPORTED, "test pointwise pair: no fused kernel for these channel counts");
+  if(fused && (dtype == DT_F32 || !pointwisePairSupported(c1, c2, c3)))
+    throw Error(KMX_ERR_UNSUPPORTED, "test pointwise pair: no fused kernel for these channel counts / this precision");
   HookCtx h(dtype, batch, X, Y, mask);
   auto conv1x1 = [](const char* name, int ic, int oc, const float* w) {  // [oc][ic] -> file order [1][1][ic][oc]
     ConvDesc c;
@@ -1360,7 +1378,7 @@ void testPointwisePair(int dtype, int batch, int X, int Y, int c1, int c2, int c
   DevBuf trunkRaw = h.toDevice(resid, c2, &trunkStride);
   const int midStride = roundUp(c3, 32);
   const size_t cells = (size_t)batch * h.S;
-  DevBuf trunkAct(cells * trunkStride * 2), midRaw(cells * midStride * 2), midAct(cells * midStride * 2);
+  DevBuf trunkAct(cells * trunkStride * dtSize(h.dtype)), midRaw(cells * midStride * dtSize(h.dtype)), midAct(cells * midStride * dtSize(h.dtype));
   if(fused) {
     PwPairArgs pa;
     memset(&pa, 0, sizeof(pa));
@@ -1391,7 +1409,8 @@ void testConvChain(int dtype, int batch, int X, int Y, int nConv, const float* x
   if(nConv != 2 && nConv != 4) throw Error(KMX_ERR_INVALID_ARG, "test conv chain: n_conv must be 2 or 4");
   if(chained != 0 && chained != 2 && chained != 4) throw Error(KMX_ERR_INVALID_ARG, "test conv chain: chained must be 0, 2 or 4");
   if(chained > nConv) chained = nConv;
-  if(chained != 0 && !convChainSupported(act)) throw Error(KMX_ERR_UNSUPPORTED, "test conv chain: no chained kernel for this activation");
+  if(chained != 0 && (dtype == DT_F32 || !convChainSupported(act)))
+    throw Error(KMX_ERR_UNSUPPORTED, "test conv chain: no chained kernel for this activation / this precision");
   const int C = CHAIN_CHANNELS;
   HookCtx h(dtype, batch, X, Y, mask);
   std::vector<FusedConv> fc;
@@ -1411,7 +1430,7 @@ void testConvChain(int dtype, int batch, int X, int Y, int nConv, const float* x
   DevBuf x = h.toDevice(xIn, C, &stride);
   DevBuf r = h.toDevice(rIn, C, &stride);
   const size_t cells = (size_t)batch * h.S;
-  DevBuf tmp(cells * C * 2);
+  DevBuf tmp(cells * C * dtSize(h.dtype));
   if(chained == 0) {
     for(int k = 0; k < nConv; k++) {
       ConvArgs a;
@@ -1455,7 +1474,7 @@ void testRmsNorm(int dtype, int batch, int X, int Y, int C, float eps, const flo
   HookCtx h(dtype, batch, X, Y, mask);
   int stride;
   DevBuf x = h.toDevice(in, C, &stride);
-  DevBuf y((size_t)batch * h.S * stride * 2);
+  DevBuf y((size_t)batch * h.S * stride * dtSize(h.dtype));
   DevBuf dw = uploadVec(std::vector<float>(w, w + C));
   DevBuf db = uploadVec(beta ? std::vector<float>(beta, beta + C) : std::vector<float>(1, 0.0f));
   DevBuf rms((size_t)batch * sizeof(float));
@@ -1495,7 +1514,7 @@ void testAttention(int dtype, int batch, int X, int Y, int H, int KVH, int QD, i
   int stride;
   DevBuf qkv = h.toDevice(cat.data(), ctot, &stride);
   const int outStride = roundUp(H * VD, 32);
-  DevBuf y(cells * outStride * 2);
+  DevBuf y(cells * outStride * dtSize(h.dtype));
   const size_t tbl = ropeCos ? (size_t)(ropeHeads > 1 ? KVH : 1) * (QD / 2) * h.S : 1;
   DevBuf dc = uploadVec(ropeCos ? std::vector<float>(ropeCos, ropeCos + tbl) : std::vector<float>(1, 1.0f));
   DevBuf ds = uploadVec(ropeSin ? std::vector<float>(ropeSin, ropeSin + tbl) : std::vector<float>(1, 0.0f));
@@ -1526,7 +1545,7 @@ void testSwiGlu(int dtype, int batch, int X, int Y, int F, const float* a1, cons
   int stride;
   DevBuf x = h.toDevice(cat.data(), 2 * F, &stride);
   const int outStride = roundUp(F, 32);
-  DevBuf y(cells * outStride * 2);
+  DevBuf y(cells * outStride * dtSize(h.dtype));
   SwiGluArgs a;
   memset(&a, 0, sizeof(a));
   a.in = x.get(); a.inStride = stride; a.gOff = F; a.F = F; a.out = y.get(); a.outStride = outStride; a.cells = cells;

@@ -15,7 +15,12 @@
 
 namespace kmx {
 
-enum { DT_F16 = 0, DT_BF16 = 1 };
+// DT_F32 (round 5): fp32 storage and arithmetic - the verification mode behind KMX_PREC_FP32 (useFP16Mode = False,
+// cpp/neuralnet/nninterface.h:50-63; what the reference's testgpuerror builds beside the 16-bit evaluator, command/gputest.cpp:122-133).
+// Same schedule, same buffers at four bytes per value, the small kernels instantiated for float; the convolutions run a plain
+// one-thread-per-output kernel (conv_f32.hip) - correct, not fast. Fused seams, chained convolutions and transformer blocks are 16-bit only.
+enum { DT_F16 = 0, DT_BF16 = 1, DT_F32 = 2 };
+inline int dtSize(int dtype) { return dtype == DT_F32 ? 4 : 2; }
 
 constexpr int KCHUNK = 32;      // input channels per K chunk
 constexpr int ZERO_PAGE_BYTES = 16384;  // >= (inC/32 + 4) * 64
@@ -60,6 +65,7 @@ struct ConvArgs {
 // KS in {1,3,5}; cfg = 10*WNW + WN (WNW waves along channels: 1 = 4-wave, 2 = 8-wave work-group; WN = 32-channel
 // tiles per wave). Returns hipSuccess or an error (unsupported combination -> hipErrorInvalidValue).
 hipError_t launchConv(int dtype, int ks, int cfg, const ConvArgs& a, hipStream_t stream);
+hipError_t launchConvF32(int ks, const ConvArgs& a, hipStream_t stream);  // conv_f32.hip: the DT_F32 form of the contract above (cfg is ignored)
 int chooseConvCfg(int ks, int coutPad, int batch);
 bool convCfgInstantiated(int ks, int cfg);  // is there a kernel for this (kernel size, shape)?
 

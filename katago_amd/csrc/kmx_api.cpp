@@ -93,6 +93,7 @@ int dtypeForPrecision(int mode) {
     case KMX_PREC_AUTO: return DT_BF16;
     case KMX_PREC_BF16: return DT_BF16;
     case KMX_PREC_FP16: return DT_F16;
+    case KMX_PREC_FP32: return DT_F32;  // the verification mode (kernels.h DT_F32): plain fp32 kernels, correct and slow
     default: return -1;
   }
 }
@@ -204,8 +205,6 @@ int kmx_context_create(const int* gpu_idxs, int num_gpu_idxs, int nn_x_len, int 
     *out = nullptr;
     if(nn_x_len < 2 || nn_y_len < 2 || nn_x_len > 19 || nn_y_len > 19)
       throw Error(KMX_ERR_INVALID_ARG, "kmx_context_create: nnXLen/nnYLen must be in 2..19");
-    if(precision_mode == KMX_PREC_FP32)
-      throw Error(KMX_ERR_UNSUPPORTED, "katamx: fp32 device arithmetic is not implemented; use fp16/bf16 (fp32 accumulate)");
     if(dtypeForPrecision(precision_mode) < 0) throw Error(KMX_ERR_INVALID_ARG, "kmx_context_create: unknown precision mode");
     const int ndev = deviceCountOrThrow();
     std::unique_ptr<kmx_context> c(new kmx_context());
@@ -234,7 +233,7 @@ int kmx_handle_create(kmx_context* ctx, const kmx_model* model, int max_batch_si
     if(dev >= ndev) throw Error(KMX_ERR_DEVICE, "kmx_handle_create: device index out of range");
     std::unique_ptr<kmx_handle> h(new kmx_handle());
     const int dtype = apiDtypeFor(ctx, model);
-    h->precision = dtype == DT_F16 ? KMX_PREC_FP16 : KMX_PREC_BF16;
+    h->precision = dtype == DT_F16 ? KMX_PREC_FP16 : dtype == DT_F32 ? KMX_PREC_FP32 : KMX_PREC_BF16;
     h->maxBatch = max_batch_size;
     int splitMin = 224;  // parts of >= 56 boards: the 8-wave work-groups of all parts together fill >= 87 % of the CUs
     if(const char* e = getenv("KMX_SPLIT_MIN")) splitMin = atoi(e);  // 0 disables splitting
@@ -532,8 +531,10 @@ int kmx_bench_mfma(int waves_per_wg, int wgs, int mode, int steps, int iters, do
   });
 }
 
-static int hookDtype(int precision_mode) {
-  if(precision_mode == KMX_PREC_FP32) throw Error(KMX_ERR_UNSUPPORTED, "fp32 device arithmetic is not implemented");
+// the layer hooks run in any precision; the hooks of kernels that only exist for 16-bit storage (the fused seam, chained convolutions,
+// transformer layers) refuse fp32
+static int hookDtype(int precision_mode, bool sixteenBitOnly = false) {
+  if(sixteenBitOnly && precision_mode == KMX_PREC_FP32) throw Error(KMX_ERR_UNSUPPORTED, "this kernel exists for 16-bit storage only");
   int dt = dtypeForPrecision(precision_mode);
   if(dt < 0) throw Error(KMX_ERR_INVALID_ARG, "unknown precision mode");
   (void)deviceCountOrThrow();
@@ -588,7 +589,7 @@ int kmx_test_conv_chain(int batch, int nn_x_len, int nn_y_len, int precision_mod
 int kmx_test_rmsnorm(int batch, int nn_x_len, int nn_y_len, int precision_mode, int num_channels, float epsilon, const float* weight,
                      const float* beta, int activation, int per_board, const float* in_nhwc, const float* mask_nhw, float* out_nhwc) {
   return guarded([&] {
-    testRmsNorm(hookDtype(precision_mode), batch, nn_x_len, nn_y_len, num_channels, epsilon, weight, beta, activation, per_board != 0,
+    testRmsNorm(hookDtype(precision_mode, true), batch, nn_x_len, nn_y_len, num_channels, epsilon, weight, beta, activation, per_board != 0,
                 in_nhwc, mask_nhw, out_nhwc);
   });
 }
@@ -596,13 +597,13 @@ int kmx_test_attention(int batch, int nn_x_len, int nn_y_len, int precision_mode
                        int v_head_dim, const float* rope_cos, const float* rope_sin, int rope_heads, const float* q, const float* k,
                        const float* v, const float* mask_nhw, float* out) {
   return guarded([&] {
-    testAttention(hookDtype(precision_mode), batch, nn_x_len, nn_y_len, num_heads, num_kv_heads, q_head_dim, v_head_dim, rope_cos,
+    testAttention(hookDtype(precision_mode, true), batch, nn_x_len, nn_y_len, num_heads, num_kv_heads, q_head_dim, v_head_dim, rope_cos,
                   rope_sin, rope_heads, q, k, v, mask_nhw, out);
   });
 }
 int kmx_test_swiglu(int batch, int nn_x_len, int nn_y_len, int precision_mode, int ffn_channels, const float* a, const float* gate,
                     float* out) {
-  return guarded([&] { testSwiGlu(hookDtype(precision_mode), batch, nn_x_len, nn_y_len, ffn_channels, a, gate, out); });
+  return guarded([&] { testSwiGlu(hookDtype(precision_mode, true), batch, nn_x_len, nn_y_len, ffn_channels, a, gate, out); });
 }
 
 }  // extern "C"

@@ -665,6 +665,7 @@ inline int gridFor(size_t total) {
   do {                                                                                             \
     if((dtype) == DT_F16) hipLaunchKernelGGL(KERNEL<TraitsF16>, grid, block, lds, stream, __VA_ARGS__); \
     else if((dtype) == DT_BF16) hipLaunchKernelGGL(KERNEL<TraitsBF16>, grid, block, lds, stream, __VA_ARGS__); \
+    else if((dtype) == DT_F32) hipLaunchKernelGGL(KERNEL<TraitsF32>, grid, block, lds, stream, __VA_ARGS__); \
     else return hipErrorInvalidValue;                                                              \
     return hipGetLastError();                                                                      \
   } while(0)

@@ -82,6 +82,7 @@ hipError_t launchConv(int dtype, int ks, int cfg, const ConvArgs& a, hipStream_t
   if(ks != 1 && ks != 3 && ks != 5) return hipErrorInvalidValue;
   if(dtype == DT_F16) return convRef<TraitsF16>(ks, a);
   if(dtype == DT_BF16) return convRef<TraitsBF16>(ks, a);
+  if(dtype == DT_F32) return convRef<TraitsF32>(ks, a);  // (the product's own fp32 kernel, conv_f32.hip, runs in the "real convolution" build)
   return hipErrorInvalidValue;
 }
 #endif

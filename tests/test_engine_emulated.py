@@ -182,7 +182,7 @@ def build_emu_full(d, conv_mutations=(), pw2_mutations=(), chain_mutations=(), s
     cxx = ["/opt/rocm/lib/llvm/bin/clang++", "-x", "c++", "-std=c++20", "-O2", "-fPIC", "-pthread", "-I" + os.path.join(FAKE, "emul"), "-I" + FAKE,
            "-I" + CSRC, "-DKMX_EMU_REAL_CONV"] + list(extra_flags)
     procs, objs = [], []
-    for src_file in [os.path.join(d, "conv_mfma.hip"), os.path.join(d, "conv_chain.hip"), os.path.join(d, "pointwise.hip")] + SOURCES:
+    for src_file in [os.path.join(d, "conv_mfma.hip"), os.path.join(d, "conv_chain.hip"), os.path.join(d, "pointwise.hip"), os.path.join(CSRC, "conv_f32.hip")] + SOURCES:
         obj = os.path.join(d, os.path.splitext(os.path.basename(src_file))[0] + ".o")
         objs.append(obj)
         procs.append((src_file, subprocess.Popen(cxx + ["-c", src_file, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -351,6 +351,30 @@ def test_convolutional_nets_emulated(emu_lib):
     res = run_cases(emu_lib, ["bf16:gen_b3c64nbt_v15", "fp16:gen_b6c96_v8", "bf16:torch_nbt", "fp16:torch_nbt", "bf16:torch_meta"])
     check({k: v for k, v in res.items() if k.startswith("bf16")}, 0.03, 0.08)
     check({k: v for k, v in res.items() if k.startswith("fp16")}, 0.03, 0.02)
+
+
+def test_fp32_verification_mode_emulated(emu_lib, emu_full_lib):
+    """KMX_PREC_FP32 (useFP16Mode = False, nninterface.h:50-63; round 5): the same schedule on four-byte tensors, the small kernels
+    instantiated for float, one plain launch per convolution. Against the fp32 oracle and the PyTorch goldens at 1e-4 of the value (what
+    a different summation order and the hardware's exp / reciprocal leave), with the engine's contract executor and with the product's
+    own fp32 convolution kernel (conv_f32.hip, the "real convolution" build); the handle reports fp32."""
+    cases = ["fp32:gen_b3c64nbt_v15", "fp32:gen_b6c96_v8", "fp32:torch_nbt", "fp32:torch_meta"]
+    check(run_cases(emu_lib, cases), 1e-4, 1e-4)
+    check(run_cases(emu_full_lib, ["fp32:gen_b3c64nbt_v15", "fp32:torch_nbt"]), 1e-4, 1e-4)
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+from katago_amd import capi
+capi._lib = capi.load_library(path=sys.argv[1])
+from katago_amd import nninterface as nn, modelgen
+nn.globalInitialize()
+import os
+p = os.path.join(os.environ.get("TMPDIR", "/tmp"), "kmx_emu_fp32.bin"); modelgen.write_model(p, "b2c32nbt", seed=4)
+h = nn.createComputeHandle(nn.createComputeContext([0], 9, 9, useFP16Mode=False), nn.loadModelFile(p), 2)
+print("PRECISION", h.precision)
+""" % (REPO,)
+    r = subprocess.run([sys.executable, "-c", code, emu_lib], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "PRECISION fp32" in r.stdout, (r.stdout + r.stderr)[-2000:]
 
 
 def test_fp16_range_transform_emulated(emu_lib):

@@ -110,10 +110,32 @@ def test_gpool_block(dtype, C, R, G, X, Y, n, kr):
     assert close(got[on], want[on])
 
 
-def test_fp32_mode_is_refused_not_emulated():
+def test_fp32_mode_layers():
+    """KMX_PREC_FP32 (round 5; until then refused): the layer hooks in fp32 storage and arithmetic against the oracle at 1e-4 of
+    max(|x|, 3) - the fp32 tolerance of the reference's own layer tests is of that order (cpp/tests/testnn.cpp) - and the hooks of
+    kernels that exist for 16-bit storage only (the fused seam, chained convolutions) say so."""
     rng = np.random.default_rng(0)
+    for ks, cin, cout, X, Y, n in [(3, 32, 64, 19, 19, 2), (1, 96, 4, 7, 7, 2), (5, 22, 96, 19, 19, 1), (3, 40, 20, 13, 9, 2), (3, 5, 3, 2, 2, 4)]:
+        w = (rng.standard_normal((cout, cin, ks, ks)) / np.sqrt(ks * ks * cin)).astype(np.float32)
+        x = rng.standard_normal((n, Y, X, cin)).astype(np.float32)
+        assert close(nn.testEvaluateConv(w, n, X, Y, "fp32", x), oracle.testEvaluateConv(w, n, X, Y, x), scale=1e-4)
+    C, R, G, X, Y, n = 64, 32, 32, 13, 13, 2
+    blk = dict(pre=_bn(rng, C, capi.ACT_MISH), convr=_cw(rng, R, C, 3), convg=_cw(rng, G, C, 3), gbn=_bn(rng, G, capi.ACT_MISH),
+               gmul=(rng.standard_normal((3 * G, R)) * 0.5 / np.sqrt(3 * G)).astype(np.float32), mid=_bn(rng, R, capi.ACT_MISH),
+               conv2=_cw(rng, C, R, 3, 0.5))
+    mask = np.ones((n, Y, X), np.float32)
+    mask[0, Y - 4:, :] = 0
+    x = rng.standard_normal((n, Y, X, C)).astype(np.float32) * mask[..., None]
+    got = nn.testEvaluateGlobalPoolingResidualBlock(blk, n, X, Y, "fp32", x, mask)
+    want = oracle.testEvaluateGlobalPoolingResidualBlock(blk, n, X, Y, x, mask)
+    assert close(got[mask > 0], want[mask > 0], scale=1e-4)
+    import pointwise_ref as ref
+
+    xs, resid, w1, s1, b1, w2, s2, b2, m = ref.make_case(rng, 81, 192, 384, 192)
+    plain = nn.testEvaluatePointwisePair(1, 9, 9, "fp32", xs, resid, w1, s1, b1, 2, w2, s2, b2, 2, m, False)  # the two plain launches
+    assert all(np.isfinite(o).all() for o in plain)
     with pytest.raises(nn.KatamxError) as e:
-        nn.testEvaluateConv(_cw(rng, 4, 4, 3), 1, 5, 5, "fp32", rng.standard_normal((1, 5, 5, 4)).astype(np.float32))
+        nn.testEvaluatePointwisePair(1, 9, 9, "fp32", xs, resid, w1, s1, b1, 2, w2, s2, b2, 2, m, True)
     assert e.value.code == capi.KMX_ERR_UNSUPPORTED
 
 

@@ -20,7 +20,8 @@ def run(*args, timeout=600, binary="katago_hip"):
 
 
 def test_nn_layer_known_answers_on_hip():
-    """cpp/tests/testnn.cpp with its fp16 tolerance 0.03*max(|x|,3) (:8-15); the fp32 variants report unsupported."""
+    """cpp/tests/testnn.cpp with its fp16 tolerance 0.03*max(|x|,3) (:8-15) and, since round 5, its fp32 variants at their own (the
+    device serves useFP16 = false)."""
     rc, out = run("runnnlayertests")
     assert rc == 0, out[-3000:]
     assert "Test failed" not in out, out[-3000:]
@@ -161,6 +162,35 @@ def test_oracle_agrees_with_reference_opencl_backend(tmp_path):
     assert margins["fp32"] < 0.05 and margins["batched fp32"] < 0.05, (margins, out[-1500:])
     if r.returncode != 0:
         print("katago_opencl testgpuerror exit code %d (its own fp16-vs-fp32 check); margins %s" % (r.returncode, margins))
+
+
+def test_reference_gpuerror_as_the_reference_runs_it(tmp_path):
+    """`testgpuerror` builds TWO evaluators on the device (command/gputest.cpp:122-133): the configured one and an fp32 one
+    (useFP16 = false). Round 5: the backend serves fp32 (KMX_PREC_FP32 -> conv_f32.hip and the small kernels on float), so the command
+    runs as the reference runs it on its own backends - no precision override. Reference values by the oracle in the role of the Eigen
+    build. Exit code 0: every statistic within its limit - the fp32 evaluator against the strict fp32 limits, the default (fp16 with
+    the 1/8 range transform) against the reduced-precision ones; the fp32 evaluator sits at fp32 rounding of the oracle (the reference's
+    own OpenCL backend: 0.0009x of the limit)."""
+    if not os.path.exists(G170):
+        pytest.skip("g170 net not packaged")
+    cfg = tmp_path / "bench.cfg"
+    cfg.write_text(BENCH_CFG)
+    ref = str(tmp_path / "ref.txt")
+    args = ["testgpuerror", "-model", G170, "-config", str(cfg), "-boardsize", "9", "-quick", "-reference-file", ref]
+    r = subprocess.run([ref_binary("katago_oracle")] + args, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0 and os.path.getsize(ref) > 100000, (r.stdout + r.stderr)[-2000:]
+    r = subprocess.run([ref_binary("katago_hip")] + args, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    out = r.stdout + r.stderr
+    assert "Loaded reference values for" in out, out[-3000:]
+    margins = {k: float(v) for k, v in re.findall(r": ((?:batched )?(?:fp32|current cfg)) error vs reference closest margin:\s+([\d.eE+-]+)x of limit", out)}
+    assert len(margins) == 4 and r.returncode == 0, (margins, out[-3000:])
+    assert margins["fp32"] < 0.05 and margins["batched fp32"] < 0.05, margins  # fp32 rounding of the oracle's values
+    assert margins["current cfg"] <= 0.25 and margins["batched current cfg"] <= 0.25, margins
+    keep = os.path.join(REPO, "gpurun_out")
+    if os.path.isdir(keep):
+        with open(os.path.join(keep, "testgpuerror_g170_fp32_evaluator.txt"), "w") as f:
+            f.write("katago_hip testgpuerror -quick on g170-b6c96 9x9, no precision override (fp32 evaluator on the device + the default): margins "
+                    "(x of the reference's limits) %s\n" % margins)
 
 
 @pytest.mark.parametrize("prec", ["auto", "fp16", "bf16"])

@@ -47,6 +47,8 @@ NEAR_TIE = 2.0
     ("auto", dict(searches=130, near_tie=NEAR_TIE, same_best=0.97, best_share_max=0.08, best_share_mean=0.01, tv_mean=0.015, root_util_max=4.0, root_util_mean=0.3)),
     ("fp16", dict(searches=130, near_tie=NEAR_TIE, same_best=0.97, best_share_max=0.08, best_share_mean=0.01, tv_mean=0.015, root_util_max=4.0, root_util_mean=0.3)),
     ("bf16", dict(searches=115, same_best=0.95, best_share_max=1.0, best_share_mean=0.04, tv_mean=0.06, root_util_max=15.0, root_util_mean=1.5)),
+    # fp32 on the device (round 5, KMX_PREC_FP32): no 16-bit rounding anywhere - held to the fp16 limits at most, figures in the record
+    ("fp32", dict(searches=130, near_tie=NEAR_TIE, same_best=0.97, best_share_max=0.08, best_share_mean=0.01, tv_mean=0.015, root_util_max=4.0, root_util_mean=0.3)),
 ])
 def test_fixed_seed_search_visit_counts_match_the_reference_golden(tmp_path, precision, limits):
     if not os.path.exists(G170):
