@@ -37,6 +37,10 @@ def test_latest_completion_catches_a_wrong_count(tmp_path):
     ], pw2_mutations=[
         # the persistent seam kernel: phase 2 of a part lets one request more stay in flight than its loads and stores account for
         (r"waitVmSel\(G::nR\(q\) \+ 2\);", "waitVmSel(G::nR(q) + 2 + 1);", 1),
+    ], pw3_mutations=[
+        # the seam kernel with resident weights: the wait for the next tile's X lets one request more stay in flight than a work-group's
+        # first tile issues after it - the last chunk of that X may then land after barrier BA1 has published it
+        (r"static constexpr int VM_AFTER_X = N_RS \+ N_RS \+ N_S1S \+ N_S1S;", "static constexpr int VM_AFTER_X = N_RS + N_RS + N_S1S + N_S1S + 1;", 1),
     ])
     runs = run_parallel([conv_only(lib, {"KMX_EMU_LATE_DMA": late}) for late in ("0", "1")])
     (rc0, so0, se0), (rc1, so1, se1) = runs
@@ -58,12 +62,14 @@ def test_latest_completion_catches_a_wrong_count(tmp_path):
     # small case reads it: the defect must show in at least one case - the two-board 19x19 one in practice - and never with immediate copies)
     assert all(ok(v) for v in c0.values()) and not all(ok(v) for v in c1.values()), (c0, c1)
     # the seam kernel with its defect: right with immediate copies, wrong when a W2 slab may land as late as the count allows
-    runs = run_parallel([([sys.executable, "-c", PW2_CODE, lib], dict(os.environ, KMX_PW_GRID="1", KMX_EMU_LATE_DMA=late_)) for late_ in ("0", "1")])
-    (rc0, so0, se0), (rc1, so1, se1) = runs
-    assert rc0 == 0 and rc1 == 0, (so0 + se0 + so1 + se1)[-3000:]
-    r0, r1 = json.loads(so0.split("RESULT ")[1]), json.loads(so1.split("RESULT ")[1])
-    print("seam, one request too generous: immediate", r0["same"], "latest", r1["same"])
-    assert all(r0["same"]) and not all(r1["same"]), (r0, r1)
+    for kern in ("2", "3"):  # round 3's persistent kernel, round 5's with resident weights
+        runs = run_parallel([([sys.executable, "-c", PW2_CODE, lib], dict(os.environ, KMX_PW_KERNEL=kern, KMX_PW_GRID="1", KMX_EMU_LATE_DMA=late_))
+                             for late_ in ("0", "1")])
+        (rc0, so0, se0), (rc1, so1, se1) = runs
+        assert rc0 == 0 and rc1 == 0, (so0 + se0 + so1 + se1)[-3000:]
+        r0, r1 = json.loads(so0.split("RESULT ")[1]), json.loads(so1.split("RESULT ")[1])
+        print("seam kernel %s, one request too generous: immediate" % kern, r0["same"], "latest", r1["same"])
+        assert all(r0["same"]) and not all(r1["same"]), (kern, r0, r1)
 
 
 CW12_CODE = r"""

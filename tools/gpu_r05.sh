@@ -47,6 +47,11 @@ search)
   timeout 900 python -m pytest "tests/test_gpu_search_fixed_seed.py" -m gpu -q -p no:cacheprovider -s 2>&1 | grep -v "^$" | tail -30 | tee $OUT/pytest.log
   cp gpurun_out/search_fixed_seed_*.txt gpurun_out/search_fixed_seed_*_output.txt.gz $OUT/ 2>/dev/null
   ;;
+fp32)
+  timeout 1200 python -m pytest tests/test_gpu_layers.py::test_fp32_mode_layers "tests/test_gpu_model.py::test_model_vs_oracle" tests/test_gpu_reference_harness.py::test_reference_gpuerror_as_the_reference_runs_it \
+     tests/test_gpu_reference_harness.py::test_nn_layer_known_answers_on_hip "tests/test_gpu_search_fixed_seed.py" -k "fp32 or gpuerror or known_answers" -m gpu -q -p no:cacheprovider -s 2>&1 | grep -v "^$" | tail -40 | tee $OUT/pytest.log
+  cp gpurun_out/search_fixed_seed_fp32.txt gpurun_out/testgpuerror_g170_fp32_evaluator.txt $OUT/ 2>/dev/null
+  ;;
 small)
   timeout 300 python tools/small_batch_scan.py 2>&1 | grep SCAN | tee $OUT/small_batch_scan.txt
   for n in 1 8 16 24 32 42 64; do b $OUT "b18 device-resident batch $n" A=1 -- --batch $n --steps 60 --warmup 10 --no-profile; done
