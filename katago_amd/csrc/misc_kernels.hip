@@ -44,6 +44,10 @@ __global__ __launch_bounds__(BT) void inputExpandKernel(const InputArgs a) {
   const int sym = a.symmetry ? a.symmetry[n] : 0;
   typename TR::T* dst = (typename TR::T*)a.out + (size_t)n * S * KCHUNK;
   float localMask = 0.0f;
+  typedef typename TR::V8 V8;
+  // Per cell: ALL of the cell's loads first (22 bytes, one per bit plane, or 22 consecutive floats), then four vector stores of the
+  // 32-channel row. (Until round 5 this was a per-channel loop of a load and a 2-byte store: the stores may alias the loads as far as the
+  // compiler knows, so every channel waited out its own memory round trip - 22 of them in a row, 33 us per launch whatever the batch.)
   if(a.packed != nullptr) {
     // bit planes: plane c, cell p = bit (7 - p%8) of byte p/8 (packBits, dataio/trainingwrite.cpp:314-337)
     const int PB = (S + 7) / 8;
@@ -51,14 +55,17 @@ __global__ __launch_bounds__(BT) void inputExpandKernel(const InputArgs a) {
     for(int p = tid; p < S; p += BT) {
       const int h = p / a.X, w = p - h * a.X;
       const int q = symDst(h, w, a.Y, a.X, sym, false);
-      typename TR::T* dp = dst + (size_t)q * KCHUNK;
       const int byte = p >> 3, shift = 7 - (p & 7);
-      float m = 0.0f;
-      for(int c = 0; c < KCHUNK; c++) {
-        const float v = c < a.cin ? (float)((src[(size_t)c * PB + byte] >> shift) & 1) : 0.0f;
-        dp[c] = TR::fromFloat(v);
-        if(c == 0) m = v;  // mask = input channel 0 (eigenbackend.cpp:2181)
-      }
+      unsigned char b[KCHUNK];
+#pragma unroll
+      for(int c = 0; c < KCHUNK; c++) b[c] = c < a.cin ? src[(size_t)c * PB + byte] : (unsigned char)0;
+      V8 row[KCHUNK / 8];
+#pragma unroll
+      for(int c = 0; c < KCHUNK; c++) row[c >> 3][c & 7] = TR::fromFloat((float)((b[c] >> shift) & 1));
+      typename TR::T* dp = dst + (size_t)q * KCHUNK;
+#pragma unroll
+      for(int k = 0; k < KCHUNK / 8; k++) *(V8*)(dp + 8 * k) = row[k];
+      const float m = (float)((b[0] >> shift) & 1);  // mask = input channel 0 (eigenbackend.cpp:2181)
       a.mask[(size_t)n * S + q] = m;
       localMask += m;
     }
@@ -69,9 +76,16 @@ __global__ __launch_bounds__(BT) void inputExpandKernel(const InputArgs a) {
       const int h = p / a.X, w = p - h * a.X;
       const int q = symDst(h, w, a.Y, a.X, sym, false);
       const float* sp = src + (size_t)p * a.cin;
+      float v[KCHUNK];
+#pragma unroll
+      for(int c = 0; c < KCHUNK; c++) v[c] = c < a.cin ? sp[c] : 0.0f;
+      V8 row[KCHUNK / 8];
+#pragma unroll
+      for(int c = 0; c < KCHUNK; c++) row[c >> 3][c & 7] = TR::fromFloat(v[c]);
       typename TR::T* dp = dst + (size_t)q * KCHUNK;
-      for(int c = 0; c < KCHUNK; c++) dp[c] = TR::fromFloat(c < a.cin ? sp[c] : 0.0f);
-      const float m = sp[0];  // mask = input channel 0 (eigenbackend.cpp:2181)
+#pragma unroll
+      for(int k = 0; k < KCHUNK / 8; k++) *(V8*)(dp + 8 * k) = row[k];
+      const float m = v[0];  // mask = input channel 0 (eigenbackend.cpp:2181)
       a.mask[(size_t)n * S + q] = m;
       localMask += m;
     }
@@ -193,6 +207,10 @@ __global__ __launch_bounds__(GV_THREADS) void gpoolApplyVecKernel(const GPoolArg
   HIP_DYNAMIC_SHARED(float, sm)
   const int n = blockIdx.x, tid = threadIdx.x;
   const int S = a.S, G = a.G, R = a.R;
+  // Round 5: grid y = parts. Every part pools the board and multiplies (the same arithmetic in the same order, a few KB from L2), then
+  // applies bias + BN + activation to ITS share of the cells: the last phase is 46 k activations per board on one CU - 8.5 us of vector
+  // ALU - and at small batches most CUs have nothing to do. Values do not depend on the split.
+  const int pBegin = (int)((long long)S * blockIdx.y / gridDim.y), pEnd = (int)((long long)S * (blockIdx.y + 1) / gridDim.y);
   const int NG = G / 8;                    // channel groups of 8
   const int cellGroups = GV_THREADS / NG;  // threads striding over the board per channel group
   float* partSum = sm;                     // [cellGroups][G]
@@ -253,7 +271,7 @@ __global__ __launch_bounds__(GV_THREADS) void gpoolApplyVecKernel(const GPoolArg
     feat[2 * G + tid] = tm;
   }
   __syncthreads();
-  if(a.featOut != nullptr)
+  if(a.featOut != nullptr && blockIdx.y == 0)
     for(int i = tid; i < 3 * G; i += GV_THREADS) a.featOut[(size_t)n * 3 * G + i] = feat[i];
   // [3G] x [3G][R] with every thread busy: the k range is split over KG thread groups (partials in LDS). One thread per
   // output looping over all 3G weights is a chain of ~200 L2 round trips and was a third of this kernel's 70 us.
@@ -290,13 +308,13 @@ __global__ __launch_bounds__(GV_THREADS) void gpoolApplyVecKernel(const GPoolArg
       bi[k] = a.bias[rv * 8 + k];
     }
     T* const col = (T*)a.r + cell0 * a.rStride + a.rOffset + rv * 8;
-    for(int p0 = tid / RV; p0 < S; p0 += pStep * UN) {
+    for(int p0 = pBegin + tid / RV; p0 < pEnd; p0 += pStep * UN) {
       V8 x[UN];
       float on[UN];
 #pragma unroll
       for(int u = 0; u < UN; u++) {
         const int p = p0 + u * pStep;
-        if(p < S) {
+        if(p < pEnd) {
           x[u] = *(const V8*)(col + (size_t)p * a.rStride);
           on[u] = maskB[p];
         }
@@ -304,7 +322,7 @@ __global__ __launch_bounds__(GV_THREADS) void gpoolApplyVecKernel(const GPoolArg
 #pragma unroll
       for(int u = 0; u < UN; u++) {
         const int p = p0 + u * pStep;
-        if(p < S) {
+        if(p < pEnd) {
           V8 y;
 #pragma unroll
           for(int k = 0; k < 8; k++) {
@@ -317,9 +335,9 @@ __global__ __launch_bounds__(GV_THREADS) void gpoolApplyVecKernel(const GPoolArg
     }
     return;
   }
-  const int total = S * RV;
+  const int total = (pEnd - pBegin) * RV;
   for(int i = tid; i < total; i += GV_THREADS) {
-    const int p = i / RV, rv = i - p * RV;
+    const int p = pBegin + i / RV, rv = i % RV;
     T* ptr = (T*)a.r + (cell0 + p) * a.rStride + a.rOffset + rv * 8;
     V8 x = *(const V8*)ptr;
     const bool on = maskB[p] == 1.0f;
@@ -466,11 +484,14 @@ __global__ __launch_bounds__(BT) void policyFinalVecKernel(const PolicyArgs a) {
   float* w2s = sm;               // [P][NP]
   float* hidden = w2s + P * NP;  // [H]
   float* partial = hidden + (H > 0 ? H : 1);  // [KG][H]
+  float* wp2s = partial + 8 * (H > 0 ? H : 1);  // [H][NP]: the second pass matmul's weights (round 5: one thread walked them in global memory)
   const int sym = a.symmetry ? a.symmetry[n] : 0;
   const float opt = a.optimism ? a.optimism[n] : 0.0f;
   const bool blend = (NP == 2 || NP == 4);  // channels 0,1 = policy, optimistic policy (eigenbackend.cpp:2553)
   float* out = a.out + (size_t)n * (S + 1);
   for(int i = tid; i < P * NP; i += BT) w2s[i] = a.w2[i];
+  if(H > 0)
+    for(int i = tid; i < H * NP; i += BT) wp2s[i] = a.wPass2[i];
   __syncthreads();
   const int PV = P / 8;
   for(int p = tid; p < S; p += BT) {
@@ -511,8 +532,8 @@ __global__ __launch_bounds__(BT) void policyFinalVecKernel(const PolicyArgs a) {
     if(tid == 0) {
       float p0 = 0.0f, p1 = 0.0f;
       for(int j = 0; j < H; j++) {
-        p0 += hidden[j] * a.wPass2[(size_t)j * NP];
-        if(blend) p1 += hidden[j] * a.wPass2[(size_t)j * NP + 1];
+        p0 += hidden[j] * wp2s[j * NP];
+        if(blend) p1 += hidden[j] * wp2s[j * NP + 1];
       }
       out[S] = blend ? p0 + (p1 - p0) * opt : p0;
     }
@@ -537,26 +558,44 @@ __global__ __launch_bounds__(BT) void valueFinalVecKernel(const ValueArgs a) {
   const int NG = V1 / 8;          // channel groups of 8
   const int cellGroups = BT / NG;  // threads striding over the board per channel group
   const int KG = BT / V2 > 0 ? (BT / V2 < 8 ? BT / V2 : 8) : 1;
-  // layout: feat[3*V1], hid[V2], wown[V1], part[max(cellGroups*V1, KG*V2)]
+  // layout: feat[3*V1], hid[V2], wown[V1], w3s[3*V2], wsvs[6*V2], part[max(cellGroups*V1, KG*V2)]
   float* feat = sm;
   float* hid = feat + 3 * V1;
   float* wown = hid + V2;
-  float* part = wown + V1;
+  float* w3s = wown + V1;
+  float* wsvs = w3s + 3 * V2;
+  float* part = wsvs + 6 * V2;
   const int sym = a.symmetry ? a.symmetry[n] : 0;
   const size_t cell0 = (size_t)n * S;
   const T* vb = (const T*)a.v + cell0 * a.vStride + a.vOffset;
+  // Round 5: every small weight vector the tail needs comes into LDS HERE, in one memory round trip that the pooling loads share - the
+  // final 3- and NSV-wide products were 128 dependent global loads on nine threads, the longest single stretch of this kernel's 39 us
   for(int i = tid; i < V1; i += BT) wown[i] = a.wOwn[i];
-  // pooling (poolRowsValueHead, eigenbackend.cpp:179-197)
+  for(int i = tid; i < 3 * V2; i += BT) w3s[i] = a.w3[i];
+  for(int i = tid; i < a.NSV * V2; i += BT) wsvs[i] = a.wsv[i];
+  // pooling (poolRowsValueHead, eigenbackend.cpp:179-197): a thread's loads in batches of UNP, all of a batch in flight at once (the sums
+  // are taken in the same order as one load at a time)
   {
     const int cg = tid % NG, grp = tid / NG;
     if(grp < cellGroups) {
       float s[8];
 #pragma unroll
       for(int i = 0; i < 8; i++) s[i] = 0.0f;
-      for(int p = grp; p < S; p += cellGroups) {
-        const V8 x = *(const V8*)(vb + (size_t)p * a.vStride + cg * 8);
+      constexpr int UNP = 6;
+      for(int p0 = grp; p0 < S; p0 += cellGroups * UNP) {
+        V8 x[UNP];
 #pragma unroll
-        for(int i = 0; i < 8; i++) s[i] += TR::toFloat(x[i]);
+        for(int u = 0; u < UNP; u++) {
+          const int p = p0 + u * cellGroups;
+          if(p < S) x[u] = *(const V8*)(vb + (size_t)p * a.vStride + cg * 8);
+        }
+#pragma unroll
+        for(int u = 0; u < UNP; u++) {
+          if(p0 + u * cellGroups < S) {
+#pragma unroll
+            for(int i = 0; i < 8; i++) s[i] += TR::toFloat(x[u][i]);
+          }
+        }
       }
 #pragma unroll
       for(int i = 0; i < 8; i++) part[grp * V1 + cg * 8 + i] = s[i];
@@ -592,14 +631,14 @@ __global__ __launch_bounds__(BT) void valueFinalVecKernel(const ValueArgs a) {
   __syncthreads();
   if(tid < 3) {
     float s = 0.0f;
-    for(int j = 0; j < V2; j++) s += hid[j] * a.w3[(size_t)j * 3 + tid];
+    for(int j = 0; j < V2; j++) s += hid[j] * w3s[j * 3 + tid];
     a.value[(size_t)n * 3 + tid] = s + a.b3[tid];
   }
   else if(tid >= 32 && tid < 32 + 6) {
     const int k = tid - 32;
     float s = 0.0f;
     if(k < a.NSV) {
-      for(int j = 0; j < V2; j++) s += hid[j] * a.wsv[(size_t)j * a.NSV + k];
+      for(int j = 0; j < V2; j++) s += hid[j] * wsvs[j * a.NSV + k];
       s += a.bsv[k];
     }
     a.score[(size_t)n * 6 + k] = s;
@@ -681,7 +720,9 @@ hipError_t launchGPoolApply(int dtype, const GPoolArgs& a, hipStream_t stream) {
   if(vec) {
     const int cellGroups = GV_THREADS / (a.G / 8);
     size_t lds = sizeof(float) * ((size_t)2 * cellGroups * a.G + 3 * a.G + a.R);
-    KMX_DISPATCH(dtype, gpoolApplyVecKernel, dim3(a.N), dim3(GV_THREADS), lds, stream, a);
+    // parts per board (the kernel's last phase): while the boards leave compute units idle
+    const int parts = a.N >= 128 ? 1 : a.N >= 48 ? 2 : 4;
+    KMX_DISPATCH(dtype, gpoolApplyVecKernel, dim3(a.N, parts), dim3(GV_THREADS), lds, stream, a);
   }
   size_t lds = sizeof(float) * (2 * BT + 3 * a.G + a.R);
   KMX_DISPATCH(dtype, gpoolApplyKernel, dim3(a.N), dim3(BT), lds, stream, a);
@@ -689,7 +730,7 @@ hipError_t launchGPoolApply(int dtype, const GPoolArgs& a, hipStream_t stream) {
 hipError_t launchPolicyFinal(int dtype, const PolicyArgs& a, hipStream_t stream) {
   if(a.P % 8 == 0 && a.pStride % 8 == 0 && a.pOffset % 8 == 0 && a.passHidden <= BT) {
     const int H = a.passHidden > 0 ? a.passHidden : 1;
-    size_t lds = sizeof(float) * ((size_t)a.P * a.NP + H + (size_t)8 * H);
+    size_t lds = sizeof(float) * ((size_t)a.P * a.NP + H + (size_t)8 * H + (size_t)H * a.NP);
     KMX_DISPATCH(dtype, policyFinalVecKernel, dim3(a.N), dim3(BT), lds, stream, a);
   }
   size_t lds = sizeof(float) * (a.passHidden > 0 ? a.passHidden : 1);
@@ -699,7 +740,7 @@ hipError_t launchValueFinal(int dtype, const ValueArgs& a, hipStream_t stream) {
   if(a.V1 % 8 == 0 && a.V1 / 8 <= BT && a.vStride % 8 == 0 && a.vOffset % 8 == 0 && a.V2 <= BT) {
     const size_t cellGroups = BT / (a.V1 / 8);
     const size_t partN = cellGroups * a.V1 > (size_t)8 * a.V2 ? cellGroups * a.V1 : (size_t)8 * a.V2;
-    size_t lds = sizeof(float) * ((size_t)3 * a.V1 + a.V2 + a.V1 + partN);
+    size_t lds = sizeof(float) * ((size_t)3 * a.V1 + a.V2 + a.V1 + 9 * (size_t)a.V2 + partN);
     KMX_DISPATCH(dtype, valueFinalVecKernel, dim3(a.N), dim3(BT), lds, stream, a);
   }
   size_t lds = sizeof(float) * (BT + 3 * a.V1 + a.V2);

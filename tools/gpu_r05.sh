@@ -52,6 +52,13 @@ fp32)
      tests/test_gpu_reference_harness.py::test_nn_layer_known_answers_on_hip "tests/test_gpu_search_fixed_seed.py" -k "fp32 or gpuerror or known_answers" -m gpu -q -p no:cacheprovider -s 2>&1 | grep -v "^$" | tail -40 | tee $OUT/pytest.log
   cp gpurun_out/search_fixed_seed_fp32.txt gpurun_out/testgpuerror_g170_fp32_evaluator.txt $OUT/ 2>/dev/null
   ;;
+carriers)
+  # configs[2] (8 games x 8 search threads): how many of a game's 8 descents share an OS thread (KATAMX_LEAVES_PER_THREAD); 50 s each, rows/s only
+  for lpt in 8 4 2 1; do
+    tools/selfplay_full_games.sh carriers_$lpt 8 8 $lpt 8 50 > /dev/null 2>&1
+    cat gpurun_out/selfplay_full_carriers_$lpt.txt | tee -a $OUT/carriers.txt
+  done
+  ;;
 small)
   timeout 300 python tools/small_batch_scan.py 2>&1 | grep SCAN | tee $OUT/small_batch_scan.txt
   for n in 1 8 16 24 32 42 64; do b $OUT "b18 device-resident batch $n" A=1 -- --batch $n --steps 60 --warmup 10 --no-profile; done
