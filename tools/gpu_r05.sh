@@ -60,8 +60,12 @@ carriers)
   done
   ;;
 small)
+  timeout 900 python -m pytest tests/test_gpu_layers.py "tests/test_gpu_model.py::test_model_vs_oracle" "tests/test_gpu_model.py::test_full_batch_properties" tests/test_gpu_fuzz.py -m gpu -q -p no:cacheprovider 2>&1 | tail -3 | tee $OUT/parity.log
   timeout 300 python tools/small_batch_scan.py 2>&1 | grep SCAN | tee $OUT/small_batch_scan.txt
-  for n in 1 8 16 24 32 42 64; do b $OUT "b18 device-resident batch $n" A=1 -- --batch $n --steps 60 --warmup 10 --no-profile; done
+  for n in 1 8 32 256; do
+    echo "== batch $n: per-class launch times (hipEvent pair per launch, one stream)" | tee -a $OUT/kernel_classes.txt
+    timeout 200 python3 bench.py --no-cpu-baseline --no-callers --batch $n --steps 30 --warmup 5 2>>$OUT/err.txt | grep -o '"kernel_avg_launch_us": {[^}]*}\|"value": [0-9.]*\|"ms_per_step": [0-9.]*' | tr '\n' ' ' | tee -a $OUT/kernel_classes.txt; echo | tee -a $OUT/kernel_classes.txt
+  done
   ;;
 esac
 done
