@@ -52,6 +52,13 @@ fp32)
      tests/test_gpu_reference_harness.py::test_nn_layer_known_answers_on_hip "tests/test_gpu_search_fixed_seed.py" -k "fp32 or gpuerror or known_answers" -m gpu -q -p no:cacheprovider -s 2>&1 | grep -v "^$" | tail -40 | tee $OUT/pytest.log
   cp gpurun_out/search_fixed_seed_fp32.txt gpurun_out/testgpuerror_g170_fp32_evaluator.txt $OUT/ 2>/dev/null
   ;;
+games)
+  # configs[2], games/hour as command/selfplay.cpp:388-389 defines it: three runs of 8 full-length games (8 game threads x 8 search threads on fibers)
+  for run in 1 2 3; do
+    tools/selfplay_full_games.sh games_run$run 8 8 8 8 400 > /dev/null 2>&1
+    cat gpurun_out/selfplay_full_games_run$run.txt | tee -a $OUT/games_per_hour_three_runs.txt
+  done
+  ;;
 carriers)
   # configs[2] (8 games x 8 search threads): how many of a game's 8 descents share an OS thread (KATAMX_LEAVES_PER_THREAD); 50 s each, rows/s only
   for lpt in 8 4 2 1; do
