@@ -18,6 +18,7 @@
 #define KMX_CONV_SMALL_KERNEL_H_
 
 #include <atomic>
+#include <type_traits>
 
 #include "conv_kernel.h"
 
@@ -87,16 +88,104 @@ static_assert(imagesLandWithSlabs<true, 0>() && imagesLandWithSlabs<false, 0>() 
 static_assert(SG<false, 1>::LDS_BYTES <= 160 * 1024 && 2 * SG<true, 0>::LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
 static_assert(SG<true, 0>::virtualImg() == 1 && SG<false, 1>::virtualImg() == 4, "prologue bookkeeping below");
 
+// ---- REGW (round 5): the weights never pass through LDS ------------------------------------------------------------------------------
+// What bounds a step of the shape above is the LDS port: per k half the four multiplying waves read 4 x (1 KB of weight fragment + MTW KB
+// of image fragments) - 16 KB = 128 cycles at 128 B/cycle for 96 cycles of matrix work (MTW = 3), 8 KB = 64 cycles for 32 (MTW = 1) - and
+// the SAME weight fragment four times over. Here every multiplying wave loads its weight fragments straight from global memory into
+// registers (global_load_dwordx4, the lane's 16 bytes of the pre-swizzled slab row; the four waves' requests hit in the vector L1), a whole
+// chunk ahead: a ring of 18 fragments = 72 registers, reloaded one k half after its use. What is left in LDS is the board image: three
+// buffers (chunk c read, c + 1 published, c + 2 in flight), fetched by waves 4-7 as before. No slab ring, so nothing is published per
+// step: ONE barrier per chunk instead of nine, the multiplying waves run a chunk's 18 k halves back to back with their image fragments read
+// NSET - 1 k halves ahead. Same MFMAs per output in the same K order (chunk, tap, k half), same epilogue: bit-identical to the other shapes.
+struct RWG {
+  static constexpr int D = 0, NSW = 0;
+  static constexpr int NSA = 3, DIST = 2;
+  static_assert((DIST + 1) * KCHUNK * 2 <= DEVBUF_TAIL_BYTES, "the image requests' run-ahead must stay inside the readable tail of a DevBuf");
+  static constexpr int RING_OFFSET = NSA * ACT_BYTES;
+  static constexpr int SLACK_OFFSET = RING_OFFSET;
+  static constexpr int MASK_OFFSET = SLACK_OFFSET + SLACK_BYTES;
+  static constexpr int PARAM_OFFSET = MASK_OFFSET + MASK_BYTES;
+  static constexpr int LDS_BYTES = PARAM_OFFSET + PARAM_BYTES;
+  static constexpr int NHS = 2 * NT;  // k halves per chunk = weight fragments in the register ring
+};
+static_assert(RWG::LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
+
+// REGW: a weight fragment from global memory into registers (the lane's 16 bytes at uniform base + lane offset), and the wait before
+// its use - hand-written, see the kernel. The wait takes the fragment as an in/out operand: no use can be scheduled ahead of it.
+template <class V8>
+__device__ __forceinline__ void gloadFrag(V8& dst, const char* base, unsigned off) {
+#if defined(__AMDGCN__)
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(off), "s"(base));
+#else
+  dst = *(const V8*)(base + off);  // (the CPU emulation enters it in the wave's in-order queue: tests/test_engine_emulated.py)
+#endif
+}
+template <int N, class V8>
+__device__ __forceinline__ void waitFrag(V8& frag) {
+#if defined(__AMDGCN__)
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(frag) : "n"(N));
+#else
+  (void)frag;  // (the CPU emulation: emu::waitVm(N))
+#endif
+}
+// ... and the same for the image fragments out of LDS (ds_read_b128; a wave's LDS reads return in order): hipcc counts its own reads
+// right (s_waitcnt lgkmcnt(5)) until the loop holds an inline-asm statement - with the loads above in the loop it drained the queue
+// (lgkmcnt(0)) every other k half, i.e. waited out a whole LDS round trip there.
+template <class V8>
+__device__ __forceinline__ void ldsReadFrag(V8& dst, unsigned addr) {
+#if defined(__AMDGCN__)
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+#else
+  dst = *(const __attribute__((address_space(3))) V8*)addr;
+#endif
+}
+template <int N, class V8>
+__device__ __forceinline__ void waitLdsFrag(V8& frag) {
+#if defined(__AMDGCN__)
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N));
+#else
+  (void)frag;
+#endif
+}
+// ... for a count that is a constant only after the k-half loop is unrolled
+template <class V8>
+__device__ __forceinline__ void waitFragSel(V8& frag, int n) {
+  switch(n) {
+    case 0: waitFrag<0>(frag); break;
+    case 1: waitFrag<1>(frag); break;
+    case 2: waitFrag<2>(frag); break;
+    case 3: waitFrag<3>(frag); break;
+    case 4: waitFrag<4>(frag); break;
+    case 5: waitFrag<5>(frag); break;
+    case 6: waitFrag<6>(frag); break;
+    case 7: waitFrag<7>(frag); break;
+    case 8: waitFrag<8>(frag); break;
+    case 9: waitFrag<9>(frag); break;
+    case 10: waitFrag<10>(frag); break;
+    case 11: waitFrag<11>(frag); break;
+    case 12: waitFrag<12>(frag); break;
+    case 13: waitFrag<13>(frag); break;
+    case 14: waitFrag<14>(frag); break;
+    case 15: waitFrag<15>(frag); break;
+    case 16: waitFrag<16>(frag); break;
+    case 17: waitFrag<17>(frag); break;  // (never asked for by the kernel: the count its tests' deliberately wrong variant asks for)
+    default: waitFrag<0>(frag); break;  // stricter than needed, never wrong
+  }
+}
+
 // PACK (the second instantiation): register allocation capped at 128 per lane so that TWO work-groups share a CU (4 waves per SIMD, 2 x 68 KB
 // of LDS) - for batches whose work-groups outnumber the CUs; the cap costs 48 bytes of scratch per lane outside the loop.
-template <class TR, bool PACK, int DEPTH, int MTW>
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ? 4 : 2, PACK ? 4 : 3))) void convSmallKernel(const ConvArgs a) {
+template <class TR, bool PACK, int DEPTH, int MTW, bool REGW, int WN>
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ? 4 : 2, PACK ? 4 : REGW ? 2 : 3))) void convSmallKernel(const ConvArgs a) {
   typedef typename TR::T T;
   typedef typename TR::V8 V8;
   typedef typename TR::V4 V4;
   extern __shared__ __attribute__((aligned(256))) char smemSmall[];
   const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smemSmall;
-  typedef SG<PACK, DEPTH> G;
+  static_assert(!REGW || (!PACK && DEPTH == 1), "the register-weights shape is one instantiation per (MTW, WN)");
+  static_assert(WN == 1 || (REGW && WN == 2 && MTW == MT), "two channel tiles per wave exist for the unsplit register-weights shape only");
+  constexpr int NTILEW = NTILE * WN;  // output channels per work-group
+  typedef std::conditional_t<REGW, RWG, SG<PACK, DEPTH>> G;
   constexpr int D = G::D, NSW = G::NSW, NSA = G::NSA, DIST = G::DIST;
   constexpr int MASK_OFFSET = G::MASK_OFFSET, PARAM_OFFSET = G::PARAM_OFFSET;
   const unsigned bufW = ldsBase + G::RING_OFFSET;
@@ -109,7 +198,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
   const int lw = wave - NCOMPUTE;        // index among the loader waves
   const int wm = wave;                   // cell-tile group of a multiplying wave
   const int n = blockIdx.y;
-  const int cout0 = blockIdx.x * NTILE;
+  const int cout0 = blockIdx.x * NTILEW;
   const int X = a.X, Y = a.Y, S = X * Y;
   const int W2 = X + 2 * HALO, HP = W2 * (Y + 2 * HALO);
   const int inC = a.inC;
@@ -138,7 +227,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
     const int idx = wave * 64 + lane;  // 0..255: scale [0,32) | bias [64,96) | per-board bias [128,160)
     const int arr = idx >> 6, c = idx & 63;
     const float* psrc = (const float*)zero;
-    if(c < NTILE) {
+    if(c < NTILEW) {
       if(arr == 0) psrc = a.scale + cout0 + c;
       else if(arr == 1) psrc = a.bias + cout0 + c;
       else if(arr == 2 && a.ncBias != nullptr) psrc = a.ncBias + (size_t)n * a.ncBiasStride + cout0 + c;
@@ -165,19 +254,42 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
       }
       srcOff[j] = off;
     }
-    const unsigned wOff = (unsigned)(lw * 64 + lane) * 16u;  // waves 4 and 5: their KiB of a slab
-    const bool slabWave = lw < 2;
-    auto issueW = [&](int step) {  // one request (waves 4, 5)
-      const bool live = step < nSteps;
-      const char* slab = wBase + (size_t)(live ? step : 0) * wSlabStride;
-      dma16(slab + wOff, live ? bufW + (unsigned)(step % NSW) * W_BYTES + (unsigned)lw * 1024u : slack);
-    };
     auto issueA = [&](int chunk, int j) {  // request j of the image of `chunk`; the pointer then moves on to the next chunk
       const bool live = chunk < nChunks;
       const unsigned off = srcOff[j];
       const char* src = (off & 0x80000000u) ? zero : inBoard + off;
       dma16(src, live ? ldsBase + (unsigned)(chunk % NSA) * ACT_BYTES + (unsigned)((j * NLOAD + lw) * 64) * 16u : slack);
       srcOff[j] = (off & 0x80000000u) ? off : off + KCHUNK * (unsigned)sizeof(T);
+    };
+    if constexpr(REGW) {
+      // Images only, a whole image per chunk: image c + 2 is requested behind the barrier at the top of chunk c (every multiplying wave is
+      // then done with image c - 1, whose buffer it takes) and waited for at the top of chunk c + 1, whose barrier publishes it - one chunk
+      // before its first read (the multiplying waves read NSET - 1 k halves ahead, across the chunk boundary). Everything this wave has
+      // in flight at a wait is one image: the counts are 0 and NPA.
+#pragma unroll
+      for(int c = 0; c < DIST; c++)
+#pragma unroll
+        for(int j = 0; j < NPA; j++) issueA(c, j);
+      waitVm<(DIST - 1) * NPA>();  // image 0 (and, older, this wave's piece of the mask) has landed; image 1 is in flight
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      for(int chunk = 0; chunk < nChunks; chunk++) {
+        waitVm<0>();  // image chunk + 1
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for(int j = 0; j < NPA; j++) issueA(chunk + DIST, j);
+      }
+      waitVm<0>();  // requests past the end went to the slack area: they must land before the LDS is released
+      return;
+    }
+    else {
+    const unsigned wOff = (unsigned)(lw * 64 + lane) * 16u;  // waves 4 and 5: their KiB of a slab
+    const bool slabWave = lw < 2;
+    auto issueW = [&](int step) {  // one request (waves 4, 5)
+      const bool live = step < nSteps;
+      const char* slab = wBase + (size_t)(live ? step : 0) * wSlabStride;
+      dma16(slab + wOff, live ? bufW + (unsigned)(step % (NSW > 0 ? NSW : 1)) * W_BYTES + (unsigned)lw * 1024u : slack);
     };
     // Fill the pipeline in the order the steady state would have: the D virtual steps -D .. -1 stand for the last D taps of a "chunk -1",
     // whose image requests would have been for image DIST - 1. So: images 0 .. DIST-2 whole, the first pieces of image DIST - 1, then per
@@ -221,6 +333,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
     }
     waitVm<0>();  // requests past the end went to the slack area: they must land before the LDS is released
     return;
+    }  // !REGW
   }
 
   // ===================================================== the multiplying waves =====================================================
@@ -248,12 +361,100 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
   auto ldsF4 = [&](unsigned addr) { return *(const __attribute__((address_space(3))) f32x4*)addr; };
   auto ldsF1 = [&](unsigned addr) { return *(const __attribute__((address_space(3))) float*)addr; };
 
-  f32x16 acc[MTW];
+  f32x16 acc[WN * MTW];  // [channel tile][cell tile]
 #pragma unroll
-  for(int pt = 0; pt < MTW; pt++)
+  for(int pt = 0; pt < WN * MTW; pt++)
 #pragma unroll
     for(int r = 0; r < 16; r++) acc[pt][r] = 0.0f;
 
+  if constexpr(REGW) {
+    // ---- weights in registers: a chunk's 18 fragments a whole chunk ahead, one barrier per chunk ----
+    constexpr int NHS = RWG::NHS;
+    constexpr int NSET = MTW == 1 ? 6 : 3;  // image-fragment register sets; the reads run NSET - 1 k halves ahead of their MFMAs
+    static_assert(NHS % NSET == 0, "the set of a k half must be a compile-time index");
+    // the ring of weight fragments: R k halves of WN fragments each. One channel tile per wave: a whole chunk (18 x 4 registers); two: half
+    // a chunk (9 x 8 registers, and a k half is twice as long)
+    constexpr int R = WN == 1 ? NHS : NHS / 2;
+    static_assert(NHS % R == 0 && (R - 2) * WN <= 17, "ring slots are compile-time indices; waitFragSel knows counts up to 17");
+    const char* const wTile = (const char*)a.w + (size_t)cout0 * ROWB;
+    const size_t wSlabStride = (size_t)a.coutPad * ROWB;
+    unsigned wOffLane[2];  // the lane's 16 bytes of its slab row: what the LDS-DMA shapes read back from the linear copy of the slab
+#pragma unroll
+    for(int kk = 0; kk < 2; kk++) wOffLane[kk] = (unsigned)(lane & 31) * ROWB + (((kk * 2 + khalf) ^ wXor) << 4);
+    // The loads and their waits are hand-written: left to the compiler, a load whose use lies beyond the loop's back edge makes hipcc drain
+    // the queue (s_waitcnt vmcnt(0)) at the top of every chunk - a memory round trip per chunk. A wave's loads return in order, WN
+    // fragments are requested per k half, R - 1 k halves before their use: in the steady state the requests of R - 2 k halves are younger.
+    V8 wf[R][WN];
+    auto loadW = [&](int slot, const char* chunkBase, int hs) {  // the WN fragments of k half hs of the chunk at chunkBase
+#pragma unroll
+      for(int wn = 0; wn < WN; wn++) gloadFrag(wf[slot][wn], chunkBase + (size_t)(hs >> 1) * wSlabStride + (size_t)(wn * NTILE * ROWB), wOffLane[hs & 1]);
+    };
+    const char* wCur = wTile;  // this chunk's nine slabs
+#pragma unroll
+    for(int hs = 0; hs + 1 < R; hs++) loadW(hs, wCur, hs);  // k half R - 1 follows in the first k half (the ring's rule below)
+    waitVm<0>();  // this wave's mask and parameter requests (and, younger, the fragments - which the first MFMA needs anyway)
+    __builtin_amdgcn_s_barrier();  // image 0, the mask and the parameters are published
+    asm volatile("" ::: "memory");
+    V8 af[NSET][MTW];
+    // address of the image fragment of k half `hs` (0 .. NHS-1, or past the end: the next chunk's) of the chunk whose buffer is curA
+    auto fragAddr = [&](int hs, unsigned curA, unsigned nextA, int pt) {
+      const int h = hs < NHS ? hs : hs - NHS;
+      const int t = h >> 1;
+      const unsigned sTap = (unsigned)(((t / 3 - HALO) * W2 + (t % 3 - HALO)) * 4) + ((ldsBase + (hs < NHS ? curA : nextA)) >> 4);
+      const unsigned q4 = aRow4[pt] + sTap;
+      return ((q4 << 4) | ((q4 ^ c40) & 0x30u)) ^ ((h & 1) ? 0x20u : 0u);
+    };
+#pragma unroll
+    for(int hs = 0; hs < NSET - 1; hs++)
+#pragma unroll
+      for(int pt = 0; pt < MTW; pt++) ldsReadFrag(af[hs][pt], fragAddr(hs, 0u, ACT_BYTES, pt));
+    int chunk = 0;
+    // one chunk: the barrier, then 18 k halves. LAST: the last chunk requests nothing beyond its own fragments (nothing stays in flight into
+    // the epilogue, whose registers a late fragment would overwrite) and its waits count down with what is left in flight.
+    auto chunkBody = [&](auto lastTag) {
+      constexpr bool LAST = decltype(lastTag)::value != 0;
+      const unsigned curA = (unsigned)(chunk % NSA) * ACT_BYTES;
+      const unsigned nextA = (unsigned)((chunk + 1) % NSA) * ACT_BYTES;
+      const char* const wNext = wCur + NT * wSlabStride;
+      __builtin_amdgcn_s_barrier();  // publishes image chunk + 1; behind it the fetching waves overwrite image chunk - 1
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for(int hs = 0; hs < NHS; hs++) {
+        // k half hs: its MFMAs; behind them, one by one, the image fragments of k half hs + NSET - 1 into the set the PREVIOUS k half
+        // used, and the weight fragments of k half hs + R - 1 (this chunk's, or the next one's) into the ring slot the previous k half used
+        const int setR = (hs + NSET - 1) % NSET;
+        const int slot = hs % R;
+        // k halves whose requests are younger than this one's: R - 2 in the steady state; in the last chunk only those that lie in the chunk
+        const int younger = (!LAST || NHS - 1 - hs > R - 2) ? R - 2 : NHS - 1 - hs;
+#pragma unroll
+        for(int wn = 0; wn < WN; wn++) waitFragSel(wf[slot][wn], younger * WN);
+#pragma unroll
+        for(int pt = 0; pt < MTW; pt++) {
+          // an image fragment is read NSET - 1 k halves before its use, MTW reads per k half: MTW (NSET - 1) - 1 younger reads at every use
+          waitLdsFrag<MTW * (NSET - 1) - 1>(af[hs % NSET][pt]);
+#pragma unroll
+          for(int wn = 0; wn < WN; wn++) {
+            acc[wn * MTW + pt] = TR::mfma(wf[slot][wn], af[hs % NSET][pt], acc[wn * MTW + pt]);
+            __builtin_amdgcn_sched_barrier(0);
+            if(wn == 0) {
+              if(pt == 0) {
+                const int f = hs + R - 1;  // the k half whose fragments are requested now
+                if(f < NHS) loadW(f % R, wCur, f);
+                else if(!LAST) loadW(f % R, wNext, f - NHS);
+              }
+              ldsReadFrag(af[setR][pt], fragAddr(hs + NSET - 1, curA, nextA, pt));
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+      }
+      wCur = wNext;
+      chunk++;
+    };
+    while(chunk + 1 < nChunks) chunkBody(ActKindTag<0>());
+    chunkBody(ActKindTag<1>());
+  }
+  else {
   waitVm<0>();  // this wave's mask and parameter requests
   __builtin_amdgcn_s_barrier();  // slab 0 and image 0 are published
   asm volatile("" ::: "memory");
@@ -314,6 +515,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
     }
   }
 
+  }  // !REGW
   // ---- epilogue: conv_kernel.h's, for one 32-channel tile per wave and cell tile ----
   if(!waveActive) return;
   const unsigned maskAddr = ldsBase + MASK_OFFSET;
@@ -328,32 +530,37 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
     constexpr int KIND = decltype(kindTag)::value;
     constexpr bool RESID = decltype(residTag)::value != 0;
     u32x4 rq[2][2];
-    auto loadResid = [&](int pt, u32x4 (&dst)[2]) {
-      const T* const rrow = (const T*)a.resid + ((size_t)n * S + cellOfTile[pt]) * a.residC - a.rawBegin;
+    // q = channel tile * MTW + cell tile (one channel tile per wave everywhere but in the 64-channel register-weights shape)
+    auto loadResid = [&](int q, u32x4 (&dst)[2]) {
+      const T* const rrow = (const T*)a.resid + ((size_t)n * S + cellOfTile[q % MTW]) * a.residC - a.rawBegin;
 #pragma unroll
       for(int j = 0; j < 2; j++) {
-        const int c = cout0 + 16 * j + 8 * khalf;
+        const int c = cout0 + (q / MTW) * 32 + 16 * j + 8 * khalf;
         const T* src = (c >= a.rawBegin && c < a.rawEnd) ? rrow + c : (const T*)zero;
         dst[j] = *(const u32x4*)src;
       }
     };
     if(RESID) loadResid(0, rq[0]);
 #pragma unroll
-    for(int pt = 0; pt < MTW; pt++) {
+    for(int q = 0; q < WN * MTW; q++) {
+      const int pt = q % MTW, ct0 = cout0 + (q / MTW) * 32;
       const int cellBase = wm * (32 * MT) + (pt0 + pt) * 32;
-      if(cellBase >= S) break;  // wave-uniform
+      if(cellBase >= S) {  // wave-uniform
+        if(WN == 1) break;
+        continue;
+      }
       const bool live = cellBase + myPos < S;
       const int cell = cellOfTile[pt];
       const unsigned onBits = ldsF1(maskAddr + cell * 4) == 1.0f ? 0xffffffffu : 0u;
       T* const rawRow = rawBoard + (size_t)cell * a.rawC;
       T* const actRow = actBoard + (size_t)cell * a.actC;
-      unsigned pOff = (unsigned)(4 * khalf) * 4u;
+      unsigned pOff = (unsigned)(4 * khalf) * 4u + (unsigned)(q / MTW) * 128u;
       asm volatile("" : "+v"(pOff));
       u32x2 rp[4], op[4];
       u32x2 resP[4];
       if(RESID) {
-        if(pt + 1 < MTW) loadResid(pt + 1, rq[(pt + 1) & 1]);
-        unpair(rq[pt & 1], resP);
+        if(q + 1 < WN * MTW) loadResid(q + 1, rq[(q + 1) & 1]);
+        unpair(rq[q & 1], resP);
       }
 #pragma unroll
       for(int g = 0; g < 4; g++) {
@@ -361,7 +568,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
         const f32x4 bi = ldsF4(biAddr + pOff + 32 * g);
         f32x4 v;
 #pragma unroll
-        for(int i = 0; i < 4; i++) v[i] = acc[pt][4 * g + i];
+        for(int i = 0; i < 4; i++) v[i] = acc[q][4 * g + i];
         if(hasNb) v += ldsF4(nbAddr + pOff + 32 * g);
         if(RESID) {
           const V4 rr = __builtin_bit_cast(V4, resP[g]);
@@ -390,7 +597,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
         pairUp(rp, rawQ);
 #pragma unroll
         for(int j = 0; j < 2; j++) {
-          const int c = cout0 + 16 * j + 8 * khalf;
+          const int c = ct0 + 16 * j + 8 * khalf;
           T* const dst = (live && c >= a.rawBegin && c < a.rawEnd) ? rawRow + c : trash;
           *(u32x4*)dst = rawQ[j];
         }
@@ -400,7 +607,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
         pairUp(op, actQ);
 #pragma unroll
         for(int j = 0; j < 2; j++) {
-          const int c = cout0 + 16 * j + 8 * khalf;
+          const int c = ct0 + 16 * j + 8 * khalf;
           T* const dst = (live && c >= a.actBegin && c < a.actEnd) ? actRow + c : trash;
           *(u32x4*)dst = actQ[j];
         }
@@ -418,11 +625,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
 // two MFMAs and four reads per step it is shorter, and three times as many CUs work. Every work-group still fetches the whole image
 // and every slab (the fetching waves are unchanged): three times the L2 traffic, which is idle at these sizes. Outputs are computed by
 // the same MFMAs in the same order: bit-identical.
-template <class TR, bool PACK, int DEPTH, int MTW>
+template <class TR, bool PACK, int DEPTH, int MTW, bool REGW = false, int WN = 1>
 hipError_t launchSmall(const ConvArgs& a, hipStream_t stream) {
-  if(a.coutPad % NTILE != 0) return hipErrorInvalidValue;
-  auto kern = convSmallKernel<TR, PACK, DEPTH, MTW>;
-  constexpr int LDS_BYTES = SG<PACK, DEPTH>::LDS_BYTES;
+  if(a.coutPad % (NTILE * WN) != 0) return hipErrorInvalidValue;
+  auto kern = convSmallKernel<TR, PACK, DEPTH, MTW, REGW, WN>;
+  constexpr int LDS_BYTES = std::conditional_t<REGW, RWG, SG<PACK, DEPTH>>::LDS_BYTES;
   constexpr int MAX_DEVICES = 64;  // the > 64 KiB LDS opt-in is per function AND device (conv_kernel.h launchOne)
   static std::atomic<bool> attrSet[MAX_DEVICES];
   int dev = 0;
@@ -434,7 +641,7 @@ hipError_t launchSmall(const ConvArgs& a, hipStream_t stream) {
     if(e != hipSuccess) return e;
     attrSet[dev].store(true, std::memory_order_release);
   }
-  hipLaunchKernelGGL(kern, dim3(a.coutPad / NTILE, a.N, MT / MTW), dim3(NTHREADS), LDS_BYTES, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.coutPad / (NTILE * WN), a.N, MT / MTW), dim3(NTHREADS), LDS_BYTES, stream, a);
   return hipGetLastError();
 }
 

@@ -198,7 +198,7 @@ inline void waveSync() { cur->waves[tIdx.x >> 6].bar->arrive_and_wait(); }
 //     barrier that publishes a slab its requester has not waited for) leaves the destination stale and the results wrong.
 // Requests that are not LDS-DMA (plain global loads and stores count in vmcnt on gfx9 too) are entered with vmNote() where a
 // kernel's counts rely on them.
-struct VmOp { const void* src; void* dst; int size; };
+struct VmOp { const void* src; void* dst; int size; bool reg = false; };  // reg: a plain load into the lane's own registers
 struct VmQueue {
   std::vector<VmOp> ops;
   size_t head = 0;     // ops[head ..) are outstanding, oldest first
@@ -230,13 +230,33 @@ inline void waitVm(int n) {
   VmQueue& q = vmQueue;
   const size_t end = q.ops.size() > (size_t)n ? q.ops.size() - (size_t)n : 0;
   if(mode == 1) vmLandUpTo(end > q.head ? end : q.head);
-  else if(end > q.required) q.required = end;
+  else {
+    // mode 2 delays what OTHER waves may see; a load into the lane's own registers (globalLoadReg) is there for its own wave once the wait
+    // returns
+    for(size_t i = q.head; i < end; i++)
+      if(q.ops[i].reg && q.ops[i].dst != nullptr) {
+        memcpy(q.ops[i].dst, q.ops[i].src, (size_t)q.ops[i].size);
+        q.ops[i].dst = nullptr;
+      }
+    if(end > q.required) q.required = end;
+  }
 }
 inline void vmAtBarrier() {  // mode 2: what the waits so far have required lands now
   if(lateDmaMode() == 2 && vmQueue.required > vmQueue.head) vmLandUpTo(vmQueue.required);
 }
 inline void vmNote() {  // a vector-memory request that is not an LDS-DMA copy: it only takes its place in the in-order queue
   if(lateDma()) vmQueue.ops.push_back(VmOp{nullptr, nullptr, 0});
+}
+// a plain global load into registers whose s_waitcnt the KERNEL writes (conv_small_kernel.h REGW: gloadFrag / waitFrag): under the late
+// modes the destination keeps its old contents until a wait of the lane forces the load - a count one too generous multiplies a stale
+// fragment
+inline void globalLoadReg(void* dst, const void* src, int size) {
+  if(lateDma()) {
+    VmOp op{src, dst, size};
+    op.reg = true;
+    vmQueue.ops.push_back(op);
+  }
+  else memcpy(dst, src, (size_t)size);
 }
 template <class G, class L>
 inline void globalLoadLds(G gsrc, L ldsBase, int size, int, int) {

@@ -136,7 +136,11 @@ SMALL_REWRITES = [
     (r'asm volatile\("" : "\+s"\(sTap\)\);', ";", 2),
     (r'asm volatile\("" : "\+v"\(pOff\)\);', ";", 1),
     (r'extern __shared__ __attribute__\(\(aligned\(256\)\)\) char smemSmall\[\];', "char* const smemSmall = (char*)emu::dynLds();", 1),
-    (r'__attribute__\(\(amdgpu_waves_per_eu\(PACK \? 4 : 2, PACK \? 4 : 3\)\)\)', "", 1),
+    (r'__attribute__\(\(amdgpu_waves_per_eu\(PACK \? 4 : 2, PACK \? 4 : REGW \? 2 : 3\)\)\)', "", 1),
+    # REGW: the weight fragments are plain loads whose waits the kernel writes itself - they take their place in the lane's in-order queue
+    # and land when a wait forces them
+    (r'dst = \*\(const V8\*\)\(base \+ off\);', "emu::globalLoadReg(&dst, base + off, 16);", 1),
+    (r'\(void\)frag;  // \(the CPU emulation: emu::waitVm\(N\)\)', "emu::waitVm(N);", 1),
 ]
 
 

@@ -74,9 +74,15 @@ def test_host_cores_per_device(tmp_path):
     cfg = os.path.join(tmp, "bench.cfg")
     with open(cfg, "w") as f:
         f.write(CFG % os.path.join(tmp, "gtp_logs"))
-    r1, c1, _, _ = run_benchmark(binary, fake_so, model, cfg, 800, 4, tmp)
-    r2, c2, eps, avg = run_benchmark(binary, fake_so, model, cfg, 6400, 4, tmp)
-    us_per_row = (c2 - c1) / (r2 - r1) * 1e6
+    # (the difference of two CPU-time totals: on a host that is busy with something else - the suite's other workers, a compiler - the
+    # start-up part of a run, identical in both, can swing by more than the difference; such a pair is measured again, three times at most)
+    for attempt in range(3):
+        r1, c1, _, _ = run_benchmark(binary, fake_so, model, cfg, 800, 4, tmp)
+        r2, c2, eps, avg = run_benchmark(binary, fake_so, model, cfg, 6400, 4, tmp)
+        us_per_row = (c2 - c1) / (r2 - r1) * 1e6
+        if 30.0 < us_per_row < 1500.0:
+            break
+        print("attempt %d: %.0f -> %.0f rows, %.2f -> %.2f s of CPU (%.0f us per row): measured again" % (attempt, r1, r2, c1, c2, us_per_row))
     cores_one = DEVICE_ROWS_PER_S * us_per_row * 1e-6
     line = ("host capacity (fake device, katago_hip benchmark on 256 descents / 16 carrier threads, b18c384nbt 19x19, own evaluator + featuriser + "
             "fibers + leaf batcher): %.0f -> %.0f rows, %.2f -> %.2f s of CPU: %.0f us of host CPU per evaluated row = %.1f cores per MI355X at "

@@ -34,6 +34,10 @@ def test_latest_completion_catches_a_wrong_count(tmp_path):
     ], small_mutations=[
         # the fetching waves of the small-batch shape let one request more stay in flight than slab s + 1 allows
         (r"if\(slabWave\) convk::waitVmSel\(G::vmAt\(t\)\);", "if(slabWave) convk::waitVmSel(G::vmAt(t) + 1);", 1),
+        # the shape with its weights in registers: a multiplying wave lets one request more stay in flight than the 16 younger fragments
+        # (the fragment it is about to multiply may then not have landed), a fetching wave lets the image a barrier publishes stay in flight
+        (r'waitFragSel\(wf\[slot\]\[wn\], younger \* WN\);', 'waitFragSel(wf[slot][wn], younger * WN + 1);', 1),
+        (r'        waitVm<0>\(\);  // image chunk \+ 1', '        waitVm<NPA>();  // image chunk + 1', 1),
     ], pw2_mutations=[
         # the persistent seam kernel: phase 2 of a part lets one request more stay in flight than its loads and stores account for
         (r"waitVmSel\(G::nR\(q\) \+ 2\);", "waitVmSel(G::nR(q) + 2 + 1);", 1),
@@ -61,6 +65,16 @@ def test_latest_completion_catches_a_wrong_count(tmp_path):
     # (the fetching waves run ahead of the multiplying ones between two barriers, so under emulation a late copy may still land before a
     # small case reads it: the defect must show in at least one case - the two-board 19x19 one in practice - and never with immediate copies)
     assert all(ok(v) for v in c0.values()) and not all(ok(v) for v in c1.values()), (c0, c1)
+    # ... and with its weights in registers: the fragment wait (mode 1: a stale fragment is multiplied) and, with cell tiles split, the image wait
+    runs = run_parallel([([sys.executable, "-c", CW12_CODE, lib], dict(os.environ, KMX_CONV_TUNE="loaders=1,loaders_split=%s,regw=%s" % (sp_, rw_), KMX_EMU_LATE_DMA=late_))
+                         for sp_, late_, rw_ in (("0", "0", "1"), ("0", "1", "1"), ("1", "2", "1"), ("0", "1", "2,loaders_max_wgs=0"))])
+    for rc, so, se in runs:
+        assert rc == 0, (so + se)[-3000:]
+    c0, c1, c2, c3 = (json.loads(so.split("RESULT ")[1]) for rc, so, se in runs)
+    print("weights in registers, one request too generous: latest completion", {k: v[:2] for k, v in c1.items()}, {k: v[:2] for k, v in c2.items()},
+          {k: v[:2] for k, v in c3.items()})
+    assert all(ok(v) for v in c0.values()) and not any(ok(v) for v in c1.values()) and not all(ok(v) for v in c2.values()), (c0, c1, c2)
+    assert not all(ok(v) for v in c3.values()), c3  # the 64-channel shape where it is taken (an even number of channel tiles)
     # the seam kernel with its defect: right with immediate copies, wrong when a W2 slab may land as late as the count allows
     for kern in ("2", "3"):  # round 3's persistent kernel, round 5's with resident weights
         runs = run_parallel([([sys.executable, "-c", PW2_CODE, lib], dict(os.environ, KMX_PW_KERNEL=kern, KMX_PW_GRID="1", KMX_EMU_LATE_DMA=late_))
@@ -81,7 +95,7 @@ capi._lib = capi.load_library(path=sys.argv[1])
 from katago_amd import nninterface as nn
 rng = np.random.default_rng(7)
 out = {}
-for (cin, cout, X, Y, n) in ((64, 32, 9, 9, 1), (96, 192, 19, 19, 2), (40, 200, 19, 19, 1), (64, 64, 13, 9, 1), (32, 96, 7, 11, 3)):
+for (cin, cout, X, Y, n) in ((64, 32, 9, 9, 1), (96, 192, 19, 19, 2), (40, 200, 19, 19, 1), (64, 64, 13, 9, 1), (32, 96, 7, 11, 3), (160, 32, 9, 9, 1)):
     w = (rng.normal(size=(cout, cin, 3, 3)) * 0.1).astype(np.float32)
     x = rng.normal(size=(n, Y * X, cin)).astype(np.float32)
     got = np.asarray(nn.testEvaluateConv(w, n, X, Y, True, x))
@@ -100,13 +114,19 @@ def test_small_batch_shape_with_fetching_waves(emu_full_lib):
     that fails round 4's deleted third depth, which the MI355X also did), at both fetch depths (SG<PACK, DEPTH>: slabs 3 / 6 steps
     ahead, the image 1 / 2 chunks) and with a board's cell tiles split over three work-groups (cfg 117, MTW = 1), and BIT-IDENTICAL to the 4-wave shapes of
     conv_kernel.h the same layers take without it (same MFMAs per output in the same K order) - square, rectangular and several
-    boards, channel counts that are not multiples of the tile."""
-    # (loaders, fetch depth, cell tiles split over three work-groups (cfg 117), completion mode)
-    variants = (("0", "0", "0", "0"), ("1", "0", "0", "0"), ("1", "0", "0", "2"), ("1", "1", "0", "0"), ("1", "1", "0", "1"), ("1", "1", "0", "2"),
-                ("1", "1", "1", "0"), ("1", "1", "1", "2"))
+    boards, channel counts that are not multiples of the tile, one to five chunks. Round 5: the same shapes with the WEIGHTS IN REGISTERS
+    (REGW, cfg 128 / 127: hand-written loads and waits, one barrier per chunk, three image buffers) under all three completion modes - the
+    weight fragments are entered in the lane's in-order queue and land when a wait forces them."""
+    # (loaders, fetch depth, cell tiles split over three work-groups (cfg 117), completion mode, weights in registers (cfg 128 / 127))
+    variants = (("0", "0", "0", "0", "0"), ("1", "0", "0", "0", "0"), ("1", "0", "0", "2", "0"), ("1", "1", "0", "0", "0"), ("1", "1", "0", "1", "0"),
+                ("1", "1", "0", "2", "0"), ("1", "1", "1", "0", "0"), ("1", "1", "1", "2", "0"),
+                ("1", "1", "0", "0", "1"), ("1", "1", "0", "1", "1"), ("1", "1", "0", "2", "1"), ("1", "1", "1", "0", "1"), ("1", "1", "1", "1", "1"),
+                ("1", "1", "1", "2", "1"),
+                # (regw 2 with loaders_max_wgs=0: layers with an even number of channel tiles take the 64-channel register-weights shape, cfg 126)
+                ("1", "1", "0", "0", "2,loaders_max_wgs=0"), ("1", "1", "0", "1", "2,loaders_max_wgs=0"), ("1", "1", "0", "2", "2,loaders_max_wgs=0"))
     runs = run_parallel([([sys.executable, "-c", CW12_CODE, emu_full_lib],
-                          dict(os.environ, KMX_CONV_TUNE="loaders=%s,loaders_depth=%s,loaders_split=%s" % (ld, depth, split), KMX_EMU_LATE_DMA=late))
-                         for ld, depth, split, late in variants])
+                          dict(os.environ, KMX_CONV_TUNE="loaders=%s,loaders_depth=%s,loaders_split=%s,regw=%s" % (ld, depth, split, regw), KMX_EMU_LATE_DMA=late))
+                         for ld, depth, split, late, regw in variants])
     res = []
     for rc, so, se in runs:
         assert rc == 0 and "RESULT " in so, (so + se)[-3000:]
@@ -140,3 +160,42 @@ def test_deep_ring_1x1_shapes(emu_full_lib):
             assert v[0] <= 2.0 ** -7 * max(1.0, v[1]) * 1.5, (env, k, v)
     for k in res[0]:
         assert len({r[k][2] for r in res}) == 1, ("not bit-identical across ring depths", k, [r[k] for r in res])
+
+
+NET_REGW_CODE = r"""
+import sys, json, hashlib, os
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+from katago_amd import capi
+capi._lib = capi.load_library(path=sys.argv[1])
+from katago_amd import nninterface as nn, modelgen
+from conftest import make_rows
+rng = np.random.default_rng(0)
+nn.globalInitialize()
+ctx = nn.createComputeContext([0], 13, 13, precision="bf16")
+sp, gl = make_rows(rng, 2, 13, [(13, 13), (9, 7)])
+sym = np.array([3, 6], np.int32); opt = np.array([0.0, 1.0], np.float32)
+h = nn.createComputeHandle(ctx, nn.loadModelFile(sys.argv[2]), 2)
+got = nn.getOutput(h, sp, gl, sym, opt)
+print("RESULT " + json.dumps({k: hashlib.sha1(np.ascontiguousarray(got[k]).tobytes()).hexdigest() for k in sorted(got)}))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_register_weights_shapes_whole_net(emu_full_lib, tmp_path):
+    """A nested-bottleneck net with 64-channel inner 3x3 layers (residuals, per-board biases, raw and activated channel ranges, a board
+    smaller than the buffer) through the slab-ring shapes and through the shapes with their weights in registers - cfg 128, its cell tiles
+    over three work-groups (127), and the 64-channel shape (126: two channel tiles per wave, half a chunk of fragments in the ring) -
+    with immediate and with the latest legal completion: the same bits in every output."""
+    from katago_amd import modelgen
+    modelgen.ARCHS["b2c128nbt"] = dict(C=128, mid=64, gpool=16, blocks=["n", "ng"], p1=16, g1=16, v1=24, v2=32)
+    model = str(tmp_path / "b2c128nbt.bin")
+    modelgen.write_model(model, "b2c128nbt", seed=4)
+    variants = (("regw=0", "0"), ("regw=1", "2"), ("regw=1,loaders_split=0", "1"), ("regw=2,loaders_max_wgs=0", "1"), ("regw=2,loaders_max_wgs=0", "2"))
+    runs = run_parallel([([sys.executable, "-c", NET_REGW_CODE, emu_full_lib, model], dict(os.environ, KMX_CONV_TUNE=tune, KMX_EMU_LATE_DMA=late))
+                         for tune, late in variants])
+    res = []
+    for rc, so, se in runs:
+        assert rc == 0 and "RESULT " in so, (so + se)[-3000:]
+        res.append(json.loads(so.split("RESULT ")[1]))
+    for r in res[1:]:
+        assert r == res[0], (variants, res)

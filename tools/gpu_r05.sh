@@ -3,6 +3,7 @@
 #   tools/gpu_r05.sh seam        the resident-weights seam kernel: parity on hardware, launch time and cycle stamps against round 3's kernel, whole-net A/B
 #   tools/gpu_r05.sh parity      the round's changed tests (configs[3] in bf16 + fp16, fixed-seed search with the flip list, bench command)
 #   tools/gpu_r05.sh small       small / mid batch scan
+#   tools/gpu_r05.sh regw        the small-batch 3x3 shapes with their weights in registers against the slab-ring shapes
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
@@ -64,6 +65,22 @@ carriers)
   for lpt in 8 4 2 1; do
     tools/selfplay_full_games.sh carriers_$lpt 8 8 $lpt 8 50 > /dev/null 2>&1
     cat gpurun_out/selfplay_full_carriers_$lpt.txt | tee -a $OUT/carriers.txt
+  done
+  ;;
+regw)
+  # the fetching-waves 3x3 shapes with their weights in registers (conv_small_kernel.h REGW, cfg 128 / 127) against the slab-ring shapes
+  # (cfg 118 / 117): parity on hardware, pass time at batch 1 .. 64 from host rows with the digest of fixed rows, launch classes, self-play rows/s
+  KMX_CONV_TUNE=regw=1 timeout 700 python -m pytest tests/test_gpu_layers.py tests/test_gpu_fuzz.py "tests/test_gpu_model.py::test_full_batch_properties" -m gpu -q -p no:cacheprovider -x 2>&1 | tail -4 | tee $OUT/parity.log
+  for t in regw=0 regw=1 regw=0 regw=1; do
+    KMX_CONV_TUNE=$t timeout 200 python tools/small_batch_scan.py 2>&1 | grep SCAN | tee -a $OUT/small_batch_scan.txt
+  done
+  for t in regw=0 regw=1; do for n in 8 32; do
+    echo "== $t batch $n: per-class launch times (hipEvent pair per launch, one stream)" | tee -a $OUT/kernel_classes.txt
+    KMX_CONV_TUNE=$t timeout 200 python3 bench.py --no-cpu-baseline --no-callers --batch $n --steps 30 --warmup 5 2>>$OUT/err.txt | grep -o '"kernel_avg_launch_us": {[^}]*}\|"value": [0-9.]*\|"ms_per_step": [0-9.]*' | tr '\n' ' ' | tee -a $OUT/kernel_classes.txt; echo | tee -a $OUT/kernel_classes.txt
+  done; done
+  for t in regw=0 regw=1; do
+    KMX_CONV_TUNE=$t tools/selfplay_full_games.sh regw_${t#regw=} 8 8 8 8 60 > /dev/null 2>&1
+    echo "$t: $(cat gpurun_out/selfplay_full_regw_${t#regw=}.txt)" | tee -a $OUT/selfplay_rows.txt
   done
   ;;
 small)
