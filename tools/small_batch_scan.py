@@ -31,20 +31,24 @@ def main():
     out = {"tune": os.environ.get("KMX_CONV_TUNE", "default"), "precision": h.precision, "ms_per_pass": {}, "rows_per_s": {}}
     ref = nn.getOutput(h, sp, gl, sym)  # 64 rows: the 4-wave shapes
     same = True
-    for n in (1, 2, 8, 16, 42):
+    for n in (1, 2, 8, 16, 42, 48):
         got = nn.getOutput(h, sp[:n], gl[:n], sym[:n])
         same = same and all(np.array_equal(got[k], ref[k][:n]) for k in ref)
     big = nn.getOutput(h, np.tile(sp, (4, 1, 1)), np.tile(gl, (4, 1)), np.tile(sym, 4))  # 256 rows: the 8-wave shapes, two streams
     same = same and all(np.array_equal(big[k][:64], ref[k]) for k in ref)
     out["rows_bit_identical_across_batch_sizes"] = bool(same)
     out["digest"] = hashlib.sha1(b"".join(np.ascontiguousarray(ref[k]).tobytes() for k in sorted(ref))).hexdigest()
-    for n in (1, 2, 4, 8, 16, 32, 42, 64):
+    big85 = nn.getOutput(h, np.tile(sp, (2, 1, 1))[:85], np.tile(gl, (2, 1))[:85], np.tile(sym, 2)[:85])
+    same = same and all(np.array_equal(big85[k][:64], ref[k]) for k in ref)
+    out["rows_bit_identical_across_batch_sizes"] = bool(same)
+    for n in (1, 2, 4, 8, 16, 24, 32, 42, 48, 64, 85):
+        spn, gln, symn = (np.tile(sp, (2, 1, 1))[:n], np.tile(gl, (2, 1))[:n], np.tile(sym, 2)[:n]) if n > 64 else (sp[:n], gl[:n], sym[:n])
         for _ in range(3):
-            nn.getOutput(h, sp[:n], gl[:n], sym[:n])
+            nn.getOutput(h, spn, gln, symn)
         t0 = time.perf_counter()
         reps = 25
         for _ in range(reps):
-            nn.getOutput(h, sp[:n], gl[:n], sym[:n])
+            nn.getOutput(h, spn, gln, symn)
         ms = (time.perf_counter() - t0) / reps * 1e3
         out["ms_per_pass"][n] = round(ms, 3)
         out["rows_per_s"][n] = round(n / ms * 1e3)
