@@ -68,7 +68,7 @@ double benchConv(int ks, int cfg, int variant, int cin, int cout, int batch, int
   mask.upload(ones.data(), cells * sizeof(float));
   ConvArgs a;
   memset(&a, 0, sizeof(a));
-  a.in = in.get(); a.w = fc.w.get(); a.zeroPage = zero.get(); a.inC = inStride; a.nChunks = fc.nChunks; a.coutPad = fc.coutPad;
+  a.in = in.get(); a.w = fc.w.get(); a.wFrag = fc.wFrag.get(); a.zeroPage = zero.get(); a.inC = inStride; a.nChunks = fc.nChunks; a.coutPad = fc.coutPad;
   a.N = batch; a.X = X; a.Y = Y;
   if(epilogueMode == 1) {
     a.resid = resid.get(); a.residC = outStride;
@@ -148,7 +148,7 @@ double benchConvChain(int batch, int nConv, int chained, int iters, int timing) 
       for(int k = 0; k < nConv; k++) {
         ConvArgs a;
         memset(&a, 0, sizeof(a));
-        a.w = fc[k].w.get(); a.zeroPage = zero.get(); a.inC = C; a.nChunks = fc[k].nChunks; a.coutPad = fc[k].coutPad;
+        a.w = fc[k].w.get(); a.wFrag = fc[k].wFrag.get(); a.zeroPage = zero.get(); a.inC = C; a.nChunks = fc[k].nChunks; a.coutPad = fc[k].coutPad;
         a.N = batch; a.X = X; a.Y = Y;
         a.scale = fc[k].scale.as<float>(); a.bias = fc[k].bias.as<float>(); a.actKind = KMX_ACT_MISH; a.mask = mask.as<float>();
         a.actC = C; a.actBegin = 0; a.actEnd = C;
@@ -262,7 +262,7 @@ double benchConvStreams(int ks, int cfg, int cin, int cout, int batch, int nStre
     hipCheck(hipEventCreate(&p->done), "event");
     ConvArgs& a = p->a;
     memset(&a, 0, sizeof(a));
-    a.in = p->in.get(); a.w = fc.w.get(); a.zeroPage = zero.get(); a.inC = inStride; a.nChunks = fc.nChunks; a.coutPad = fc.coutPad;
+    a.in = p->in.get(); a.w = fc.w.get(); a.wFrag = fc.wFrag.get(); a.zeroPage = zero.get(); a.inC = inStride; a.nChunks = fc.nChunks; a.coutPad = fc.coutPad;
     a.N = batch; a.X = X; a.Y = Y;
     if(epilogueMode == 1) {
       a.resid = p->resid.get(); a.residC = outStride;

@@ -64,8 +64,9 @@ constexpr int CFG_REGW64 = 126;      // a board x 64 channels (two channel tiles
 //   deep1x1         1    1x1 at small batch on a ring of four steps (0: two)
 //   deep1x1_max_wgs 256  work-groups up to which the 32-channel deep shape is taken (tests: 0 sends even tile counts to the 64-channel one)
 //   split1x1        1    a board's cell tiles over three work-groups for 1x1 layers too
-//   regw            0    the one-per-CU fetching-waves shapes with their weights in registers (cfg 128 / 127 in place of 118 / 117);
-//                        2: also the 64-channel one (cfg 126) where the two-per-CU shape (cfg 119) is taken
+//   regw            0    the fetching-waves shapes with their weights in registers: 1 - cfg 128 in place of 118; 2 - also the 64-channel
+//                        one (cfg 126) where the two-per-CU shape (cfg 119) is taken; 3 - also cfg 127 (cell tiles over three work-groups)
+//                        in place of 117
 //   regw64_max_wgs  256  work-groups up to which cfg 126 is taken
 struct ConvTune {
   int minWgs8 = 150, loaders = 1, loadersDepth = 1, loadersSplit = 1, loadersMaxWgs = 256, packedMaxWgs = 512, deep1x1 = 1, deep1x1MaxWgs = 256,
@@ -164,7 +165,7 @@ int chooseConvCfg(int ks, int coutPad, int batch) {
   if(widest8 && wgs(widest8) >= tn.minWgs8) return widest8;
   // the fetching-waves shape while it is the only work-group on its CU (134 VGPRs x 8 waves: one work-group per CU), its cell tiles over
   // three work-groups while even that leaves CUs idle
-  if(ks == 3 && tn.loaders && tn.loadersSplit && batch * tiles * 3 <= tn.loadersMaxWgs) return tn.regw ? CFG_REGW_SPLIT : CFG_LOADERS_SPLIT;
+  if(ks == 3 && tn.loaders && tn.loadersSplit && batch * tiles * 3 <= tn.loadersMaxWgs) return tn.regw >= 3 ? CFG_REGW_SPLIT : CFG_LOADERS_SPLIT;
   // (split AND two work-groups per CU for the next 256 work-groups - 88 registers, 68 KB of LDS - measured within 1 % of the unsplit
   // shape at batch 16 - 28 and is not kept: profiles/r04_steps/small_batch/split1x1_scan.txt)
   if(ks == 3 && tn.loaders && batch * tiles <= tn.loadersMaxWgs) return tn.regw ? CFG_REGW : CFG_LOADERS;

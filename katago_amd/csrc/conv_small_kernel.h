@@ -376,11 +376,14 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
     // a chunk (9 x 8 registers, and a k half is twice as long)
     constexpr int R = WN == 1 ? NHS : NHS / 2;
     static_assert(NHS % R == 0 && (R - 2) * WN <= 17, "ring slots are compile-time indices; waitFragSel knows counts up to 17");
-    const char* const wTile = (const char*)a.w + (size_t)cout0 * ROWB;
+    // from the copy in fragment order (ConvArgs::wFrag): a wave's load is 1 KB of consecutive bytes, lane l at + 16 l. (Read from the
+    // slab rows of ConvArgs::w - 32 rows of 64 bytes, the lane's slot in each - the same load touched 64 separate 16-byte pieces of 16 cache
+    // lines: the register-weights shapes gained 6-9 % per launch where the LDS traffic they take away promised 25 %.)
+    const char* const wTile = (const char*)a.wFrag + (size_t)cout0 * ROWB;
     const size_t wSlabStride = (size_t)a.coutPad * ROWB;
-    unsigned wOffLane[2];  // the lane's 16 bytes of its slab row: what the LDS-DMA shapes read back from the linear copy of the slab
+    unsigned wOffLane[2];  // k half kk of a tile's 2 KB: 1 KB of 64 lanes x 16 bytes
 #pragma unroll
-    for(int kk = 0; kk < 2; kk++) wOffLane[kk] = (unsigned)(lane & 31) * ROWB + (((kk * 2 + khalf) ^ wXor) << 4);
+    for(int kk = 0; kk < 2; kk++) wOffLane[kk] = (unsigned)kk * 1024u + (unsigned)lane * 16u;
     // The loads and their waits are hand-written: left to the compiler, a load whose use lies beyond the loop's back edge makes hipcc drain
     // the queue (s_waitcnt vmcnt(0)) at the top of every chunk - a memory round trip per chunk. A wave's loads return in order, WN
     // fragments are requested per k half, R - 1 k halves before their use: in the steady state the requests of R - 2 k halves are younger.
@@ -545,10 +548,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
     for(int q = 0; q < WN * MTW; q++) {
       const int pt = q % MTW, ct0 = cout0 + (q / MTW) * 32;
       const int cellBase = wm * (32 * MT) + (pt0 + pt) * 32;
-      if(cellBase >= S) {  // wave-uniform
-        if(WN == 1) break;
-        continue;
-      }
+      // wave-uniform. (Two channel tiles per wave: a cell tile off the board is walked with every piece going to the trash area - the
+      // residual requests run one (channel tile, cell tile) ahead in a fixed order.)
+      if(WN == 1 && cellBase >= S) break;
       const bool live = cellBase + myPos < S;
       const int cell = cellOfTile[pt];
       const unsigned onBits = ldsF1(maskAddr + cell * 4) == 1.0f ? 0xffffffffu : 0u;
@@ -628,6 +630,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
 template <class TR, bool PACK, int DEPTH, int MTW, bool REGW = false, int WN = 1>
 hipError_t launchSmall(const ConvArgs& a, hipStream_t stream) {
   if(a.coutPad % (NTILE * WN) != 0) return hipErrorInvalidValue;
+  if(REGW && a.wFrag == nullptr) return hipErrorInvalidValue;  // the register-weights shapes read the copy in fragment order
   auto kern = convSmallKernel<TR, PACK, DEPTH, MTW, REGW, WN>;
   constexpr int LDS_BYTES = std::conditional_t<REGW, RWG, SG<PACK, DEPTH>>::LDS_BYTES;
   constexpr int MAX_DEVICES = 64;  // the > 64 KiB LDS opt-in is per function AND device (conv_kernel.h launchOne)

@@ -113,6 +113,22 @@ FusedConv buildFusedConv(int dtype, const std::vector<ConvSegment>& segs, std::v
   else {
     fc.w = DevBuf(w.size() * sizeof(uint16_t), false);
     fc.w.upload(w.data(), w.size() * sizeof(uint16_t));
+    if(fc.ks == 3) {
+      // the second copy, in fragment order (ConvArgs::wFrag): row `co`, slot-swizzled 8-value group g of the row above -> tile co / 32,
+      // k half g / 2, lane (co % 32) + 32 (g % 2)
+      std::vector<uint16_t> wfr(w.size(), 0);
+      const size_t rows = (size_t)fc.nChunks * nt * fc.coutPad;
+      for(size_t r = 0; r < rows; r++) {
+        const size_t slab = r / fc.coutPad, co = r % fc.coutPad;
+        for(int g = 0; g < 4; g++) {
+          const int slot = g ^ (int)((co >> 2) & 3);
+          const size_t dst = ((((slab * (fc.coutPad / 32) + co / 32) * 2 + (size_t)(g >> 1)) * 64) + (co % 32) + 32 * (size_t)(g & 1)) * 8;
+          memcpy(&wfr[dst], &w[r * WROW_HALFS + (size_t)slot * 8], 8 * sizeof(uint16_t));
+        }
+      }
+      fc.wFrag = DevBuf(wfr.size() * sizeof(uint16_t), false);
+      fc.wFrag.upload(wfr.data(), wfr.size() * sizeof(uint16_t));
+    }
   }
   fc.scale = DevBuf(scale.size() * sizeof(float), false);
   fc.scale.upload(scale.data(), scale.size() * sizeof(float));
@@ -290,6 +306,7 @@ ConvArgs Engine::makeConvArgs(const FusedConv* fc, const void* in, int inStride,
   memset(&a, 0, sizeof(a));
   a.in = in;
   a.w = fc->w.get();
+  a.wFrag = fc->wFrag.get();
   a.zeroPage = zeroPage_.get();
   a.inC = inStride;
   a.nChunks = fc->nChunks;
@@ -1216,7 +1233,7 @@ struct HookCtx {
             int rawBegin, int rawEnd, void* actOut, int actStride, int actBegin, int actEnd, int actKind) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.in = in; a.w = fc.w.get(); a.zeroPage = zero.get(); a.inC = inStride; a.nChunks = fc.nChunks; a.coutPad = fc.coutPad;
+    a.in = in; a.w = fc.w.get(); a.wFrag = fc.wFrag.get(); a.zeroPage = zero.get(); a.inC = inStride; a.nChunks = fc.nChunks; a.coutPad = fc.coutPad;
     a.N = N; a.X = X; a.Y = Y;
     a.resid = resid; a.residC = residStride;
     a.rawOut = rawOut; a.rawC = rawStride; a.rawBegin = rawBegin; a.rawEnd = std::min(rawEnd, rawBegin + rawStride);
@@ -1435,7 +1452,7 @@ void testConvChain(int dtype, int batch, int X, int Y, int nConv, const float* x
     for(int k = 0; k < nConv; k++) {
       ConvArgs a;
       memset(&a, 0, sizeof(a));
-      a.w = fc[k].w.get(); a.zeroPage = h.zero.get(); a.inC = C; a.nChunks = fc[k].nChunks; a.coutPad = fc[k].coutPad;
+      a.w = fc[k].w.get(); a.wFrag = fc[k].wFrag.get(); a.zeroPage = h.zero.get(); a.inC = C; a.nChunks = fc[k].nChunks; a.coutPad = fc[k].coutPad;
       a.N = batch; a.X = X; a.Y = Y;
       a.scale = fc[k].scale.as<float>(); a.bias = fc[k].bias.as<float>(); a.actKind = act; a.mask = h.mask.as<float>();
       a.actC = C; a.actBegin = 0; a.actEnd = C;

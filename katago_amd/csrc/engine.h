@@ -61,6 +61,7 @@ struct FusedConv {
   int cout = 0;      // channels in the fused output space (segments padded to multiples of 4)
   int coutPad = 0;   // multiple of 64
   DevBuf w;          // T[nChunks][ks*ks][coutPad][32], the four 8-value slots of a row XOR-swizzled (kernels.h)
+  DevBuf wFrag;      // 3x3, 16-bit: the same weights in MFMA-fragment order (ConvArgs::wFrag); empty otherwise
   DevBuf scale, bias;  // float[coutPad]; zero outside act segments
   double macPerCell = 0;  // real MACs per board cell (for flop accounting)
 };

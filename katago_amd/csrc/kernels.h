@@ -42,6 +42,10 @@ constexpr int WROW_HALFS = 32;  // halfs per weight/activation LDS row (64 bytes
 struct ConvArgs {
   const void* in;
   const void* w;
+  // 3x3, 16-bit only (else null): the SAME weights in MFMA-fragment order for the shapes that load them straight into registers
+  // (conv_small_kernel.h REGW) - T[chunk][tap][coutPad/32][k half of the chunk (2)][lane (64)][8]: lane l holds output channel
+  // 32 tile + (l & 31), input channels 16 khalf + 8 (l >> 5) + [0, 8) of the chunk - a wave's fragment load is 1 KB of consecutive bytes
+  const void* wFrag;
   const void* zeroPage;  // ZERO_PAGE_BYTES of zeros (halo lanes walk it 64 bytes per input-channel chunk), followed by TRASH_BYTES of writable scratch
   int inC;               // channel stride of `in`
   int nChunks;           // ceil(real Cin / 32)

@@ -67,7 +67,7 @@ def test_latest_completion_catches_a_wrong_count(tmp_path):
     assert all(ok(v) for v in c0.values()) and not all(ok(v) for v in c1.values()), (c0, c1)
     # ... and with its weights in registers: the fragment wait (mode 1: a stale fragment is multiplied) and, with cell tiles split, the image wait
     runs = run_parallel([([sys.executable, "-c", CW12_CODE, lib], dict(os.environ, KMX_CONV_TUNE="loaders=1,loaders_split=%s,regw=%s" % (sp_, rw_), KMX_EMU_LATE_DMA=late_))
-                         for sp_, late_, rw_ in (("0", "0", "1"), ("0", "1", "1"), ("1", "2", "1"), ("0", "1", "2,loaders_max_wgs=0"))])
+                         for sp_, late_, rw_ in (("0", "0", "1"), ("0", "1", "1"), ("1", "2", "3"), ("0", "1", "2,loaders_max_wgs=0"))])
     for rc, so, se in runs:
         assert rc == 0, (so + se)[-3000:]
     c0, c1, c2, c3 = (json.loads(so.split("RESULT ")[1]) for rc, so, se in runs)
@@ -115,13 +115,13 @@ def test_small_batch_shape_with_fetching_waves(emu_full_lib):
     ahead, the image 1 / 2 chunks) and with a board's cell tiles split over three work-groups (cfg 117, MTW = 1), and BIT-IDENTICAL to the 4-wave shapes of
     conv_kernel.h the same layers take without it (same MFMAs per output in the same K order) - square, rectangular and several
     boards, channel counts that are not multiples of the tile, one to five chunks. Round 5: the same shapes with the WEIGHTS IN REGISTERS
-    (REGW, cfg 128 / 127: hand-written loads and waits, one barrier per chunk, three image buffers) under all three completion modes - the
+    (REGW, cfg 128 / 127 / 126: hand-written loads and waits, one barrier per chunk, three image buffers) under all three completion modes - the
     weight fragments are entered in the lane's in-order queue and land when a wait forces them."""
     # (loaders, fetch depth, cell tiles split over three work-groups (cfg 117), completion mode, weights in registers (cfg 128 / 127))
     variants = (("0", "0", "0", "0", "0"), ("1", "0", "0", "0", "0"), ("1", "0", "0", "2", "0"), ("1", "1", "0", "0", "0"), ("1", "1", "0", "1", "0"),
                 ("1", "1", "0", "2", "0"), ("1", "1", "1", "0", "0"), ("1", "1", "1", "2", "0"),
-                ("1", "1", "0", "0", "1"), ("1", "1", "0", "1", "1"), ("1", "1", "0", "2", "1"), ("1", "1", "1", "0", "1"), ("1", "1", "1", "1", "1"),
-                ("1", "1", "1", "2", "1"),
+                ("1", "1", "0", "0", "1"), ("1", "1", "0", "1", "1"), ("1", "1", "0", "2", "1"), ("1", "1", "1", "0", "3"), ("1", "1", "1", "1", "3"),
+                ("1", "1", "1", "2", "3"),
                 # (regw 2 with loaders_max_wgs=0: layers with an even number of channel tiles take the 64-channel register-weights shape, cfg 126)
                 ("1", "1", "0", "0", "2,loaders_max_wgs=0"), ("1", "1", "0", "1", "2,loaders_max_wgs=0"), ("1", "1", "0", "2", "2,loaders_max_wgs=0"))
     runs = run_parallel([([sys.executable, "-c", CW12_CODE, emu_full_lib],
@@ -172,12 +172,19 @@ from katago_amd import nninterface as nn, modelgen
 from conftest import make_rows
 rng = np.random.default_rng(0)
 nn.globalInitialize()
-ctx = nn.createComputeContext([0], 13, 13, precision="bf16")
-sp, gl = make_rows(rng, 2, 13, [(13, 13), (9, 7)])
-sym = np.array([3, 6], np.int32); opt = np.array([0.0, 1.0], np.float32)
-h = nn.createComputeHandle(ctx, nn.loadModelFile(sys.argv[2]), 2)
-got = nn.getOutput(h, sp, gl, sym, opt)
-print("RESULT " + json.dumps({k: hashlib.sha1(np.ascontiguousarray(got[k]).tobytes()).hexdigest() for k in sorted(got)}))
+out = {}
+# a 13x13 buffer with a smaller board inside, and a 2x3 buffer (6 cells: most of a wave's cell tiles lie off the board)
+for X, Y, sizes in ((13, 13, [(13, 13), (9, 7)]), (2, 3, [(2, 3), (2, 2), (2, 3)])):
+    L, n = max(X, Y), len(sizes)
+    ctx = nn.createComputeContext([0], X, Y, precision="bf16")
+    sp_full, gl = make_rows(rng, n, L, sizes)
+    sp = np.ascontiguousarray(sp_full.reshape(n, L, L, 22)[:, :Y, :X, :]).reshape(n, X * Y, 22)
+    sym = np.array([3, 6, 1][:n], np.int32); opt = np.array([0.0, 1.0, 0.5][:n], np.float32)
+    h = nn.createComputeHandle(ctx, nn.loadModelFile(sys.argv[2]), 4)
+    got = nn.getOutput(h, sp, gl, sym, opt)
+    out.update({"%%dx%%d %%s" %% (X, Y, k): hashlib.sha1(np.ascontiguousarray(got[k]).tobytes()).hexdigest() for k in sorted(got)})
+    h.close()
+print("RESULT " + json.dumps(out))
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -185,12 +192,14 @@ def test_register_weights_shapes_whole_net(emu_full_lib, tmp_path):
     """A nested-bottleneck net with 64-channel inner 3x3 layers (residuals, per-board biases, raw and activated channel ranges, a board
     smaller than the buffer) through the slab-ring shapes and through the shapes with their weights in registers - cfg 128, its cell tiles
     over three work-groups (127), and the 64-channel shape (126: two channel tiles per wave, half a chunk of fragments in the ring) -
-    with immediate and with the latest legal completion: the same bits in every output."""
+    with immediate and with the latest legal completion: the same bits in every output. The 2x3 buffer is the case the MI355X found in
+    the first version of cfg 126 (fuzz case 34): cell tiles off the board were skipped, and the residual requests, which run one tile ahead
+    in a fixed order, then delivered the wrong tile's residual to the second channel tile."""
     from katago_amd import modelgen
     modelgen.ARCHS["b2c128nbt"] = dict(C=128, mid=64, gpool=16, blocks=["n", "ng"], p1=16, g1=16, v1=24, v2=32)
     model = str(tmp_path / "b2c128nbt.bin")
     modelgen.write_model(model, "b2c128nbt", seed=4)
-    variants = (("regw=0", "0"), ("regw=1", "2"), ("regw=1,loaders_split=0", "1"), ("regw=2,loaders_max_wgs=0", "1"), ("regw=2,loaders_max_wgs=0", "2"))
+    variants = (("regw=0", "0"), ("regw=3", "2"), ("regw=1,loaders_split=0", "1"), ("regw=2,loaders_max_wgs=0", "1"), ("regw=2,loaders_max_wgs=0", "2"))
     runs = run_parallel([([sys.executable, "-c", NET_REGW_CODE, emu_full_lib, model], dict(os.environ, KMX_CONV_TUNE=tune, KMX_EMU_LATE_DMA=late))
                          for tune, late in variants])
     res = []

@@ -17,27 +17,25 @@ for f in search_driven_rate.txt selfplay_rate_b18.txt selfplay_rate_b18_own_eval
 export KMX_SPLIT_MIN=0   # kernels are profiled with the chip to themselves (one stream), as bench.py's roofline pass measures them
 BENCH="python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile --no-callers"
 timeout 150 rocprofv3 --kernel-trace --stats -d $OUT/bench_trace -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-callers > $OUT/bench_trace.log 2>&1
-for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" \
-            "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM"; do
+for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA"; do
   tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
   timeout 150 rocprofv3 --pmc $pass -d $OUT/benchpmc_$tag -o bench -- $BENCH > $OUT/benchpmc_$tag.log 2>&1
 done
 unset KMX_SPLIT_MIN
-timeout 150 rocprofv3 --kernel-trace --stats -d $OUT/bench_trace_two_streams -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile --no-callers > $OUT/bench_trace_two_streams.log 2>&1
+# a small pass (batch 32, where self-play sits) under the kernel trace: the register-weights 3x3 shape, the 1x1 and small kernels per launch
+timeout 150 rocprofv3 --kernel-trace --stats -d $OUT/trace_batch32 -o bench -- python bench.py --batch 32 --steps 30 --warmup 5 --no-cpu-baseline --no-callers --no-profile > $OUT/trace_batch32.log 2>&1
 timeout 100 python tools/rocpd_summary.py $OUT $OUT/summary > $OUT/summary.log 2>&1
-for k in 3 2; do for dt in fp16 bf16; do
-  echo "== KMX_PW_KERNEL=$k $dt" >> $OUT/seam_timing.log
-  KMX_PW_KERNEL=$k KMX_BENCH_DTYPE=$dt timeout 120 python tools/seam_timing.py 256 >> $OUT/seam_timing.log 2>&1
-done; done
-KMX_BENCH_DTYPE=fp16 timeout 200 python tools/chain_timing.py 256 > $OUT/chain_timing_fp16.txt 2>&1
+for k in 3 2; do
+  echo "== KMX_PW_KERNEL=$k fp16" >> $OUT/seam_timing.log
+  KMX_PW_KERNEL=$k KMX_BENCH_DTYPE=fp16 timeout 120 python tools/seam_timing.py 256 >> $OUT/seam_timing.log 2>&1
+done
 timeout 200 python tools/small_batch_scan.py 2>&1 | grep SCAN > $OUT/small_batch_scan.txt
+KMX_CONV_TUNE=regw=0 timeout 200 python tools/small_batch_scan.py 2>&1 | grep SCAN >> $OUT/small_batch_scan.txt
 b() { local name=$1; shift; local envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
   local v=$(env "${envs[@]}" timeout 150 python3 bench.py --no-cpu-baseline --no-callers "$@" 2>>"$OUT/scan.err" | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"frac": [0-9.]*\|"dtype": "[a-z0-9]*"' | tr '\n' ' ')
   echo "$name | $v" | tee -a "$OUT/scan.txt"; }
-for n in 1 8 32 64 128 512; do b "b18c384nbt default precision batch $n" A=1 -- --batch $n --steps 40 --warmup 5 --no-profile; done
+for n in 8 32 64 128; do b "b18c384nbt default precision batch $n" A=1 -- --batch $n --steps 40 --warmup 5 --no-profile; done
 b "b18c384nbt bf16 batch 256" A=1 -- --dtype bf16 --steps 40 --warmup 5
-b "b18c384nbt default batch 256, seam kernel of round 3 (KMX_PW_KERNEL=2)" KMX_PW_KERNEL=2 -- --steps 40 --warmup 5
-b "b18c384nbt default batch 256 one stream" KMX_SPLIT_MIN=0 -- --steps 40 --warmup 5 --no-profile
 b "b28c512nbt default batch 512" A=1 -- --model b28c512nbt --batch 512 --steps 10 --warmup 2
 b "b40c256 default batch 512" A=1 -- --model b40c256 --batch 512 --steps 10 --warmup 2
 KMX_BENCH_SELFPLAY_TIMEOUT=0 timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --pmc > $OUT/bench_pmc.json 2> $OUT/bench_pmc.err
