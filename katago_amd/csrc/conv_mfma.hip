@@ -64,13 +64,16 @@ constexpr int CFG_REGW64 = 126;      // a board x 64 channels (two channel tiles
 //   deep1x1         1    1x1 at small batch on a ring of four steps (0: two)
 //   deep1x1_max_wgs 256  work-groups up to which the 32-channel deep shape is taken (tests: 0 sends even tile counts to the 64-channel one)
 //   split1x1        1    a board's cell tiles over three work-groups for 1x1 layers too
-//   regw            0    the fetching-waves shapes with their weights in registers: 1 - cfg 128 in place of 118; 2 - also the 64-channel
-//                        one (cfg 126) where the two-per-CU shape (cfg 119) is taken; 3 - also cfg 127 (cell tiles over three work-groups)
-//                        in place of 117
+//   regw            3    the fetching-waves shapes with their weights in registers: 0 - none (the slab-ring shapes of round 4); 1 - cfg 128
+//                        in place of 118; 2 - also the 64-channel one (cfg 126) where the two-per-CU shape (cfg 119) was taken; 3 - also
+//                        cfg 127 (cell tiles over three work-groups) in place of 117. Measured on one box (profiles/r05_steps/regw): a pass
+//                        from host rows 1.38 -> 1.31 ms at batch 1, 1.59 -> 1.49 at 8, 2.11 -> 1.93 at 16, 2.12 -> 1.98 at 32, 3.24 -> 2.88 at 64,
+//                        3.78 -> 3.36 at 85; self-play at 8 games x 8 leaves 20.4 -> 21.7 k NN rows/s
 //   regw64_max_wgs  256  work-groups up to which cfg 126 is taken
+//   regw_early      1    their instantiation that requests what a launch waits for first (conv_small_kernel.h EARLY; 0: the first form, for A/B)
 struct ConvTune {
   int minWgs8 = 150, loaders = 1, loadersDepth = 1, loadersSplit = 1, loadersMaxWgs = 256, packedMaxWgs = 512, deep1x1 = 1, deep1x1MaxWgs = 256,
-      split1x1 = 1, regw = 0, regw64MaxWgs = 256;
+      split1x1 = 1, regw = 3, regw64MaxWgs = 256, regwEarly = 1;
 };
 const ConvTune& convTune() {
   static const ConvTune t = [] {
@@ -80,7 +83,7 @@ const ConvTune& convTune() {
     const struct { const char* key; int* v; } keys[] = {
       {"min_wgs8", &t.minWgs8}, {"loaders", &t.loaders}, {"loaders_depth", &t.loadersDepth}, {"loaders_split", &t.loadersSplit},
       {"loaders_max_wgs", &t.loadersMaxWgs}, {"packed_max_wgs", &t.packedMaxWgs}, {"deep1x1", &t.deep1x1},
-      {"deep1x1_max_wgs", &t.deep1x1MaxWgs}, {"split1x1", &t.split1x1}, {"regw", &t.regw}, {"regw64_max_wgs", &t.regw64MaxWgs}};
+      {"deep1x1_max_wgs", &t.deep1x1MaxWgs}, {"split1x1", &t.split1x1}, {"regw", &t.regw}, {"regw64_max_wgs", &t.regw64MaxWgs}, {"regw_early", &t.regwEarly}};
     std::string s(e);
     size_t i = 0;
     while(i < s.size()) {
@@ -113,6 +116,11 @@ hipError_t launchT(int ks, int cfg, const ConvArgs& a, hipStream_t stream) {
   }
   if(ks == 3 && cfg == CFG_LOADERS_SPLIT) return smallk::launchSmall<TR, false, 1, 1>(a, stream);
   if(ks == 3 && cfg == CFG_LOADERS_PACKED) return smallk::launchSmall<TR, true, 0, 3>(a, stream);
+  if(convTune().regwEarly) {
+    if(ks == 3 && cfg == CFG_REGW) return smallk::launchSmall<TR, false, 1, 3, true, 1, true>(a, stream);
+    if(ks == 3 && cfg == CFG_REGW_SPLIT) return smallk::launchSmall<TR, false, 1, 1, true, 1, true>(a, stream);
+    if(ks == 3 && cfg == CFG_REGW64) return smallk::launchSmall<TR, false, 1, 3, true, 2, true>(a, stream);
+  }
   if(ks == 3 && cfg == CFG_REGW) return smallk::launchSmall<TR, false, 1, 3, true>(a, stream);
   if(ks == 3 && cfg == CFG_REGW_SPLIT) return smallk::launchSmall<TR, false, 1, 1, true>(a, stream);
   if(ks == 3 && cfg == CFG_REGW64) return smallk::launchSmall<TR, false, 1, 3, true, 2>(a, stream);

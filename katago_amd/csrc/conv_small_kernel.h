@@ -175,7 +175,7 @@ __device__ __forceinline__ void waitFragSel(V8& frag, int n) {
 
 // PACK (the second instantiation): register allocation capped at 128 per lane so that TWO work-groups share a CU (4 waves per SIMD, 2 x 68 KB
 // of LDS) - for batches whose work-groups outnumber the CUs; the cap costs 48 bytes of scratch per lane outside the loop.
-template <class TR, bool PACK, int DEPTH, int MTW, bool REGW, int WN>
+template <class TR, bool PACK, int DEPTH, int MTW, bool REGW, int WN, bool EARLY>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ? 4 : 2, PACK ? 4 : REGW ? 2 : 3))) void convSmallKernel(const ConvArgs a) {
   typedef typename TR::T T;
   typedef typename TR::V8 V8;
@@ -184,6 +184,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
   const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smemSmall;
   static_assert(!REGW || (!PACK && DEPTH == 1), "the register-weights shape is one instantiation per (MTW, WN)");
   static_assert(WN == 1 || (REGW && WN == 2 && MTW == MT), "two channel tiles per wave exist for the unsplit register-weights shape only");
+  static_assert(!EARLY || REGW, "");
+  // EARLY (register-weights shapes): what a launch waits for first goes out first. A small launch is mostly FIXED time - the loop is a
+  // third of it at batch 32 - and the first image request used to leave its wave ~560 instructions into the kernel (seven pieces' source
+  // offsets, a division by the halo width each, were computed before the first request), the first weight fragment ~250 (behind the cell
+  // bookkeeping of the epilogue), the first residual tile only after the loop. Now: an image piece is requested as soon as ITS offset is
+  // known (the division is a multiplication by a 16-bit reciprocal, exact below 441 x 21), the fragments go out at the top of a
+  // multiplying wave, the first residual tile before the last chunk.
   constexpr int NTILEW = NTILE * WN;  // output channels per work-group
   typedef std::conditional_t<REGW, RWG, SG<PACK, DEPTH>> G;
   constexpr int D = G::D, NSW = G::NSW, NSA = G::NSA, DIST = G::DIST;
@@ -241,6 +248,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
     const char* const wBase = (const char*)a.w + (size_t)cout0 * ROWB;
     const size_t wSlabStride = (size_t)a.coutPad * ROWB;
     unsigned srcOff[NPA];  // byte offset from this board's tensor, or (bit 31) the zero page; + 64 bytes per chunk
+    if constexpr(!EARLY) {
 #pragma unroll
     for(int j = 0; j < NPA; j++) {
       const int p = (j * NLOAD + lw) * 64 + lane;
@@ -254,6 +262,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
       }
       srcOff[j] = off;
     }
+    }
     auto issueA = [&](int chunk, int j) {  // request j of the image of `chunk`; the pointer then moves on to the next chunk
       const bool live = chunk < nChunks;
       const unsigned off = srcOff[j];
@@ -266,10 +275,33 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
       // then done with image c - 1, whose buffer it takes) and waited for at the top of chunk c + 1, whose barrier publishes it - one chunk
       // before its first read (the multiplying waves read NSET - 1 k halves ahead, across the chunk boundary). Everything this wave has
       // in flight at a wait is one image: the counts are 0 and NPA.
+      if constexpr(EARLY) {
+        const unsigned invW2 = (65536u + (unsigned)W2 - 1u) / (unsigned)W2;  // hp / W2 == hp * invW2 >> 16 for hp < 441, W2 <= 21
 #pragma unroll
-      for(int c = 0; c < DIST; c++)
+        for(int j = 0; j < NPA; j++) {
+          const int p = (j * NLOAD + lw) * 64 + lane;
+          const int hp = p >> 2;
+          const int slot = (p & 3) ^ ((hp >> 2) & 3);
+          unsigned off = 0x80000000u;
+          if(hp < HP) {
+            const int hy = (int)(((unsigned)hp * invW2) >> 16), hx = hp - hy * W2;
+            const int y = hy - HALO, x = hx - HALO;
+            if(y >= 0 && y < Y && x >= 0 && x < X) off = (unsigned)(((y * X + x) * inC + slot * 8) * (int)sizeof(T));
+          }
+          srcOff[j] = off;
+          issueA(0, j);
+        }
 #pragma unroll
-        for(int j = 0; j < NPA; j++) issueA(c, j);
+        for(int c = 1; c < DIST; c++)
+#pragma unroll
+          for(int j = 0; j < NPA; j++) issueA(c, j);
+      }
+      else {
+#pragma unroll
+        for(int c = 0; c < DIST; c++)
+#pragma unroll
+          for(int j = 0; j < NPA; j++) issueA(c, j);
+      }
       waitVm<(DIST - 1) * NPA>();  // image 0 (and, older, this wave's piece of the mask) has landed; image 1 is in flight
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -337,6 +369,21 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
   }
 
   // ===================================================== the multiplying waves =====================================================
+  // REGW: the ring of weight fragments and its loads (described at the loop); EARLY: the first R - 1 k halves are requested here, before
+  // the wave's cell bookkeeping
+  constexpr int R = !REGW ? 1 : WN == 1 ? RWG::NHS : RWG::NHS / 2;
+  V8 wf[R][WN];
+  const char* const wTile = (const char*)a.wFrag + (size_t)cout0 * ROWB;
+  const size_t wSlabStrideRw = (size_t)a.coutPad * ROWB;
+  const unsigned wOffLane[2] = {(unsigned)lane * 16u, 1024u + (unsigned)lane * 16u};  // k half kk of a tile's 2 KB: 1 KB of 64 lanes x 16 bytes
+  auto loadW = [&](int slot, const char* chunkBase, int hs) {  // the WN fragments of k half hs of the chunk at chunkBase
+#pragma unroll
+    for(int wn = 0; wn < WN; wn++) gloadFrag(wf[slot][wn], chunkBase + (size_t)(hs >> 1) * wSlabStrideRw + (size_t)(wn * NTILE * ROWB), wOffLane[hs & 1]);
+  };
+  if constexpr(REGW && EARLY) {
+#pragma unroll
+    for(int hs = 0; hs + 1 < R; hs++) loadW(hs, wTile, hs);
+  }
   const unsigned khalf = lane >> 5;
   const unsigned wXor = (lane >> 2) & 3;
   unsigned wLane[2];
@@ -367,6 +414,18 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
 #pragma unroll
     for(int r = 0; r < 16; r++) acc[pt][r] = 0.0f;
 
+  // the residual of (channel tile, cell tile) q = channel tile * MTW + cell tile, as the epilogue wants it (two 16-byte pieces per lane)
+  auto loadResid = [&](int q, u32x4 (&dst)[2]) {
+    const T* const rrow = (const T*)a.resid + ((size_t)n * S + cellOfTile[q % MTW]) * a.residC - a.rawBegin;
+#pragma unroll
+    for(int j = 0; j < 2; j++) {
+      const int c = cout0 + (q / MTW) * 32 + 16 * j + 8 * khalf;
+      const T* src = (c >= a.rawBegin && c < a.rawEnd) ? rrow + c : (const T*)zero;
+      dst[j] = *(const u32x4*)src;
+    }
+  };
+  u32x4 rqFirst[2];  // EARLY: tile 0's residual, requested before the last chunk
+
   if constexpr(REGW) {
     // ---- weights in registers: a chunk's 18 fragments a whole chunk ahead, one barrier per chunk ----
     constexpr int NHS = RWG::NHS;
@@ -374,27 +433,19 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
     static_assert(NHS % NSET == 0, "the set of a k half must be a compile-time index");
     // the ring of weight fragments: R k halves of WN fragments each. One channel tile per wave: a whole chunk (18 x 4 registers); two: half
     // a chunk (9 x 8 registers, and a k half is twice as long)
-    constexpr int R = WN == 1 ? NHS : NHS / 2;
     static_assert(NHS % R == 0 && (R - 2) * WN <= 17, "ring slots are compile-time indices; waitFragSel knows counts up to 17");
     // from the copy in fragment order (ConvArgs::wFrag): a wave's load is 1 KB of consecutive bytes, lane l at + 16 l. (Read from the
     // slab rows of ConvArgs::w - 32 rows of 64 bytes, the lane's slot in each - the same load touched 64 separate 16-byte pieces of 16 cache
-    // lines: the register-weights shapes gained 6-9 % per launch where the LDS traffic they take away promised 25 %.)
-    const char* const wTile = (const char*)a.wFrag + (size_t)cout0 * ROWB;
-    const size_t wSlabStride = (size_t)a.coutPad * ROWB;
-    unsigned wOffLane[2];  // k half kk of a tile's 2 KB: 1 KB of 64 lanes x 16 bytes
-#pragma unroll
-    for(int kk = 0; kk < 2; kk++) wOffLane[kk] = (unsigned)kk * 1024u + (unsigned)lane * 16u;
+    // lines: the shape whose cell tiles are split over three work-groups was SLOWER than its slab-ring twin that way, 13.5 against 12.4 us.)
     // The loads and their waits are hand-written: left to the compiler, a load whose use lies beyond the loop's back edge makes hipcc drain
     // the queue (s_waitcnt vmcnt(0)) at the top of every chunk - a memory round trip per chunk. A wave's loads return in order, WN
     // fragments are requested per k half, R - 1 k halves before their use: in the steady state the requests of R - 2 k halves are younger.
-    V8 wf[R][WN];
-    auto loadW = [&](int slot, const char* chunkBase, int hs) {  // the WN fragments of k half hs of the chunk at chunkBase
-#pragma unroll
-      for(int wn = 0; wn < WN; wn++) gloadFrag(wf[slot][wn], chunkBase + (size_t)(hs >> 1) * wSlabStride + (size_t)(wn * NTILE * ROWB), wOffLane[hs & 1]);
-    };
+    const size_t wSlabStride = wSlabStrideRw;
     const char* wCur = wTile;  // this chunk's nine slabs
+    if constexpr(!EARLY) {
 #pragma unroll
-    for(int hs = 0; hs + 1 < R; hs++) loadW(hs, wCur, hs);  // k half R - 1 follows in the first k half (the ring's rule below)
+      for(int hs = 0; hs + 1 < R; hs++) loadW(hs, wCur, hs);  // k half R - 1 follows in the first k half (the ring's rule below)
+    }
     waitVm<0>();  // this wave's mask and parameter requests (and, younger, the fragments - which the first MFMA needs anyway)
     __builtin_amdgcn_s_barrier();  // image 0, the mask and the parameters are published
     asm volatile("" ::: "memory");
@@ -455,6 +506,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
       chunk++;
     };
     while(chunk + 1 < nChunks) chunkBody(ActKindTag<0>());
+    // (plain loads, older than everything the last chunk requests: the chunk's hand-written waits may only become stricter by them)
+    if(EARLY && a.resid != nullptr) loadResid(0, rqFirst);
     chunkBody(ActKindTag<1>());
   }
   else {
@@ -534,16 +587,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
     constexpr bool RESID = decltype(residTag)::value != 0;
     u32x4 rq[2][2];
     // q = channel tile * MTW + cell tile (one channel tile per wave everywhere but in the 64-channel register-weights shape)
-    auto loadResid = [&](int q, u32x4 (&dst)[2]) {
-      const T* const rrow = (const T*)a.resid + ((size_t)n * S + cellOfTile[q % MTW]) * a.residC - a.rawBegin;
-#pragma unroll
-      for(int j = 0; j < 2; j++) {
-        const int c = cout0 + (q / MTW) * 32 + 16 * j + 8 * khalf;
-        const T* src = (c >= a.rawBegin && c < a.rawEnd) ? rrow + c : (const T*)zero;
-        dst[j] = *(const u32x4*)src;
+    if(RESID) {
+      if(EARLY) {
+        rq[0][0] = rqFirst[0];
+        rq[0][1] = rqFirst[1];
       }
-    };
-    if(RESID) loadResid(0, rq[0]);
+      else loadResid(0, rq[0]);
+    }
 #pragma unroll
     for(int q = 0; q < WN * MTW; q++) {
       const int pt = q % MTW, ct0 = cout0 + (q / MTW) * 32;
@@ -627,11 +677,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
 // two MFMAs and four reads per step it is shorter, and three times as many CUs work. Every work-group still fetches the whole image
 // and every slab (the fetching waves are unchanged): three times the L2 traffic, which is idle at these sizes. Outputs are computed by
 // the same MFMAs in the same order: bit-identical.
-template <class TR, bool PACK, int DEPTH, int MTW, bool REGW = false, int WN = 1>
+template <class TR, bool PACK, int DEPTH, int MTW, bool REGW = false, int WN = 1, bool EARLY = false>
 hipError_t launchSmall(const ConvArgs& a, hipStream_t stream) {
   if(a.coutPad % (NTILE * WN) != 0) return hipErrorInvalidValue;
   if(REGW && a.wFrag == nullptr) return hipErrorInvalidValue;  // the register-weights shapes read the copy in fragment order
-  auto kern = convSmallKernel<TR, PACK, DEPTH, MTW, REGW, WN>;
+  auto kern = convSmallKernel<TR, PACK, DEPTH, MTW, REGW, WN, EARLY>;
   constexpr int LDS_BYTES = std::conditional_t<REGW, RWG, SG<PACK, DEPTH>>::LDS_BYTES;
   constexpr int MAX_DEVICES = 64;  // the > 64 KiB LDS opt-in is per function AND device (conv_kernel.h launchOne)
   static std::atomic<bool> attrSet[MAX_DEVICES];

@@ -56,7 +56,7 @@ def test_latest_completion_catches_a_wrong_count(tmp_path):
     print("late completion, one request too generous:", late)
     assert "conv3_64_32" in wrong and "conv3_96_192" in wrong, late  # the padded 4-wave shape and the 8-wave loader shape
     # the small-batch shape with its fetching waves' wait one request too generous
-    runs = run_parallel([([sys.executable, "-c", CW12_CODE, lib], dict(os.environ, KMX_CONV_TUNE="loaders=1", KMX_EMU_LATE_DMA=late_)) for late_ in ("0", "2")])
+    runs = run_parallel([([sys.executable, "-c", CW12_CODE, lib], dict(os.environ, KMX_CONV_TUNE="loaders=1,regw=0", KMX_EMU_LATE_DMA=late_)) for late_ in ("0", "2")])
     (rc0, so0, se0), (rc1, so1, se1) = runs
     assert rc0 == 0 and rc1 == 0, (so0 + se0 + so1 + se1)[-3000:]
     c0, c1 = json.loads(so0.split("RESULT ")[1]), json.loads(so1.split("RESULT ")[1])
@@ -123,7 +123,9 @@ def test_small_batch_shape_with_fetching_waves(emu_full_lib):
                 ("1", "1", "0", "0", "1"), ("1", "1", "0", "1", "1"), ("1", "1", "0", "2", "1"), ("1", "1", "1", "0", "3"), ("1", "1", "1", "1", "3"),
                 ("1", "1", "1", "2", "3"),
                 # (regw 2 with loaders_max_wgs=0: layers with an even number of channel tiles take the 64-channel register-weights shape, cfg 126)
-                ("1", "1", "0", "0", "2,loaders_max_wgs=0"), ("1", "1", "0", "1", "2,loaders_max_wgs=0"), ("1", "1", "0", "2", "2,loaders_max_wgs=0"))
+                ("1", "1", "0", "0", "2,loaders_max_wgs=0"), ("1", "1", "0", "1", "2,loaders_max_wgs=0"), ("1", "1", "0", "2", "2,loaders_max_wgs=0"),
+                # (the instantiations without the early requests: conv_small_kernel.h EARLY = false)
+                ("1", "1", "1", "2", "3,regw_early=0"), ("1", "1", "0", "1", "2,loaders_max_wgs=0,regw_early=0"))
     runs = run_parallel([([sys.executable, "-c", CW12_CODE, emu_full_lib],
                           dict(os.environ, KMX_CONV_TUNE="loaders=%s,loaders_depth=%s,loaders_split=%s,regw=%s" % (ld, depth, split, regw), KMX_EMU_LATE_DMA=late))
                          for ld, depth, split, late, regw in variants])

@@ -68,19 +68,20 @@ carriers)
   done
   ;;
 regw)
-  # the fetching-waves 3x3 shapes with their weights in registers (conv_small_kernel.h REGW, cfg 128 / 126 / 127) against the slab-ring shapes
-  # (cfg 118 / 119 / 117): parity on hardware, pass time at batch 1 .. 85 from host rows with the digest of fixed rows, launch classes, self-play rows/s
-  KMX_CONV_TUNE=regw=3 timeout 600 python -m pytest tests/test_gpu_layers.py tests/test_gpu_fuzz.py "tests/test_gpu_model.py::test_full_batch_properties" -m gpu -q -p no:cacheprovider 2>&1 | tail -40 | cut -c1-600 | tee $OUT/parity.log
-  for t in regw=0 regw=2 regw=3 regw=0 regw=2 regw=3; do
+  # the fetching-waves 3x3 shapes with their weights in registers (conv_small_kernel.h REGW, cfg 128 / 126 / 127; the default since this call)
+  # against the slab-ring shapes (KMX_CONV_TUNE regw=0: cfg 118 / 119 / 117) and against their own first form (regw_early=0): parity on
+  # hardware, pass time at batch 1 .. 85 from host rows with the digest of fixed rows, launch classes, self-play rows/s
+  timeout 600 python -m pytest tests/test_gpu_layers.py tests/test_gpu_fuzz.py "tests/test_gpu_model.py::test_full_batch_properties" -m gpu -q -p no:cacheprovider 2>&1 | tail -40 | cut -c1-600 | tee $OUT/parity.log
+  for t in regw=0 regw_early=0 regw_early=1 regw=0 regw_early=0 regw_early=1; do
     KMX_CONV_TUNE=$t timeout 200 python tools/small_batch_scan.py 2>&1 | grep SCAN | tee -a $OUT/small_batch_scan.txt
   done
-  for t in regw=0 regw=3; do for n in 8 32 64; do
+  for t in regw_early=0 regw_early=1; do for n in 8 32 64; do
     echo "== $t batch $n: per-class launch times (hipEvent pair per launch, one stream)" | tee -a $OUT/kernel_classes.txt
     KMX_CONV_TUNE=$t timeout 200 python3 bench.py --no-cpu-baseline --no-callers --batch $n --steps 30 --warmup 5 2>>$OUT/err.txt | grep -o '"kernel_avg_launch_us": {[^}]*}\|"value": [0-9.]*\|"ms_per_step": [0-9.]*' | tr '\n' ' ' | tee -a $OUT/kernel_classes.txt; echo | tee -a $OUT/kernel_classes.txt
   done; done
-  for t in regw=0 regw=2; do
-    KMX_CONV_TUNE=$t tools/selfplay_full_games.sh regw_${t#regw=} 8 8 8 8 60 > /dev/null 2>&1
-    echo "$t: $(cat gpurun_out/selfplay_full_regw_${t#regw=}.txt)" | tee -a $OUT/selfplay_rows.txt
+  for t in regw=0 regw_early=1; do
+    KMX_CONV_TUNE=$t tools/selfplay_full_games.sh regw_${t#*=} 8 8 8 8 60 > /dev/null 2>&1
+    echo "$t: $(cat gpurun_out/selfplay_full_regw_${t#*=}.txt)" | tee -a $OUT/selfplay_rows.txt
   done
   ;;
 small)
