@@ -563,4 +563,63 @@ double benchMfma(int wavesPerWg, int wgs, int mode, int steps, int iters, double
   return avg;
 }
 
+
+// ---- what a dependent launch costs before it does anything (kmx_bench_launch_floor; tools/launch_floor.py) ----
+// A small pass is ~122 dependent launches of 11-17 us; the loops in them are a third of that. This measures the floor under a launch of
+// the small-batch shapes' geometry: `launches` dependent launches of a kernel of 512 threads and `ldsBytes` of LDS on `wgs` work-groups,
+// captured in ONE hipGraph (as the engine replays its schedule) and replayed. mode 0: the kernel ends at once; 1: every lane loads 16
+// bytes that the launch before stored (one round trip through the memory the launches hand their tensors over in) and stores them again;
+// 2: as 1, and the loaded value is first written to and read back from LDS behind a barrier (the work-group's LDS allocation is touched).
+template <int MODE>
+__global__ __launch_bounds__(512) void launchFloorKernel(const u32x4* in, u32x4* out) {
+  extern __shared__ __attribute__((aligned(16))) char smemFloor[];
+  if(MODE == 0) return;
+  const size_t i = (size_t)blockIdx.x * 512 + threadIdx.x;
+  u32x4 v = in[i];
+  if(MODE == 2) {
+    u32x4* l = (u32x4*)smemFloor;
+    l[threadIdx.x] = v;
+    __syncthreads();
+    v = l[threadIdx.x ^ 1];
+  }
+  out[i] = v;
+}
+double benchLaunchFloor(int wgs, int ldsBytes, int mode, int launches, int iters) {
+  DevBuf a((size_t)wgs * 512 * 16), b((size_t)wgs * 512 * 16);
+  hipStream_t st;
+  hipCheck(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "stream");
+  auto kern = mode == 0 ? launchFloorKernel<0> : mode == 1 ? launchFloorKernel<1> : launchFloorKernel<2>;
+  hipCheck(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes), "lds attribute");
+  auto chain = [&] {
+    for(int i = 0; i < launches; i++) {
+      const u32x4* src = (const u32x4*)((i & 1) ? b.get() : a.get());
+      u32x4* dst = (u32x4*)((i & 1) ? a.get() : b.get());
+      hipLaunchKernelGGL(kern, dim3(wgs), dim3(512), ldsBytes, st, src, dst);
+    }
+  };
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  hipCheck(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal), "capture");
+  chain();
+  hipCheck(hipStreamEndCapture(st, &graph), "end capture");
+  hipCheck(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0), "instantiate");
+  for(int i = 0; i < 3; i++) hipCheck(hipGraphLaunch(exec, st), "graph launch");
+  hipCheck(hipStreamSynchronize(st), "sync");
+  hipEvent_t e0, e1;
+  hipCheck(hipEventCreate(&e0), "event");
+  hipCheck(hipEventCreate(&e1), "event");
+  hipCheck(hipEventRecord(e0, st), "record");
+  for(int i = 0; i < iters; i++) hipCheck(hipGraphLaunch(exec, st), "graph launch");
+  hipCheck(hipEventRecord(e1, st), "record");
+  hipCheck(hipStreamSynchronize(st), "sync");
+  float ms = 0;
+  hipCheck(hipEventElapsedTime(&ms, e0, e1), "elapsed");
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipGraphExecDestroy(exec);
+  (void)hipGraphDestroy(graph);
+  (void)hipStreamDestroy(st);
+  return (double)ms * 1e3 / ((double)iters * launches);  // us per launch
+}
+
 }  // namespace kmx

@@ -70,10 +70,9 @@ constexpr int CFG_REGW64 = 126;      // a board x 64 channels (two channel tiles
 //                        from host rows 1.38 -> 1.31 ms at batch 1, 1.59 -> 1.49 at 8, 2.11 -> 1.93 at 16, 2.12 -> 1.98 at 32, 3.24 -> 2.88 at 64,
 //                        3.78 -> 3.36 at 85; self-play at 8 games x 8 leaves 20.4 -> 21.7 k NN rows/s
 //   regw64_max_wgs  256  work-groups up to which cfg 126 is taken
-//   regw_early      1    their instantiation that requests what a launch waits for first (conv_small_kernel.h EARLY; 0: the first form, for A/B)
 struct ConvTune {
   int minWgs8 = 150, loaders = 1, loadersDepth = 1, loadersSplit = 1, loadersMaxWgs = 256, packedMaxWgs = 512, deep1x1 = 1, deep1x1MaxWgs = 256,
-      split1x1 = 1, regw = 3, regw64MaxWgs = 256, regwEarly = 1;
+      split1x1 = 1, regw = 3, regw64MaxWgs = 256;
 };
 const ConvTune& convTune() {
   static const ConvTune t = [] {
@@ -83,7 +82,7 @@ const ConvTune& convTune() {
     const struct { const char* key; int* v; } keys[] = {
       {"min_wgs8", &t.minWgs8}, {"loaders", &t.loaders}, {"loaders_depth", &t.loadersDepth}, {"loaders_split", &t.loadersSplit},
       {"loaders_max_wgs", &t.loadersMaxWgs}, {"packed_max_wgs", &t.packedMaxWgs}, {"deep1x1", &t.deep1x1},
-      {"deep1x1_max_wgs", &t.deep1x1MaxWgs}, {"split1x1", &t.split1x1}, {"regw", &t.regw}, {"regw64_max_wgs", &t.regw64MaxWgs}, {"regw_early", &t.regwEarly}};
+      {"deep1x1_max_wgs", &t.deep1x1MaxWgs}, {"split1x1", &t.split1x1}, {"regw", &t.regw}, {"regw64_max_wgs", &t.regw64MaxWgs}};
     std::string s(e);
     size_t i = 0;
     while(i < s.size()) {
@@ -116,11 +115,6 @@ hipError_t launchT(int ks, int cfg, const ConvArgs& a, hipStream_t stream) {
   }
   if(ks == 3 && cfg == CFG_LOADERS_SPLIT) return smallk::launchSmall<TR, false, 1, 1>(a, stream);
   if(ks == 3 && cfg == CFG_LOADERS_PACKED) return smallk::launchSmall<TR, true, 0, 3>(a, stream);
-  if(convTune().regwEarly) {
-    if(ks == 3 && cfg == CFG_REGW) return smallk::launchSmall<TR, false, 1, 3, true, 1, true>(a, stream);
-    if(ks == 3 && cfg == CFG_REGW_SPLIT) return smallk::launchSmall<TR, false, 1, 1, true, 1, true>(a, stream);
-    if(ks == 3 && cfg == CFG_REGW64) return smallk::launchSmall<TR, false, 1, 3, true, 2, true>(a, stream);
-  }
   if(ks == 3 && cfg == CFG_REGW) return smallk::launchSmall<TR, false, 1, 3, true>(a, stream);
   if(ks == 3 && cfg == CFG_REGW_SPLIT) return smallk::launchSmall<TR, false, 1, 1, true>(a, stream);
   if(ks == 3 && cfg == CFG_REGW64) return smallk::launchSmall<TR, false, 1, 3, true, 2>(a, stream);

@@ -175,7 +175,7 @@ __device__ __forceinline__ void waitFragSel(V8& frag, int n) {
 
 // PACK (the second instantiation): register allocation capped at 128 per lane so that TWO work-groups share a CU (4 waves per SIMD, 2 x 68 KB
 // of LDS) - for batches whose work-groups outnumber the CUs; the cap costs 48 bytes of scratch per lane outside the loop.
-template <class TR, bool PACK, int DEPTH, int MTW, bool REGW, int WN, bool EARLY>
+template <class TR, bool PACK, int DEPTH, int MTW, bool REGW, int WN>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ? 4 : 2, PACK ? 4 : REGW ? 2 : 3))) void convSmallKernel(const ConvArgs a) {
   typedef typename TR::T T;
   typedef typename TR::V8 V8;
@@ -184,13 +184,14 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
   const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smemSmall;
   static_assert(!REGW || (!PACK && DEPTH == 1), "the register-weights shape is one instantiation per (MTW, WN)");
   static_assert(WN == 1 || (REGW && WN == 2 && MTW == MT), "two channel tiles per wave exist for the unsplit register-weights shape only");
-  static_assert(!EARLY || REGW, "");
-  // EARLY (register-weights shapes): what a launch waits for first goes out first. A small launch is mostly FIXED time - the loop is a
-  // third of it at batch 32 - and the first image request used to leave its wave ~560 instructions into the kernel (seven pieces' source
-  // offsets, a division by the halo width each, were computed before the first request), the first weight fragment ~250 (behind the cell
-  // bookkeeping of the epilogue), the first residual tile only after the loop. Now: an image piece is requested as soon as ITS offset is
-  // known (the division is a multiplication by a 16-bit reciprocal, exact below 441 x 21), the fragments go out at the top of a
-  // multiplying wave, the first residual tile before the last chunk.
+  // EARLY (the register-weights shapes): what a launch waits for first goes out first. In their first form the first image request left its
+  // wave ~560 instructions into the kernel (seven pieces' source offsets, a division by the halo width each, were computed before the first
+  // request), the first weight fragment ~250 (behind the cell bookkeeping of the epilogue), the first residual tile only after the loop.
+  // Now an image piece is requested as soon as ITS offset is known (the division is a multiplication by a 16-bit reciprocal, exact below
+  // 441 x 21), the fragments go out at the top of a multiplying wave, the first residual tile before the last chunk. Measured A/B on one
+  // box (profiles/r05_steps/regw/call3_*): 12.32 -> 12.19 us per 3x3 launch at batch 8, 17.66 -> 17.38 at 32, 25.64 -> 25.42 at 64 - a
+  // launch's fixed time is not its instruction count. The first form is deleted.
+  constexpr bool EARLY = REGW;
   constexpr int NTILEW = NTILE * WN;  // output channels per work-group
   typedef std::conditional_t<REGW, RWG, SG<PACK, DEPTH>> G;
   constexpr int D = G::D, NSW = G::NSW, NSA = G::NSA, DIST = G::DIST;
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
       // then done with image c - 1, whose buffer it takes) and waited for at the top of chunk c + 1, whose barrier publishes it - one chunk
       // before its first read (the multiplying waves read NSET - 1 k halves ahead, across the chunk boundary). Everything this wave has
       // in flight at a wait is one image: the counts are 0 and NPA.
-      if constexpr(EARLY) {
+      {
         const unsigned invW2 = (65536u + (unsigned)W2 - 1u) / (unsigned)W2;  // hp / W2 == hp * invW2 >> 16 for hp < 441, W2 <= 21
 #pragma unroll
         for(int j = 0; j < NPA; j++) {
@@ -293,12 +294,6 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
         }
 #pragma unroll
         for(int c = 1; c < DIST; c++)
-#pragma unroll
-          for(int j = 0; j < NPA; j++) issueA(c, j);
-      }
-      else {
-#pragma unroll
-        for(int c = 0; c < DIST; c++)
 #pragma unroll
           for(int j = 0; j < NPA; j++) issueA(c, j);
       }
@@ -380,7 +375,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
 #pragma unroll
     for(int wn = 0; wn < WN; wn++) gloadFrag(wf[slot][wn], chunkBase + (size_t)(hs >> 1) * wSlabStrideRw + (size_t)(wn * NTILE * ROWB), wOffLane[hs & 1]);
   };
-  if constexpr(REGW && EARLY) {
+  if constexpr(REGW) {
 #pragma unroll
     for(int hs = 0; hs + 1 < R; hs++) loadW(hs, wTile, hs);
   }
@@ -442,10 +437,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
     // fragments are requested per k half, R - 1 k halves before their use: in the steady state the requests of R - 2 k halves are younger.
     const size_t wSlabStride = wSlabStrideRw;
     const char* wCur = wTile;  // this chunk's nine slabs
-    if constexpr(!EARLY) {
-#pragma unroll
-      for(int hs = 0; hs + 1 < R; hs++) loadW(hs, wCur, hs);  // k half R - 1 follows in the first k half (the ring's rule below)
-    }
+    // (k halves 0 .. R - 2 were requested at the top of the wave; k half R - 1 follows in the first k half: the ring's rule below)
     waitVm<0>();  // this wave's mask and parameter requests (and, younger, the fragments - which the first MFMA needs anyway)
     __builtin_amdgcn_s_barrier();  // image 0, the mask and the parameters are published
     asm volatile("" ::: "memory");
@@ -677,11 +669,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
 // two MFMAs and four reads per step it is shorter, and three times as many CUs work. Every work-group still fetches the whole image
 // and every slab (the fetching waves are unchanged): three times the L2 traffic, which is idle at these sizes. Outputs are computed by
 // the same MFMAs in the same order: bit-identical.
-template <class TR, bool PACK, int DEPTH, int MTW, bool REGW = false, int WN = 1, bool EARLY = false>
+template <class TR, bool PACK, int DEPTH, int MTW, bool REGW = false, int WN = 1>
 hipError_t launchSmall(const ConvArgs& a, hipStream_t stream) {
   if(a.coutPad % (NTILE * WN) != 0) return hipErrorInvalidValue;
   if(REGW && a.wFrag == nullptr) return hipErrorInvalidValue;  // the register-weights shapes read the copy in fragment order
-  auto kern = convSmallKernel<TR, PACK, DEPTH, MTW, REGW, WN, EARLY>;
+  auto kern = convSmallKernel<TR, PACK, DEPTH, MTW, REGW, WN>;
   constexpr int LDS_BYTES = std::conditional_t<REGW, RWG, SG<PACK, DEPTH>>::LDS_BYTES;
   constexpr int MAX_DEVICES = 64;  // the > 64 KiB LDS opt-in is per function AND device (conv_kernel.h launchOne)
   static std::atomic<bool> attrSet[MAX_DEVICES];

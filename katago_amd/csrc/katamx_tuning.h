@@ -38,6 +38,11 @@ int kmx_debug_conv_cfg(int ks, int cout_pad, int batch, int* cfg, int* instantia
  * practical ceiling the convolution is measured against. Kernel tuning instrumentation. */
 int kmx_bench_mfma(int waves_per_wg, int wgs, int mode, int steps, int iters, double* avg_ms, double* tflops, double* core_mhz);
 
+/* What a dependent launch costs before it does anything: `launches` dependent launches of a 512-thread kernel with lds_bytes of LDS on
+ * `wgs` work-groups, captured in one hipGraph and replayed `iters` times; us per launch. mode 0: the kernel ends at once; 1: every lane
+ * loads 16 bytes the launch before stored and stores them again; 2: as 1 through LDS and a barrier. tools/launch_floor.py. */
+int kmx_bench_launch_floor(int wgs, int lds_bytes, int mode, int launches, int iters, double* us_per_launch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,7 @@ double benchConvStreams(int ks, int cfg, int cin, int cout, int batch, int nStre
 double benchSeam(int batch, int iters, int timing);  // conv_bench.hip
 double benchConvChain(int batch, int nConv, int chained, int iters, int timing);  // conv_bench.hip
 double benchMfma(int wavesPerWg, int wgs, int mode, int steps, int iters, double* tflops, double* coreMhz);       // conv_bench.hip
+double benchLaunchFloor(int wgs, int ldsBytes, int mode, int launches, int iters);                                 // conv_bench.hip
 }
 
 struct kmx_model {
@@ -528,6 +529,16 @@ int kmx_bench_mfma(int waves_per_wg, int wgs, int mode, int steps, int iters, do
       throw Error(KMX_ERR_INVALID_ARG, "kmx_bench_mfma: bad argument");
     (void)deviceCountOrThrow();
     *avg_ms = benchMfma(waves_per_wg, wgs, mode, steps, iters, tflops, core_mhz);
+  });
+}
+
+int kmx_bench_launch_floor(int wgs, int lds_bytes, int mode, int launches, int iters, double* us_per_launch) {
+  return guarded([&] {
+    if(!us_per_launch || wgs < 1 || wgs > 65536 || lds_bytes < 8192 || lds_bytes > 160 * 1024 || mode < 0 || mode > 2 || launches < 1 || launches > 4096 ||
+       iters < 1)
+      throw Error(KMX_ERR_INVALID_ARG, "kmx_bench_launch_floor: bad argument");
+    (void)deviceCountOrThrow();
+    *us_per_launch = benchLaunchFloor(wgs, lds_bytes, mode, launches, iters);
   });
 }
 

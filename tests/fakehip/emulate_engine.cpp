@@ -27,6 +27,7 @@ hipError_t launchConvChain(int, const ConvChainArgs&, hipStream_t) { return 801;
 double benchConv(int, int, int, int, int, int, int, int, int, int) { return 0.0; }
 double benchConvStreams(int, int, int, int, int, int, double, int, int) { return 0.0; }
 double benchMfma(int, int, int, int, int, double*, double*) { return 0.0; }
+double benchLaunchFloor(int, int, int, int, int) { return 0.0; }
 double benchSeam(int, int, int) { return 0.0; }
 double benchConvChain(int, int, int, int, int) { return 0.0; }
 

@@ -24,7 +24,7 @@ def test_header_symbols_exported_and_bound():
     # the public header holds the boundary only: kernel-tuning instrumentation lives in a private header (ABI 7)
     assert not [s for s in syms if s.startswith(("kmx_bench_", "kmx_debug_"))]
     tuning = declared_symbols(os.path.join("katago_amd", "csrc", "katamx_tuning.h"))
-    assert sorted(capi.TUNING_SIGNATURES) == tuning and len(tuning) == 6
+    assert sorted(capi.TUNING_SIGNATURES) == tuning and len(tuning) == 7
     for s in tuning:
         assert hasattr(lib, s), "libkatamx.so does not export %s" % s
 

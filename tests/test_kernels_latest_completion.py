@@ -123,9 +123,7 @@ def test_small_batch_shape_with_fetching_waves(emu_full_lib):
                 ("1", "1", "0", "0", "1"), ("1", "1", "0", "1", "1"), ("1", "1", "0", "2", "1"), ("1", "1", "1", "0", "3"), ("1", "1", "1", "1", "3"),
                 ("1", "1", "1", "2", "3"),
                 # (regw 2 with loaders_max_wgs=0: layers with an even number of channel tiles take the 64-channel register-weights shape, cfg 126)
-                ("1", "1", "0", "0", "2,loaders_max_wgs=0"), ("1", "1", "0", "1", "2,loaders_max_wgs=0"), ("1", "1", "0", "2", "2,loaders_max_wgs=0"),
-                # (the instantiations without the early requests: conv_small_kernel.h EARLY = false)
-                ("1", "1", "1", "2", "3,regw_early=0"), ("1", "1", "0", "1", "2,loaders_max_wgs=0,regw_early=0"))
+                ("1", "1", "0", "0", "2,loaders_max_wgs=0"), ("1", "1", "0", "1", "2,loaders_max_wgs=0"), ("1", "1", "0", "2", "2,loaders_max_wgs=0"))
     runs = run_parallel([([sys.executable, "-c", CW12_CODE, emu_full_lib],
                           dict(os.environ, KMX_CONV_TUNE="loaders=%s,loaders_depth=%s,loaders_split=%s,regw=%s" % (ld, depth, split, regw), KMX_EMU_LATE_DMA=late))
                          for ld, depth, split, late, regw in variants])
