@@ -116,16 +116,18 @@ def test_transformer_schedule_is_consistent(name, C, H, KVH, QD, VD, F, blocks, 
         assert "boardrms" in kinds and kinds.count("attention") == 3  # two inside the nested block, one in the trunk
     # every convolution tiles its padded channels with the chosen shape
     for (kname, grid, block, lds, args), k in zip(launches, kinds):
-        if k == "conv" and "convSmallKernel" in kname:  # the small-batch 3x3 shape: a board x 32 channels, 4 + 4 waves
-            cout_pad = int(args[4], 16) & 0xFFFFFFFF
-            # (grid z = 3: the cell tiles of a board over three work-groups while batch x channel tiles x 3 <= 256, cfg 117)
-            assert grid[:2] == (cout_pad // 32, n) and block == 512 and lds <= 160 * 1024
+        if k == "conv" and "convSmallKernel" in kname:  # the small-batch 3x3 shapes: a board x 32 (or 64) channels, 4 + 4 waves
+            cout_pad = int(args[5], 16) & 0xFFFFFFFF  # (ConvArgs: in, w, wFrag, zeroPage, inC | nChunks, coutPad | N, ...)
+            wn = 2 if kname.endswith("ELb1ELi2EEEvNS_8ConvArgsE") else 1  # cfg 126: two channel tiles per wave
+            # (grid z = 3: the cell tiles of a board over three work-groups while batch x channel tiles x 3 <= 256, cfg 127 / 117)
+            assert grid[:2] == (cout_pad // (32 * wn), n) and block == 512 and lds <= 160 * 1024
             assert grid[2] == (3 if n * (cout_pad // 32) * 3 <= 256 else 1), (grid, n, cout_pad)
+            assert wn == (2 if n * (cout_pad // 32) > 256 else 1), (kname, n, cout_pad)
         elif k == "conv":
             # kernel size, WN, WNW, ring depth, flags (0, or 262144 = ABL_SPLIT: a board's cell tiles over three work-groups, cfg 113)
             m = re.search(r"ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(0|262144)EEE", kname)
             ks, wn, wnw = int(m.group(1)), int(m.group(2)), int(m.group(3))
-            cout_pad = int(args[4], 16) & 0xFFFFFFFF
+            cout_pad = int(args[5], 16) & 0xFFFFFFFF
             assert grid == (cout_pad // (32 * wn * wnw), n, 3 if m.group(5) != "0" else 1) and block == 256 * wnw and lds <= 160 * 1024
 
 
