@@ -10,6 +10,7 @@
 
 #include "conv_chain_kernel.h"
 #include "conv_kernel.h"
+#include "conv_small_kernel.h"
 #include "engine.h"
 
 namespace kmx {
@@ -80,7 +81,13 @@ double benchConv(int ks, int cfg, int variant, int cin, int cout, int batch, int
   a.dbg = dbg.as<unsigned long long>();
   hipStream_t st = nullptr;
   auto launch = [&]() {
-    hipError_t e = variant == 0 ? launchConv(dtype, ks, cfg, a, st) : launchVariant(ks, cfg, variant, a, st);
+    // variant 9999: the register-weights small-batch shapes (cfg 126 / 127 / 128 of conv_mfma.hip) with cycle stamps (conv_small_kernel.h TIMING)
+    hipError_t e = variant == 0      ? launchConv(dtype, ks, cfg, a, st)
+                   : variant == 9999 ? (cfg == 128   ? smallk::launchSmall<TraitsBF16, false, 1, 3, true, 1, true>(a, st)
+                                        : cfg == 127 ? smallk::launchSmall<TraitsBF16, false, 1, 1, true, 1, true>(a, st)
+                                        : cfg == 126 ? smallk::launchSmall<TraitsBF16, false, 1, 3, true, 2, true>(a, st)
+                                                     : hipErrorInvalidValue)
+                                     : launchVariant(ks, cfg, variant, a, st);
     hipCheck(e, "bench conv launch");
   };
   for(int i = 0; i < 3; i++) launch();
@@ -105,6 +112,16 @@ double benchConv(int ks, int cfg, int variant, int cin, int cout, int batch, int
       fprintf(stderr, "[timing] wave %d: wait+barrier %llu | MFMA F0 + read F1 %llu | DMA issue %llu | MFMA F1 + read F0' %llu | loop %llu "
                       "| prologue %llu | epilogue %llu | kernel %llu cycles\n",
               w, h[w * 8 + 0], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3], h[w * 8 + 4], h[w * 8 + 5], h[w * 8 + 6], h[w * 8 + 7]);
+  }
+  if(variant == 9999) {  // one line per wave of the middle board's first work-group, last launch
+    unsigned long long h[64];
+    hipCheck(hipMemcpy(h, dbg.get(), sizeof(h), hipMemcpyDeviceToHost), "copy timing");
+    for(int w = 0; w < 4; w++)
+      fprintf(stderr, "[timing] multiplying wave %d: start -> ready %llu | wait for the first image, fragments, parameters %llu | waits at the chunk barriers %llu | "
+                      "the chunks' k halves %llu | epilogue %llu | kernel %llu cycles\n", w, h[w * 8], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3], h[w * 8 + 4], h[w * 8 + 7]);
+    for(int w = 4; w < 8; w++)
+      fprintf(stderr, "[timing] fetching wave %d: start -> two images requested %llu | wait for image 0 %llu | waits for an image %llu | waits at the chunk barriers %llu | "
+                      "kernel %llu cycles\n", w, h[w * 8], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3], h[w * 8 + 7]);
   }
   return (double)ms / iters;
 }

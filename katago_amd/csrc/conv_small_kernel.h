@@ -175,7 +175,7 @@ __device__ __forceinline__ void waitFragSel(V8& frag, int n) {
 
 // PACK (the second instantiation): register allocation capped at 128 per lane so that TWO work-groups share a CU (4 waves per SIMD, 2 x 68 KB
 // of LDS) - for batches whose work-groups outnumber the CUs; the cap costs 48 bytes of scratch per lane outside the loop.
-template <class TR, bool PACK, int DEPTH, int MTW, bool REGW, int WN>
+template <class TR, bool PACK, int DEPTH, int MTW, bool REGW, int WN, bool TIMING>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ? 4 : 2, PACK ? 4 : REGW ? 2 : 3))) void convSmallKernel(const ConvArgs a) {
   typedef typename TR::T T;
   typedef typename TR::V8 V8;
@@ -192,6 +192,19 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
   // box (profiles/r05_steps/regw/call3_*): 12.32 -> 12.19 us per 3x3 launch at batch 8, 17.66 -> 17.38 at 32, 25.64 -> 25.42 at 64 - a
   // launch's fixed time is not its instruction count. The first form is deleted.
   constexpr bool EARLY = REGW;
+  // TIMING (conv_bench.hip only, register-weights shapes): cycle stamps of one work-group's waves into ConvArgs::dbg, eight per wave -
+  // multiplying waves: [0] start -> ready to wait, [1] the wait for the first image / fragments / parameters, [2] sum of the waits at the
+  // chunk barriers, [3] sum of the chunks' 18 k halves, [4] epilogue, [7] whole kernel; fetching waves: [0] start -> the first two images
+  // requested, [1] the wait for image 0, [2] sum of the waits for an image, [3] sum of the waits at the chunk barriers, [7] whole kernel
+  static_assert(!TIMING || REGW, "");
+  const unsigned long long tk0 = TIMING ? __builtin_readcyclecounter() : 0;
+  unsigned long long tkA = 0, tkB = 0, tkC = 0, tkD = 0;
+  auto stampOut = [&](unsigned long long t4) {
+    if(TIMING && a.dbg != nullptr && (threadIdx.x & 63) == 0 && blockIdx.x == 0 && (int)blockIdx.y == a.N / 2 && blockIdx.z == 0) {
+      unsigned long long* d = a.dbg + (threadIdx.x >> 6) * 8;
+      d[0] = tkA; d[1] = tkB; d[2] = tkC; d[3] = tkD; d[4] = t4; d[7] = __builtin_readcyclecounter() - tk0;
+    }
+  };
   constexpr int NTILEW = NTILE * WN;  // output channels per work-group
   typedef std::conditional_t<REGW, RWG, SG<PACK, DEPTH>> G;
   constexpr int D = G::D, NSW = G::NSW, NSA = G::NSA, DIST = G::DIST;
@@ -297,17 +310,24 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
 #pragma unroll
           for(int j = 0; j < NPA; j++) issueA(c, j);
       }
+      unsigned long long tq = 0;
+      if(TIMING) { tq = __builtin_readcyclecounter(); tkA = tq - tk0; }
       waitVm<(DIST - 1) * NPA>();  // image 0 (and, older, this wave's piece of the mask) has landed; image 1 is in flight
+      if(TIMING) tkB = __builtin_readcyclecounter() - tq;
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       for(int chunk = 0; chunk < nChunks; chunk++) {
+        if(TIMING) tq = __builtin_readcyclecounter();
         waitVm<0>();  // image chunk + 1
+        if(TIMING) { const unsigned long long t = __builtin_readcyclecounter(); tkC += t - tq; tq = t; }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if(TIMING) tkD += __builtin_readcyclecounter() - tq;
 #pragma unroll
         for(int j = 0; j < NPA; j++) issueA(chunk + DIST, j);
       }
       waitVm<0>();  // requests past the end went to the slack area: they must land before the LDS is released
+      stampOut(0);
       return;
     }
     else {
@@ -438,9 +458,12 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
     const size_t wSlabStride = wSlabStrideRw;
     const char* wCur = wTile;  // this chunk's nine slabs
     // (k halves 0 .. R - 2 were requested at the top of the wave; k half R - 1 follows in the first k half: the ring's rule below)
+    unsigned long long tq = 0;
+    if(TIMING) { tq = __builtin_readcyclecounter(); tkA = tq - tk0; }
     waitVm<0>();  // this wave's mask and parameter requests (and, younger, the fragments - which the first MFMA needs anyway)
     __builtin_amdgcn_s_barrier();  // image 0, the mask and the parameters are published
     asm volatile("" ::: "memory");
+    if(TIMING) tkB = __builtin_readcyclecounter() - tq;
     V8 af[NSET][MTW];
     // address of the image fragment of k half `hs` (0 .. NHS-1, or past the end: the next chunk's) of the chunk whose buffer is curA
     auto fragAddr = [&](int hs, unsigned curA, unsigned nextA, int pt) {
@@ -462,8 +485,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
       const unsigned curA = (unsigned)(chunk % NSA) * ACT_BYTES;
       const unsigned nextA = (unsigned)((chunk + 1) % NSA) * ACT_BYTES;
       const char* const wNext = wCur + NT * wSlabStride;
+      if(TIMING) tq = __builtin_readcyclecounter();
       __builtin_amdgcn_s_barrier();  // publishes image chunk + 1; behind it the fetching waves overwrite image chunk - 1
       asm volatile("" ::: "memory");
+      if(TIMING) { const unsigned long long t = __builtin_readcyclecounter(); tkC += t - tq; tq = t; }
 #pragma unroll
       for(int hs = 0; hs < NHS; hs++) {
         // k half hs: its MFMAs; behind them, one by one, the image fragments of k half hs + NSET - 1 into the set the PREVIOUS k half
@@ -494,6 +519,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
           }
         }
       }
+      if(TIMING) tkD += __builtin_readcyclecounter() - tq;
       wCur = wNext;
       chunk++;
     };
@@ -565,7 +591,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
 
   }  // !REGW
   // ---- epilogue: conv_kernel.h's, for one 32-channel tile per wave and cell tile ----
-  if(!waveActive) return;
+  if(!waveActive) {
+    stampOut(0);
+    return;
+  }
+  const unsigned long long tEpi = TIMING ? __builtin_readcyclecounter() : 0;
   const unsigned maskAddr = ldsBase + MASK_OFFSET;
   const unsigned scAddr = ldsBase + PARAM_OFFSET, biAddr = scAddr + 64 * 4, nbAddr = biAddr + 64 * 4;
   const bool hasResid = a.resid != nullptr;
@@ -662,6 +692,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
     if(hasResid) epilogue(kindTag, ActKindTag<1>());
     else epilogue(kindTag, ActKindTag<0>());
   });
+  if(TIMING) stampOut(__builtin_readcyclecounter() - tEpi);
 }
 
 // MTW = 1: the cell tiles of a board x 32 channels over THREE work-groups (grid z) - for batches that leave most CUs idle (batch x
@@ -669,11 +700,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
 // two MFMAs and four reads per step it is shorter, and three times as many CUs work. Every work-group still fetches the whole image
 // and every slab (the fetching waves are unchanged): three times the L2 traffic, which is idle at these sizes. Outputs are computed by
 // the same MFMAs in the same order: bit-identical.
-template <class TR, bool PACK, int DEPTH, int MTW, bool REGW = false, int WN = 1>
+template <class TR, bool PACK, int DEPTH, int MTW, bool REGW = false, int WN = 1, bool TIMING = false>
 hipError_t launchSmall(const ConvArgs& a, hipStream_t stream) {
   if(a.coutPad % (NTILE * WN) != 0) return hipErrorInvalidValue;
   if(REGW && a.wFrag == nullptr) return hipErrorInvalidValue;  // the register-weights shapes read the copy in fragment order
-  auto kern = convSmallKernel<TR, PACK, DEPTH, MTW, REGW, WN>;
+  auto kern = convSmallKernel<TR, PACK, DEPTH, MTW, REGW, WN, TIMING>;
   constexpr int LDS_BYTES = std::conditional_t<REGW, RWG, SG<PACK, DEPTH>>::LDS_BYTES;
   constexpr int MAX_DEVICES = 64;  // the > 64 KiB LDS opt-in is per function AND device (conv_kernel.h launchOne)
   static std::atomic<bool> attrSet[MAX_DEVICES];

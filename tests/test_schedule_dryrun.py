@@ -118,7 +118,7 @@ def test_transformer_schedule_is_consistent(name, C, H, KVH, QD, VD, F, blocks, 
     for (kname, grid, block, lds, args), k in zip(launches, kinds):
         if k == "conv" and "convSmallKernel" in kname:  # the small-batch 3x3 shapes: a board x 32 (or 64) channels, 4 + 4 waves
             cout_pad = int(args[5], 16) & 0xFFFFFFFF  # (ConvArgs: in, w, wFrag, zeroPage, inC | nChunks, coutPad | N, ...)
-            wn = 2 if kname.endswith("ELb1ELi2EEEvNS_8ConvArgsE") else 1  # cfg 126: two channel tiles per wave
+            wn = 2 if kname.endswith("ELb1ELi2ELb0EEEvNS_8ConvArgsE") else 1  # cfg 126: two channel tiles per wave
             # (grid z = 3: the cell tiles of a board over three work-groups while batch x channel tiles x 3 <= 256, cfg 127 / 117)
             assert grid[:2] == (cout_pad // (32 * wn), n) and block == 512 and lds <= 160 * 1024
             assert grid[2] == (3 if n * (cout_pad // 32) * 3 <= 256 else 1), (grid, n, cout_pad)
