@@ -85,7 +85,6 @@ double benchConv(int ks, int cfg, int variant, int cin, int cout, int batch, int
     hipError_t e = variant == 0      ? launchConv(dtype, ks, cfg, a, st)
                    : variant == 9999 ? (cfg == 128   ? smallk::launchSmall<TraitsBF16, false, 1, 3, true, 1, true>(a, st)
                                         : cfg == 127 ? smallk::launchSmall<TraitsBF16, false, 1, 1, true, 1, true>(a, st)
-                                        : cfg == 125 ? smallk::launchSmall<TraitsBF16, false, 1, 2, true, 1, true>(a, st)
                                         : cfg == 126 ? smallk::launchSmall<TraitsBF16, false, 1, 3, true, 2, true>(a, st)
                                                      : hipErrorInvalidValue)
                                      : launchVariant(ks, cfg, variant, a, st);

@@ -184,13 +184,6 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
   const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smemSmall;
   static_assert(!REGW || (!PACK && DEPTH == 1), "the register-weights shape is one instantiation per (MTW, WN)");
   static_assert(WN == 1 || (REGW && WN == 2 && MTW == MT), "two channel tiles per wave exist for the unsplit register-weights shape only");
-  // PAIR (MTW = 2, register-weights only): the cell tiles of a board over three work-groups like MTW = 1, but TWO multiplying waves of two
-  // cell tiles each instead of four of one. At one tile per wave the chunk is bound by the CU's 64 B/clk vector-memory path - every one
-  // of the four waves loads the chunk's 18 KB of fragments: 72 of the 100 KB a chunk pulls through it, 1.77 k cycles per chunk for 576 of
-  // matrix work (profiles/r05_steps/regw/small_conv_timing.txt). Two waves load them twice: 64 KB per chunk against 1152 cycles of matrix
-  // work on two SIMDs. Waves 2 and 3 only fetch their share of the mask and the parameters and meet the others at the barriers.
-  constexpr bool PAIR = MTW == 2;
-  static_assert(!PAIR || (REGW && WN == 1), "");
   // EARLY (the register-weights shapes): what a launch waits for first goes out first. In their first form the first image request left its
   // wave ~560 instructions into the kernel (seven pieces' source offsets, a division by the halo width each, were computed before the first
   // request), the first weight fragment ~250 (behind the cell bookkeeping of the epilogue), the first residual tile only after the loop.
@@ -393,18 +386,6 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
   // ===================================================== the multiplying waves =====================================================
   // REGW: the ring of weight fragments and its loads (described at the loop); EARLY: the first R - 1 k halves are requested here, before
   // the wave's cell bookkeeping
-  if constexpr(PAIR) {
-    if(wave >= 2) {  // wave-uniform
-      waitVm<0>();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      for(int chunk = 0; chunk < nChunks; chunk++) {
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-      }
-      return;
-    }
-  }
   constexpr int R = !REGW ? 1 : WN == 1 ? RWG::NHS : RWG::NHS / 2;
   V8 wf[R][WN];
   const char* const wTile = (const char*)a.wFrag + (size_t)cout0 * ROWB;
@@ -426,20 +407,18 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
   // MTW = 3: the wave's three cell tiles; MTW = 1 (grid z = 3): tile blockIdx.z of them - three work-groups share a board x 32 channels,
   // each fetches the whole image and slabs and does a third of the matrix work (see launchSmall)
   const int pt0 = MTW == MT ? 0 : (int)blockIdx.z;
-  // first GEMM column of the wave's cell tile pt (PAIR: tile blockIdx.z of the cell-tile groups 2 wave and 2 wave + 1)
-  auto tileBase = [&](int pt) { return PAIR ? (2 * wm + pt) * (32 * MT) + pt0 * 32 : wm * (32 * MT) + (pt0 + pt) * 32; };
   unsigned aRow4[MTW];
   int cellOfTile[MTW];
 #pragma unroll
   for(int pt = 0; pt < MTW; pt++) {
-    int j = tileBase(pt) + myPos;
+    int j = wm * (32 * MT) + (pt0 + pt) * 32 + myPos;
     j = cellOf(j < S ? j : S - 1);
     cellOfTile[pt] = j;
     const int y = j / X, x = j - y * X;
     aRow4[pt] = (unsigned)((y + HALO) * W2 + (x + HALO)) << 2;
   }
   const unsigned c40 = khalf << 4;
-  const bool waveActive = tileBase(0) < S;
+  const bool waveActive = wm * (32 * MT) + pt0 * 32 < S;
   auto ldsV8 = [&](unsigned addr) { return *(const __attribute__((address_space(3))) V8*)addr; };
   auto ldsF4 = [&](unsigned addr) { return *(const __attribute__((address_space(3))) f32x4*)addr; };
   auto ldsF1 = [&](unsigned addr) { return *(const __attribute__((address_space(3))) float*)addr; };
@@ -465,7 +444,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
   if constexpr(REGW) {
     // ---- weights in registers: a chunk's 18 fragments a whole chunk ahead, one barrier per chunk ----
     constexpr int NHS = RWG::NHS;
-    constexpr int NSET = MTW < MT ? 6 : 3;  // image-fragment register sets; the reads run NSET - 1 k halves ahead of their MFMAs
+    constexpr int NSET = MTW == 1 ? 6 : 3;  // image-fragment register sets; the reads run NSET - 1 k halves ahead of their MFMAs
     static_assert(NHS % NSET == 0, "the set of a k half must be a compile-time index");
     // the ring of weight fragments: R k halves of WN fragments each. One channel tile per wave: a whole chunk (18 x 4 registers); two: half
     // a chunk (9 x 8 registers, and a k half is twice as long)
@@ -640,7 +619,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
 #pragma unroll
     for(int q = 0; q < WN * MTW; q++) {
       const int pt = q % MTW, ct0 = cout0 + (q / MTW) * 32;
-      const int cellBase = tileBase(pt);
+      const int cellBase = wm * (32 * MT) + (pt0 + pt) * 32;
       // wave-uniform. (Two channel tiles per wave: a cell tile off the board is walked with every piece going to the trash area - the
       // residual requests run one (channel tile, cell tile) ahead in a fixed order.)
       if(WN == 1 && cellBase >= S) break;
@@ -738,7 +717,7 @@ hipError_t launchSmall(const ConvArgs& a, hipStream_t stream) {
     if(e != hipSuccess) return e;
     attrSet[dev].store(true, std::memory_order_release);
   }
-  hipLaunchKernelGGL(kern, dim3(a.coutPad / (NTILE * WN), a.N, MTW == MT ? 1 : MT), dim3(NTHREADS), LDS_BYTES, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.coutPad / (NTILE * WN), a.N, MT / MTW), dim3(NTHREADS), LDS_BYTES, stream, a);
   return hipGetLastError();
 }
 

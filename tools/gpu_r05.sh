@@ -84,14 +84,6 @@ regw)
     echo "$t: $(cat gpurun_out/selfplay_full_regw_${t#*=}.txt)" | tee -a $OUT/selfplay_rows.txt
   done
   ;;
-pair)
-  # the split register-weights shape with two multiplying waves of two cell tiles (cfg 125, KMX_CONV_TUNE regw_pair=1) against four of one (127)
-  KMX_CONV_TUNE=regw_pair=1 timeout 600 python -m pytest tests/test_gpu_layers.py tests/test_gpu_fuzz.py "tests/test_gpu_model.py::test_full_batch_properties" -m gpu -q -p no:cacheprovider 2>&1 | tail -40 | cut -c1-600 | tee $OUT/parity.log
-  for t in regw_pair=0 regw_pair=1 regw_pair=0 regw_pair=1; do
-    KMX_CONV_TUNE=$t timeout 200 python tools/small_batch_scan.py 2>&1 | grep SCAN | tee -a $OUT/small_batch_scan.txt
-  done
-  timeout 200 python tools/small_conv_timing.py 2>&1 | head -44 | tee $OUT/small_conv_timing.txt
-  ;;
 small)
   timeout 900 python -m pytest tests/test_gpu_layers.py "tests/test_gpu_model.py::test_model_vs_oracle" "tests/test_gpu_model.py::test_full_batch_properties" tests/test_gpu_fuzz.py -m gpu -q -p no:cacheprovider 2>&1 | tail -3 | tee $OUT/parity.log
   timeout 300 python tools/small_batch_scan.py 2>&1 | grep SCAN | tee $OUT/small_batch_scan.txt
