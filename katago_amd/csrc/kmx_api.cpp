@@ -518,7 +518,7 @@ int kmx_debug_conv_cfg(int ks, int cout_pad, int batch, int* cfg, int* instantia
       throw Error(KMX_ERR_INVALID_ARG, "kmx_debug_conv_cfg: bad argument");
     *cfg = chooseConvCfg(ks, cout_pad, batch);
     // the special shapes of conv_mfma.hip: 113 / 114 (1x1, deep ring), 117 (3x3, split) and 118 / 119 (3x3, fetching waves) tile 32 channels, 124 tiles 64
-    const int ntile = *cfg == 124 ? 64 : *cfg >= 111 ? 32 : 32 * (*cfg / 10) * (*cfg % 10);
+    const int ntile = (*cfg == 124 || *cfg == 126) ? 64 : *cfg >= 111 ? 32 : 32 * (*cfg / 10) * (*cfg % 10);
     *instantiated = (convCfgInstantiated(ks, *cfg) && cout_pad % ntile == 0) ? 1 : 0;
   });
 }
