@@ -14,6 +14,11 @@
 // and meet the others at the step's barrier. Same decomposition (board x 32 channels: same DMA bytes, same LDS images), same MFMAs
 // per output in the same K order (chunk, tap, k half) and the same epilogue arithmetic: BIT-IDENTICAL to every other shape
 // (tests/test_kernels_latest_completion.py on the CPU emulation, tests/test_gpu_layers.py on the MI355X).
+//
+// Round 5, the default since then (REGW, below): the multiplying waves load their weight fragments straight from global memory into
+// registers - from a copy of the weights in fragment order, ConvArgs::wFrag -, LDS holds only the board image, and there is ONE barrier
+// per chunk; three instantiations: cfg 128 (a board x 32 channels), 127 (its cell tiles over three work-groups), 126 (a board x 64
+// channels). The slab-ring form above stays instantiated behind KMX_CONV_TUNE=regw=0 as the measured baseline.
 #ifndef KMX_CONV_SMALL_KERNEL_H_
 #define KMX_CONV_SMALL_KERNEL_H_
 
