@@ -241,9 +241,12 @@ def test_handle_errors(ctx19, small_model):
     model = nn.loadModelFile(small_model)
     with pytest.raises(nn.KatamxError):
         nn.createComputeHandle(ctx19["bf16"], model, 0)
+    # (fp32 was refused until round 5 - KMX_ERR_UNSUPPORTED, asserted here; it is a served mode now, and what must be refused is a
+    # precision mode that does not exist)
+    nn.createComputeContext([0], 19, 19, precision="fp32").close()
     with pytest.raises(nn.KatamxError) as e:
-        nn.createComputeContext([0], 19, 19, precision="fp32")
-    assert e.value.code == capi.KMX_ERR_UNSUPPORTED
+        nn.createComputeContext([0], 19, 19, precision=99)
+    assert e.value.code == capi.KMX_ERR_INVALID_ARG
     with pytest.raises(nn.KatamxError):
         nn.createComputeContext([0], 25, 19)
     h = nn.createComputeHandle(ctx19["bf16"], model, 4)
