@@ -50,6 +50,7 @@ constexpr int CFG_LOADERS_PACKED = 119;  // the same with two work-groups per CU
 constexpr int CFG_REGW = 128;        // a board x 32 channels in one work-group (in place of cfg 118)
 constexpr int CFG_REGW_SPLIT = 127;  // its cell tiles over three work-groups (in place of cfg 117)
 constexpr int CFG_REGW64 = 126;      // a board x 64 channels (two channel tiles per wave), one per CU, for the next 256 work-groups (in place of cfg 119)
+constexpr int CFG_REGW_HALF = 125;   // cfg 128's cell tiles over TWO work-groups (two tiles | one), between the three-way split and cfg 128
 // ---- ONE debug override for every switch of the shape choice: KMX_CONV_TUNE="key=value,key=value" (read once) ----
 // Defaults are the product; the keys exist for A/B scans (tools/small_batch_scan.py) and for tests that force a shape at a size the
 // chooser would not pick it for (tests/test_kernels_latest_completion.py, tests/test_engine_emulated.py). Unknown keys abort: a typo must
@@ -70,9 +71,11 @@ constexpr int CFG_REGW64 = 126;      // a board x 64 channels (two channel tiles
 //                        from host rows 1.38 -> 1.31 ms at batch 1, 1.59 -> 1.49 at 8, 2.11 -> 1.93 at 16, 2.12 -> 1.98 at 32, 3.24 -> 2.88 at 64,
 //                        3.78 -> 3.36 at 85; self-play at 8 games x 8 leaves 20.4 -> 21.7 k NN rows/s
 //   regw64_max_wgs  256  work-groups up to which cfg 126 is taken
+//   regw_half       0    cfg 125 (cell tiles over two work-groups) while batch x channel tiles x 2 <= loaders_max_wgs; 2: also where the
+//                        three-way split would be taken (tests)
 struct ConvTune {
   int minWgs8 = 150, loaders = 1, loadersDepth = 1, loadersSplit = 1, loadersMaxWgs = 256, packedMaxWgs = 512, deep1x1 = 1, deep1x1MaxWgs = 256,
-      split1x1 = 1, regw = 3, regw64MaxWgs = 256;
+      split1x1 = 1, regw = 3, regw64MaxWgs = 256, regwHalf = 0;
 };
 const ConvTune& convTune() {
   static const ConvTune t = [] {
@@ -82,7 +85,7 @@ const ConvTune& convTune() {
     const struct { const char* key; int* v; } keys[] = {
       {"min_wgs8", &t.minWgs8}, {"loaders", &t.loaders}, {"loaders_depth", &t.loadersDepth}, {"loaders_split", &t.loadersSplit},
       {"loaders_max_wgs", &t.loadersMaxWgs}, {"packed_max_wgs", &t.packedMaxWgs}, {"deep1x1", &t.deep1x1},
-      {"deep1x1_max_wgs", &t.deep1x1MaxWgs}, {"split1x1", &t.split1x1}, {"regw", &t.regw}, {"regw64_max_wgs", &t.regw64MaxWgs}};
+      {"deep1x1_max_wgs", &t.deep1x1MaxWgs}, {"split1x1", &t.split1x1}, {"regw", &t.regw}, {"regw64_max_wgs", &t.regw64MaxWgs}, {"regw_half", &t.regwHalf}};
     std::string s(e);
     size_t i = 0;
     while(i < s.size()) {
@@ -118,6 +121,7 @@ hipError_t launchT(int ks, int cfg, const ConvArgs& a, hipStream_t stream) {
   if(ks == 3 && cfg == CFG_REGW) return smallk::launchSmall<TR, false, 1, 3, true>(a, stream);
   if(ks == 3 && cfg == CFG_REGW_SPLIT) return smallk::launchSmall<TR, false, 1, 1, true>(a, stream);
   if(ks == 3 && cfg == CFG_REGW64) return smallk::launchSmall<TR, false, 1, 3, true, 2>(a, stream);
+  if(ks == 3 && cfg == CFG_REGW_HALF) return smallk::launchSmall<TR, false, 1, 2, true>(a, stream);
   if(ks == 1 && cfg == CFG_DEEP1X1_4) return launchOne<TR, 1, 1, 1, 4, 0>(a, stream);
   if(ks == 1 && cfg == CFG_DEEP1X1_64) return launchOne<TR, 1, 2, 1, 4, 0>(a, stream);
   if(ks == 1 && cfg == CFG_DEEP1X1_SPLIT) return launchOne<TR, 1, 1, 1, 4, ABL_SPLIT>(a, stream);
@@ -140,7 +144,7 @@ hipError_t launchConv(int dtype, int ks, int cfg, const ConvArgs& a, hipStream_t
 }
 
 bool convCfgInstantiated(int ks, int cfg) {
-  if(ks == 3 && (cfg == CFG_LOADERS || cfg == CFG_LOADERS_SPLIT || cfg == CFG_LOADERS_PACKED || cfg == CFG_REGW || cfg == CFG_REGW_SPLIT || cfg == CFG_REGW64)) return true;
+  if(ks == 3 && (cfg == CFG_LOADERS || cfg == CFG_LOADERS_SPLIT || cfg == CFG_LOADERS_PACKED || cfg == CFG_REGW || cfg == CFG_REGW_SPLIT || cfg == CFG_REGW64 || cfg == CFG_REGW_HALF)) return true;
   if(ks == 1 && (cfg == CFG_DEEP1X1_4 || cfg == CFG_DEEP1X1_64 || cfg == CFG_DEEP1X1_SPLIT)) return true;
 #define KMX_CFG(KS_, WNW_, WN_, D_) \
   if(ks == KS_ && cfg == 10 * WNW_ + WN_) return true;
@@ -167,9 +171,11 @@ int chooseConvCfg(int ks, int coutPad, int batch) {
   if(widest8 && wgs(widest8) >= tn.minWgs8) return widest8;
   // the fetching-waves shape while it is the only work-group on its CU (134 VGPRs x 8 waves: one work-group per CU), its cell tiles over
   // three work-groups while even that leaves CUs idle
+  if(ks == 3 && tn.loaders && tn.loadersSplit && tn.regw >= 3 && tn.regwHalf >= 2 && batch * tiles * 2 <= tn.loadersMaxWgs) return CFG_REGW_HALF;
   if(ks == 3 && tn.loaders && tn.loadersSplit && batch * tiles * 3 <= tn.loadersMaxWgs) return tn.regw >= 3 ? CFG_REGW_SPLIT : CFG_LOADERS_SPLIT;
   // (split AND two work-groups per CU for the next 256 work-groups - 88 registers, 68 KB of LDS - measured within 1 % of the unsplit
   // shape at batch 16 - 28 and is not kept: profiles/r04_steps/small_batch/split1x1_scan.txt)
+  if(ks == 3 && tn.loaders && tn.loadersSplit && tn.regw >= 3 && tn.regwHalf && batch * tiles * 2 <= tn.loadersMaxWgs) return CFG_REGW_HALF;
   if(ks == 3 && tn.loaders && batch * tiles <= tn.loadersMaxWgs) return tn.regw ? CFG_REGW : CFG_LOADERS;
   // ... and two per CU up to twice that. Measured on the MI355X, b18c384nbt device-resident: batch 43 2.72 -> 2.43 ms per pass,
   // 48 2.77 -> 2.51, 64 2.86 -> 2.69, 85 3.06 -> 3.05; beyond two per CU it loses (96: 3.89 -> 4.10 ms),

@@ -411,7 +411,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
   for(int kk = 0; kk < 2; kk++) wLane[kk] = bufW + (unsigned)(lane & 31) * ROWB + (((kk * 2 + khalf) ^ wXor) << 4);
   // MTW = 3: the wave's three cell tiles; MTW = 1 (grid z = 3): tile blockIdx.z of them - three work-groups share a board x 32 channels,
   // each fetches the whole image and slabs and does a third of the matrix work (see launchSmall)
-  const int pt0 = MTW == MT ? 0 : (int)blockIdx.z;
+  // MTW = 2 (register-weights only, cfg 125): the cell tiles over TWO work-groups - grid z = 0: tiles 0 and 1 of each wave, z = 1: tile 2
+  // (its second "tile" lies past the wave's three: multiplied like any other, never stored) - for the batches between the three-way
+  // split and one work-group per board x 32 channels
+  static_assert(MTW != 2 || (REGW && WN == 1), "");
+  const int pt0 = MTW == MT ? 0 : MTW == 2 ? 2 * (int)blockIdx.z : (int)blockIdx.z;
   unsigned aRow4[MTW];
   int cellOfTile[MTW];
 #pragma unroll
@@ -449,7 +453,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
   if constexpr(REGW) {
     // ---- weights in registers: a chunk's 18 fragments a whole chunk ahead, one barrier per chunk ----
     constexpr int NHS = RWG::NHS;
-    constexpr int NSET = MTW == 1 ? 6 : 3;  // image-fragment register sets; the reads run NSET - 1 k halves ahead of their MFMAs
+    constexpr int NSET = MTW < MT ? 6 : 3;  // image-fragment register sets; the reads run NSET - 1 k halves ahead of their MFMAs
     static_assert(NHS % NSET == 0, "the set of a k half must be a compile-time index");
     // the ring of weight fragments: R k halves of WN fragments each. One channel tile per wave: a whole chunk (18 x 4 registers); two: half
     // a chunk (9 x 8 registers, and a k half is twice as long)
@@ -625,6 +629,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
     for(int q = 0; q < WN * MTW; q++) {
       const int pt = q % MTW, ct0 = cout0 + (q / MTW) * 32;
       const int cellBase = wm * (32 * MT) + (pt0 + pt) * 32;
+      if(MTW == 2 && pt0 + pt >= MT) break;  // wave-uniform: the tile past the wave's three
       // wave-uniform. (Two channel tiles per wave: a cell tile off the board is walked with every piece going to the trash area - the
       // residual requests run one (channel tile, cell tile) ahead in a fixed order.)
       if(WN == 1 && cellBase >= S) break;
@@ -722,7 +727,7 @@ hipError_t launchSmall(const ConvArgs& a, hipStream_t stream) {
     if(e != hipSuccess) return e;
     attrSet[dev].store(true, std::memory_order_release);
   }
-  hipLaunchKernelGGL(kern, dim3(a.coutPad / (NTILE * WN), a.N, MT / MTW), dim3(NTHREADS), LDS_BYTES, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.coutPad / (NTILE * WN), a.N, MTW == MT ? 1 : MTW == 2 ? 2 : MT), dim3(NTHREADS), LDS_BYTES, stream, a);
   return hipGetLastError();
 }
 

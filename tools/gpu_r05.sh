@@ -84,6 +84,14 @@ regw)
     echo "$t: $(cat gpurun_out/selfplay_full_regw_${t#*=}.txt)" | tee -a $OUT/selfplay_rows.txt
   done
   ;;
+half)
+  # cfg 125: the register-weights shape with its cell tiles over TWO work-groups (KMX_CONV_TUNE regw_half=1: batch 15-21 at 192 channels;
+  # =2 forces it wherever the three-way split would be taken, for the parity run)
+  KMX_CONV_TUNE=regw_half=2 timeout 600 python -m pytest tests/test_gpu_layers.py tests/test_gpu_fuzz.py "tests/test_gpu_model.py::test_full_batch_properties" -m gpu -q -p no:cacheprovider 2>&1 | tail -40 | cut -c1-600 | tee $OUT/parity.log
+  for t in regw_half=0 regw_half=1 regw_half=0 regw_half=1; do
+    KMX_CONV_TUNE=$t timeout 200 python tools/small_batch_scan.py 2>&1 | grep SCAN | tee -a $OUT/small_batch_scan.txt
+  done
+  ;;
 small)
   timeout 900 python -m pytest tests/test_gpu_layers.py "tests/test_gpu_model.py::test_model_vs_oracle" "tests/test_gpu_model.py::test_full_batch_properties" tests/test_gpu_fuzz.py -m gpu -q -p no:cacheprovider 2>&1 | tail -3 | tee $OUT/parity.log
   timeout 300 python tools/small_batch_scan.py 2>&1 | grep SCAN | tee $OUT/small_batch_scan.txt

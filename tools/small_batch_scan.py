@@ -31,7 +31,7 @@ def main():
     out = {"tune": os.environ.get("KMX_CONV_TUNE", "default"), "precision": h.precision, "ms_per_pass": {}, "rows_per_s": {}}
     ref = nn.getOutput(h, sp, gl, sym)  # 64 rows: the 4-wave shapes
     same = True
-    for n in (1, 2, 8, 16, 42, 48):
+    for n in (1, 2, 8, 16, 20, 42, 48):
         got = nn.getOutput(h, sp[:n], gl[:n], sym[:n])
         same = same and all(np.array_equal(got[k], ref[k][:n]) for k in ref)
     big = nn.getOutput(h, np.tile(sp, (4, 1, 1)), np.tile(gl, (4, 1)), np.tile(sym, 4))  # 256 rows: the 8-wave shapes, two streams
@@ -41,7 +41,7 @@ def main():
     big85 = nn.getOutput(h, np.tile(sp, (2, 1, 1))[:85], np.tile(gl, (2, 1))[:85], np.tile(sym, 2)[:85])
     same = same and all(np.array_equal(big85[k][:64], ref[k]) for k in ref)
     out["rows_bit_identical_across_batch_sizes"] = bool(same)
-    for n in (1, 2, 4, 8, 16, 24, 32, 42, 48, 64, 85):
+    for n in (1, 2, 4, 8, 15, 16, 18, 21, 24, 32, 42, 48, 64, 85):
         spn, gln, symn = (np.tile(sp, (2, 1, 1))[:n], np.tile(gl, (2, 1))[:n], np.tile(sym, 2)[:n]) if n > 64 else (sp[:n], gl[:n], sym[:n])
         for _ in range(3):
             nn.getOutput(h, spn, gln, symn)
