@@ -123,7 +123,9 @@ def test_small_batch_shape_with_fetching_waves(emu_full_lib):
                 ("1", "1", "0", "0", "1"), ("1", "1", "0", "1", "1"), ("1", "1", "0", "2", "1"), ("1", "1", "1", "0", "3"), ("1", "1", "1", "1", "3"),
                 ("1", "1", "1", "2", "3"),
                 # (regw 2 with loaders_max_wgs=0: layers with an even number of channel tiles take the 64-channel register-weights shape, cfg 126)
-                ("1", "1", "0", "0", "2,loaders_max_wgs=0"), ("1", "1", "0", "1", "2,loaders_max_wgs=0"), ("1", "1", "0", "2", "2,loaders_max_wgs=0"))
+                ("1", "1", "0", "0", "2,loaders_max_wgs=0"), ("1", "1", "0", "1", "2,loaders_max_wgs=0"), ("1", "1", "0", "2", "2,loaders_max_wgs=0"),
+                # (regw_half=2: the cell tiles over TWO work-groups, cfg 125, also where the three-way split would be taken)
+                ("1", "1", "1", "0", "3,regw_half=2"), ("1", "1", "1", "1", "3,regw_half=2"), ("1", "1", "1", "2", "3,regw_half=2"))
     runs = run_parallel([([sys.executable, "-c", CW12_CODE, emu_full_lib],
                           dict(os.environ, KMX_CONV_TUNE="loaders=%s,loaders_depth=%s,loaders_split=%s,regw=%s" % (ld, depth, split, regw), KMX_EMU_LATE_DMA=late))
                          for ld, depth, split, late, regw in variants])
@@ -191,7 +193,7 @@ print("RESULT " + json.dumps(out))
 def test_register_weights_shapes_whole_net(emu_full_lib, tmp_path):
     """A nested-bottleneck net with 64-channel inner 3x3 layers (residuals, per-board biases, raw and activated channel ranges, a board
     smaller than the buffer) through the slab-ring shapes and through the shapes with their weights in registers - cfg 128, its cell tiles
-    over three work-groups (127), and the 64-channel shape (126: two channel tiles per wave, half a chunk of fragments in the ring) -
+    over three work-groups (127) or two (125), and the 64-channel shape (126: two channel tiles per wave, half a chunk of fragments in the ring) -
     with immediate and with the latest legal completion: the same bits in every output. The 2x3 buffer is the case the MI355X found in
     the first version of cfg 126 (fuzz case 34): cell tiles off the board were skipped, and the residual requests, which run one tile ahead
     in a fixed order, then delivered the wrong tile's residual to the second channel tile."""
@@ -199,7 +201,8 @@ def test_register_weights_shapes_whole_net(emu_full_lib, tmp_path):
     modelgen.ARCHS["b2c128nbt"] = dict(C=128, mid=64, gpool=16, blocks=["n", "ng"], p1=16, g1=16, v1=24, v2=32)
     model = str(tmp_path / "b2c128nbt.bin")
     modelgen.write_model(model, "b2c128nbt", seed=4)
-    variants = (("regw=0", "0"), ("regw=3", "2"), ("regw=1,loaders_split=0", "1"), ("regw=2,loaders_max_wgs=0", "1"), ("regw=2,loaders_max_wgs=0", "2"))
+    variants = (("regw=0", "0"), ("regw=3", "2"), ("regw=1,loaders_split=0", "1"), ("regw=2,loaders_max_wgs=0", "1"), ("regw=2,loaders_max_wgs=0", "2"),
+                ("regw=3,regw_half=2", "1"), ("regw=3,regw_half=2", "2"))
     runs = run_parallel([([sys.executable, "-c", NET_REGW_CODE, emu_full_lib, model], dict(os.environ, KMX_CONV_TUNE=tune, KMX_EMU_LATE_DMA=late))
                          for tune, late in variants])
     res = []

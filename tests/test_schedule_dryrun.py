@@ -121,7 +121,8 @@ def test_transformer_schedule_is_consistent(name, C, H, KVH, QD, VD, F, blocks, 
             wn = 2 if kname.endswith("ELb1ELi2ELb0EEEvNS_8ConvArgsE") else 1  # cfg 126: two channel tiles per wave
             # (grid z = 3: the cell tiles of a board over three work-groups while batch x channel tiles x 3 <= 256, cfg 127 / 117)
             assert grid[:2] == (cout_pad // (32 * wn), n) and block == 512 and lds <= 160 * 1024
-            assert grid[2] == (3 if n * (cout_pad // 32) * 3 <= 256 else 1), (grid, n, cout_pad)
+            # (z = 2: over two work-groups, cfg 125, while batch x channel tiles x 2 <= 256)
+            assert grid[2] == (3 if n * (cout_pad // 32) * 3 <= 256 else 2 if n * (cout_pad // 32) * 2 <= 256 else 1), (grid, n, cout_pad)
             assert wn == (2 if n * (cout_pad // 32) > 256 else 1), (kname, n, cout_pad)
         elif k == "conv":
             # kernel size, WN, WNW, ring depth, flags (0, or 262144 = ABL_SPLIT: a board's cell tiles over three work-groups, cfg 113)
