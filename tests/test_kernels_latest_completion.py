@@ -63,7 +63,7 @@ def test_latest_completion_catches_a_wrong_count(tmp_path):
     ok = lambda v: v[0] <= 2.0 ** -7 * max(1.0, v[1]) * 1.5  # noqa: E731
     print("fetching-waves shape, one request too generous: latest completion", {k: v[:2] for k, v in c1.items()})
     # (the fetching waves run ahead of the multiplying ones between two barriers, so under emulation a late copy may still land before a
-    # small case reads it: the defect must show in at least one case - the two-board 19x19 one in practice - and never with immediate copies)
+    # small case reads it: the defect must show in at least one case - the 19x19 one in practice - and never with immediate copies)
     assert all(ok(v) for v in c0.values()) and not all(ok(v) for v in c1.values()), (c0, c1)
     # ... and with its weights in registers: the fragment wait (mode 1: a stale fragment is multiplied) and, with cell tiles split, the image wait
     runs = run_parallel([([sys.executable, "-c", CW12_CODE, lib], dict(os.environ, KMX_CONV_TUNE="loaders=1,loaders_split=%s,regw=%s" % (sp_, rw_), KMX_EMU_LATE_DMA=late_))
@@ -95,7 +95,7 @@ capi._lib = capi.load_library(path=sys.argv[1])
 from katago_amd import nninterface as nn
 rng = np.random.default_rng(7)
 out = {}
-for (cin, cout, X, Y, n) in ((64, 32, 9, 9, 1), (96, 192, 19, 19, 2), (40, 200, 19, 19, 1), (64, 64, 13, 9, 1), (32, 96, 7, 11, 3), (160, 32, 9, 9, 1)):
+for (cin, cout, X, Y, n) in ((64, 32, 9, 9, 1), (96, 192, 13, 13, 2), (40, 200, 19, 19, 1), (64, 64, 13, 9, 1), (32, 96, 7, 11, 3), (160, 32, 9, 9, 1)):
     w = (rng.normal(size=(cout, cin, 3, 3)) * 0.1).astype(np.float32)
     x = rng.normal(size=(n, Y * X, cin)).astype(np.float32)
     got = np.asarray(nn.testEvaluateConv(w, n, X, Y, True, x))

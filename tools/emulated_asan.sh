@@ -44,9 +44,9 @@ h.close()
 print("clean:", os.environ.get("KMX_CONV_TUNE"))
 PY
 export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1
-# the default small-batch shapes (cfg 113 / 117: a board's cell tiles over three work-groups; 114), the unsplit ones (114 / 118), the
-# two-per-CU shape (119), the 4-wave shapes of conv_kernel.h, the 8-wave shapes
-for v in "A=1" "KMX_CONV_TUNE=regw=0" "KMX_CONV_TUNE=loaders_split=0,split1x1=0" "KMX_CONV_TUNE=loaders_max_wgs=0" "KMX_CONV_TUNE=loaders_max_wgs=0,regw=0" "KMX_CONV_TUNE=loaders=0,deep1x1=0" "KMX_CONV_TUNE=min_wgs8=1"; do
+# the default small-batch shapes (round 5: the register-weights 3x3 shapes, cfg 127 - a board's cell tiles over three work-groups -, 125 - over
+# two -, 128, 126; cfg 113 / 114 for 1x1), round 4's slab-ring shapes (regw=0: 117 / 118 / 119), the 4-wave shapes of conv_kernel.h, the 8-wave shapes
+for v in "A=1" "KMX_CONV_TUNE=regw_half=2" "KMX_CONV_TUNE=regw=0" "KMX_CONV_TUNE=loaders_split=0,split1x1=0" "KMX_CONV_TUNE=loaders_max_wgs=0" "KMX_CONV_TUNE=loaders_max_wgs=0,regw=0" "KMX_CONV_TUNE=loaders=0,deep1x1=0" "KMX_CONV_TUNE=min_wgs8=1"; do
   env LD_PRELOAD="$ASAN" $v python3 run.py
 done
 echo "emulated ASAN run: clean"
