@@ -46,3 +46,12 @@ def test_no_oracle_in_product():
             if f.endswith((".py", ".cpp", ".h", ".hip")):
                 src = open(os.path.join(root, f), errors="replace").read()
                 assert "okmx_" not in src and "kmx_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_tuning_hooks_refuse_bad_arguments_without_gpu():
+    """kmx_bench_launch_floor (round 5) checks its arguments before it looks for a device."""
+    lib = capi.load_library()
+    us = ctypes.c_double()
+    for args in ((0, 8192, 0, 10, 1), (18, 4096, 0, 10, 1), (18, 8192, 3, 10, 1), (18, 8192, 0, 0, 1), (18, 200 * 1024, 0, 10, 1)):
+        assert lib.kmx_bench_launch_floor(*args, ctypes.byref(us)) == capi.KMX_ERR_INVALID_ARG, args
+    assert lib.kmx_bench_launch_floor(18, 8192, 0, 10, 1, None) == capi.KMX_ERR_INVALID_ARG
