@@ -37,3 +37,21 @@ def test_baseline_shapes_unchanged():
         assert (cfg.value, ok.value) == (want, 1), (ks, cout_pad, cfg.value)
     for bad in ((2, 64, 1), (3, 100, 1), (3, 64, 0)):
         assert lib.kmx_debug_conv_cfg(bad[0], bad[1], bad[2], ctypes.byref(cfg), ctypes.byref(ok)) == capi.KMX_ERR_INVALID_ARG
+
+
+def test_small_batch_3x3_ranges_of_b18():
+    """192-channel 3x3 layers (b18c384nbt's trunk) by batch: the cell tiles over three work-groups (cfg 127) while batch x 6 x 3 <= 256, over
+    two (125) while batch x 6 x 2 <= 256, one work-group per board x 32 channels (128) while batch x 6 <= 256, a board x 64 channels (126)
+    while batch x 3 <= 256, then the 4-wave shapes of conv_kernel.h and from 150 work-groups the 8-wave x 192 one. The net's 64-channel
+    layers keep the split shapes longer."""
+    lib = capi.load_library()
+    cfg, ok = ctypes.c_int(), ctypes.c_int()
+
+    def choice(cout_pad, batch):
+        capi.check(lib.kmx_debug_conv_cfg(3, cout_pad, batch, ctypes.byref(cfg), ctypes.byref(ok)), lib)
+        assert ok.value == 1
+        return cfg.value
+
+    want = {1: 127, 14: 127, 15: 125, 21: 125, 22: 128, 42: 128, 43: 126, 85: 126, 86: 12, 149: 13, 150: 23, 256: 23}
+    assert {b: choice(192, b) for b in want} == want
+    assert [choice(64, b) for b in (1, 42, 43, 64, 65, 128, 129, 256)] == [127, 127, 125, 125, 128, 128, 126, 126]
