@@ -68,21 +68,24 @@ carriers)
   done
   ;;
 regw)
-  # the fetching-waves 3x3 shapes with their weights in registers (conv_small_kernel.h REGW, cfg 128 / 126 / 127; the default since this call)
-  # against the slab-ring shapes (KMX_CONV_TUNE regw=0: cfg 118 / 119 / 117) and against their own first form (regw_early=0): parity on
-  # hardware, pass time at batch 1 .. 85 from host rows with the digest of fixed rows, launch classes, self-play rows/s
-  timeout 600 python -m pytest tests/test_gpu_layers.py tests/test_gpu_fuzz.py "tests/test_gpu_model.py::test_full_batch_properties" -m gpu -q -p no:cacheprovider 2>&1 | tail -40 | cut -c1-600 | tee $OUT/parity.log
-  for t in regw=0 regw_early=0 regw_early=1 regw=0 regw_early=0 regw_early=1; do
+  # the fetching-waves 3x3 shapes with their weights in registers (conv_small_kernel.h REGW, cfg 128 / 126 / 127 / 125; the default) against
+  # round 4's slab-ring shapes (KMX_CONV_TUNE regw=0: cfg 118 / 119 / 117): parity on hardware, pass time at batch 1 .. 85 from host rows with
+  # the digest of fixed rows, launch classes, self-play rows/s. (The round's calls 1-3 ran earlier forms of this section: regw=0 / 2 / 3 with the
+  # shapes still off by default, then regw_early=0 / 1 - keys that are gone with the forms they selected; profiles/r05_steps/regw/README.md.)
+  timeout 600 python -m pytest tests/test_gpu_layers.py tests/test_gpu_fuzz.py tests/test_gpu_small_shapes.py "tests/test_gpu_model.py::test_full_batch_properties" -m gpu -q -p no:cacheprovider 2>&1 | tail -40 | cut -c1-600 | tee $OUT/parity.log
+  for t in regw=0 regw=3 regw=0 regw=3; do
     KMX_CONV_TUNE=$t timeout 200 python tools/small_batch_scan.py 2>&1 | grep SCAN | tee -a $OUT/small_batch_scan.txt
   done
-  for t in regw_early=0 regw_early=1; do for n in 8 32 64; do
+  for t in regw=0 regw=3; do for n in 8 32 64; do
     echo "== $t batch $n: per-class launch times (hipEvent pair per launch, one stream)" | tee -a $OUT/kernel_classes.txt
     KMX_CONV_TUNE=$t timeout 200 python3 bench.py --no-cpu-baseline --no-callers --batch $n --steps 30 --warmup 5 2>>$OUT/err.txt | grep -o '"kernel_avg_launch_us": {[^}]*}\|"value": [0-9.]*\|"ms_per_step": [0-9.]*' | tr '\n' ' ' | tee -a $OUT/kernel_classes.txt; echo | tee -a $OUT/kernel_classes.txt
   done; done
-  for t in regw=0 regw_early=1; do
+  for t in regw=0 regw=3; do
     KMX_CONV_TUNE=$t tools/selfplay_full_games.sh regw_${t#*=} 8 8 8 8 60 > /dev/null 2>&1
     echo "$t: $(cat gpurun_out/selfplay_full_regw_${t#*=}.txt)" | tee -a $OUT/selfplay_rows.txt
   done
+  timeout 60 python tools/launch_floor.py | tee $OUT/launch_floor.txt
+  timeout 100 python tools/small_conv_timing.py 2>&1 | tee $OUT/small_conv_timing.txt
   ;;
 half)
   # cfg 125: the register-weights shape with its cell tiles over TWO work-groups (KMX_CONV_TUNE regw_half=1: batch 15-21 at 192 channels;
