@@ -94,14 +94,16 @@ static_assert(SG<false, 1>::LDS_BYTES <= 160 * 1024 && 2 * SG<true, 0>::LDS_BYTE
 static_assert(SG<true, 0>::virtualImg() == 1 && SG<false, 1>::virtualImg() == 4, "prologue bookkeeping below");
 
 // ---- REGW (round 5): the weights never pass through LDS ------------------------------------------------------------------------------
-// What bounds a step of the shape above is the LDS port: per k half the four multiplying waves read 4 x (1 KB of weight fragment + MTW KB
-// of image fragments) - 16 KB = 128 cycles at 128 B/cycle for 96 cycles of matrix work (MTW = 3), 8 KB = 64 cycles for 32 (MTW = 1) - and
-// the SAME weight fragment four times over. Here every multiplying wave loads its weight fragments straight from global memory into
-// registers (global_load_dwordx4, the lane's 16 bytes of the pre-swizzled slab row; the four waves' requests hit in the vector L1), a whole
-// chunk ahead: a ring of 18 fragments = 72 registers, reloaded one k half after its use. What is left in LDS is the board image: three
-// buffers (chunk c read, c + 1 published, c + 2 in flight), fetched by waves 4-7 as before. No slab ring, so nothing is published per
-// step: ONE barrier per chunk instead of nine, the multiplying waves run a chunk's 18 k halves back to back with their image fragments read
-// NSET - 1 k halves ahead. Same MFMAs per output in the same K order (chunk, tap, k half), same epilogue: bit-identical to the other shapes.
+// In the shape above the four multiplying waves read, per k half, 4 x (1 KB of weight fragment + MTW KB of image fragments) from LDS -
+// 16 KB = 128 cycles of the LDS port for 96 cycles of matrix work (MTW = 3), 8 KB = 64 cycles for 32 (MTW = 1) - the SAME weight fragment
+// four times over, and nine barriers per chunk publish nothing but the next slab. Here every multiplying wave loads its weight fragments
+// straight from global memory into registers (global_load_dwordx4 from ConvArgs::wFrag, the copy of the weights in MFMA-fragment order:
+// a wave's load is 1 KB of consecutive bytes; the four waves' requests hit in the vector L1), a whole chunk ahead: a ring of 18 fragments
+// = 72 registers, reloaded one k half after its use. What is left in LDS is the board image: three buffers (chunk c read, c + 1 published,
+// c + 2 in flight), fetched by waves 4-7 as before. No slab ring, so nothing is published per step: ONE barrier per chunk instead of
+// nine, the multiplying waves run a chunk's 18 k halves back to back with their image fragments read NSET - 1 k halves ahead. Same MFMAs
+// per output in the same K order (chunk, tap, k half), same epilogue: bit-identical to the other shapes. What it bought and what the
+// cycle stamps then showed a small launch's time to be made of: DESIGN.md 4.14, profiles/r05_steps/regw.
 struct RWG {
   static constexpr int D = 0, NSW = 0;
   static constexpr int NSA = 3, DIST = 2;
