@@ -26,7 +26,7 @@ Rank 0 prints ONE JSON line, including
                  bytes per launch / average launch duration of the same instrumented pass, against 8 TB/s;
   callers      : (N = 1, outside the timed region, ~15 s; --no-callers skips) what the callers of the path get on this box:
                  host rows through the persistent leaf batcher (katago_amd/leaf_pump, this repo's C++ consumer of the C ABI)
-                 and, when oracle/_ref/katago_hip was built, the reference's own `benchmark` (nnEvals/s as
+                 and, when integration/_build/katago_hip was built, the reference's own `benchmark` (nnEvals/s as
                  cpp/program/playutils.cpp:843,991-1000 defines it) from its unmodified search on 1024 fibers;
   small_batches: (N = 1, outside the timed region, < 1 s) ms per pass and rows/s of the same net at batch 1 / 8 / 32 from host rows
                  through kmx_eval - the latency-bound regime of a few games per GPU (BASELINE configs[2]; DESIGN.md 4.12);
@@ -202,7 +202,7 @@ def caller_rates(model_path, tmp):
         r = subprocess.run([pump, model_path, "19", "256", "2", "8", "128", "3"], capture_output=True, text=True, timeout=120)
         if r.returncode == 0:
             out["host_rows_through_batcher_per_s"] = round(json.loads(r.stdout.strip().splitlines()[-1])["rows_per_s"], 1)
-    hipx = os.path.join(REPO, "oracle", "_ref", "katago_hip")
+    hipx = os.path.join(REPO, "integration", "_build", "katago_hip")
     if os.path.exists(hipx):
         cfg = os.path.join(tmp, "kmx_bench_callers.cfg")
         with open(cfg, "w") as f:

@@ -24,6 +24,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -78,6 +79,9 @@ class Batcher {
       }
       else sealAt_ = maxBatch;
       if(const char* e = getenv("KMX_BATCH_LINGER_US")) lingerUs_ = atoi(e) < 0 ? 0 : atoi(e);
+      // fault triage: one line per launched batch on stderr (slot, rows, what else is on the device) - the last lines before a device
+      // fault name the batch sizes that were in flight (bench.py keeps them when the self-play leg dies)
+      if(const char* e = getenv("KMX_BATCH_TRACE")) trace_ = atoi(e) != 0;
     }
     maxBatch = sealAt_;  // no batch ever holds more rows: engines and staging are sized for what can be used
     maxBatch_ = sealAt_;
@@ -309,6 +313,7 @@ class Batcher {
       rowsOnDevice_ += s.count;
       const int n = s.count;
       const bool anyOwner = s.anyOwner;
+      if(trace_) fprintf(stderr, "[kmx batch] slot %d rows %d beside %d rows in %d batches\n", si, n, rowsOnDevice_ - n, running_ - 1);
       l.unlock();
       while(s.copied.load(std::memory_order_acquire) < n) std::this_thread::yield();  // a row copy takes a few microseconds
       int err = KMX_OK;
@@ -412,6 +417,7 @@ class Batcher {
   int lingerUs_ = 150;
   static constexpr int SMALL_ROWS = 96;     // partial batches may run side by side while the device holds at most this many rows
   bool closing_ = false;
+  bool trace_ = false;
   uint64_t nextTicket_ = 1;
   // node-based map: references to its elements stay valid while other tickets come and go (a waiter sleeps holding one)
   std::map<uint64_t, Pending> pending_;

@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 namespace kmx {
 
@@ -14,23 +16,100 @@ void hipCheck(hipError_t e, const char* what) {
   if(e != hipSuccess) throw Error(KMX_ERR_DEVICE, std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
 }
 
+// KMX_DEBUG_GUARD=1 (fault triage): every DevBuf is placed with the HIP virtual-memory API so that the first byte BEHIND
+// its readable tail is unmapped - the allocation ends (up to 255 bytes of alignment slack: device pointers stay 256-byte aligned as
+// hipMalloc's are) where its physical backing ends, and one more granule of address space behind it is reserved and never mapped. A
+// kernel that reads or writes past DEVBUF_TAIL then takes a memory-access fault in the parity test that first runs it, instead of
+// reading a neighbouring allocation unnoticed (hipMalloc hands out pieces of large mapped pools: an overrun of kilobytes is silent
+// there). KMX_DEBUG_GUARD=2 guards the FRONT instead (the allocation starts where its backing starts, the granule before it is unmapped).
+namespace {
+int guardMode() {
+  static const int m = [] { const char* e = getenv("KMX_DEBUG_GUARD"); return e ? atoi(e) : 0; }();
+  return m;
+}
+#ifndef KMX_EMULATED_HIP
+struct GuardedAlloc {
+  void* base = nullptr;       // start of the reserved address range
+  size_t reserved = 0;        // its size
+  void* mapped = nullptr;     // start of the mapped part
+  size_t mappedBytes = 0;
+  hipMemGenericAllocationHandle_t handle{};
+};
+std::mutex guardMu;
+std::map<void*, GuardedAlloc>& guardTable() { static std::map<void*, GuardedAlloc> t; return t; }
+
+void* guardedMalloc(size_t bytes) {
+  int dev = 0;
+  hipCheck(hipGetDevice(&dev), "hipGetDevice");
+  hipMemAllocationProp prop;
+  memset(&prop, 0, sizeof(prop));
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = dev;
+  size_t gran = 0;
+  hipCheck(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum), "hipMemGetAllocationGranularity");
+  if(gran == 0) gran = 2u << 20;
+  GuardedAlloc g;
+  g.mappedBytes = (bytes + gran - 1) / gran * gran;
+  g.reserved = g.mappedBytes + 2 * gran;  // an unmapped granule on either side
+  hipCheck(hipMemAddressReserve(&g.base, g.reserved, gran, nullptr, 0), "hipMemAddressReserve");
+  g.mapped = (char*)g.base + gran;
+  hipCheck(hipMemCreate(&g.handle, g.mappedBytes, &prop, 0), "hipMemCreate");
+  hipCheck(hipMemMap(g.mapped, g.mappedBytes, 0, g.handle, 0), "hipMemMap");
+  hipMemAccessDesc acc;
+  memset(&acc, 0, sizeof(acc));
+  acc.location.type = hipMemLocationTypeDevice;
+  acc.location.id = dev;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  hipCheck(hipMemSetAccess(g.mapped, g.mappedBytes, &acc, 1), "hipMemSetAccess");
+  // end guard: the buffer's last byte is within 255 bytes of the last mapped byte; front guard: the buffer starts the mapping
+  void* p = guardMode() == 2 ? g.mapped : (void*)((char*)g.mapped + (g.mappedBytes - bytes) / 256 * 256);
+  std::lock_guard<std::mutex> l(guardMu);
+  guardTable()[p] = g;
+  return p;
+}
+bool guardedFree(void* p) {
+  GuardedAlloc g;
+  {
+    std::lock_guard<std::mutex> l(guardMu);
+    auto it = guardTable().find(p);
+    if(it == guardTable().end()) return false;
+    g = it->second;
+    guardTable().erase(it);
+  }
+  (void)hipDeviceSynchronize();  // hipFree synchronises; unmapping does not
+  (void)hipMemUnmap(g.mapped, g.mappedBytes);
+  (void)hipMemRelease(g.handle);
+  (void)hipMemAddressFree(g.base, g.reserved);
+  return true;
+}
+#else
+void* guardedMalloc(size_t) { throw Error(KMX_ERR_UNSUPPORTED, "KMX_DEBUG_GUARD needs the device's virtual-memory API"); }
+bool guardedFree(void*) { return false; }
+#endif
+void devFree(void* p) {
+  if(p == nullptr) return;
+  if(guardMode() != 0 && guardedFree(p)) return;
+  (void)hipFree(p);
+}
+}  // namespace
+
 DevBuf::DevBuf(size_t bytes, bool zero) : p_(nullptr), bytes_(bytes) {
   if(bytes == 0) return;
   // DEVBUF_TAIL readable bytes follow every allocation: the convolution's DMA pointers run up to D chunks (64 bytes
   // each) past the last channel chunk of the last cell; those requests land in a scratch area and are never used.
-  hipCheck(hipMalloc(&p_, bytes + DEVBUF_TAIL), "hipMalloc");
+  if(guardMode() != 0) p_ = guardedMalloc(bytes + DEVBUF_TAIL);
+  else hipCheck(hipMalloc(&p_, bytes + DEVBUF_TAIL), "hipMalloc");
   // The zero fill runs on the null stream; the engine's work runs on hipStreamNonBlocking streams, which do not
   // synchronise with it: Engine::construct ends with hipDeviceSynchronize() so that no launch can overtake a fill.
   if(zero) hipCheck(hipMemsetAsync(p_, 0, bytes + DEVBUF_TAIL, nullptr), "hipMemset");
   static const bool debugAlloc = getenv("KMX_DEBUG_ALLOC") != nullptr;  // fault triage: which buffer does an address belong to
   if(debugAlloc) fprintf(stderr, "[kmx alloc] %p .. %p (%zu + %zu bytes)\n", p_, (char*)p_ + bytes + DEVBUF_TAIL, bytes, DEVBUF_TAIL);
 }
-DevBuf::~DevBuf() {
-  if(p_) (void)hipFree(p_);
-}
+DevBuf::~DevBuf() { devFree(p_); }
 DevBuf& DevBuf::operator=(DevBuf&& o) noexcept {
   if(this != &o) {
-    if(p_) (void)hipFree(p_);
+    devFree(p_);
     p_ = o.p_;
     bytes_ = o.bytes_;
     o.p_ = nullptr;
@@ -952,8 +1031,16 @@ void Engine::runSchedule(int n, const float* dSpatial, const unsigned char* dPac
       graphLaunches_++;
       return;
     }
+    // KMX_DEBUG_SYNC=1 (fault triage, with KMX_GRAPHS=0): every op is named on stderr before its launch and waited for after it - the
+    // last line before a device fault names the op that faulted (round 6)
+    static const bool debugSync = getenv("KMX_DEBUG_SYNC") != nullptr;
     for(size_t i = 0; i < ops_.size(); i++) {
+      if(debugSync) {
+        fprintf(stderr, "[kmx op] %zu %s rows %d\n", i, opClasses_[ops_[i].cls].c_str(), n);
+        fflush(stderr);
+      }
       ops_[i].fn(n, stream_);
+      if(debugSync) hipCheck(hipStreamSynchronize(stream_), "hipStreamSynchronize (KMX_DEBUG_SYNC)");
       if((int)i + 1 == forkAt) hipCheck(hipEventRecord(forkEv_, stream_), "hipEventRecord");
     }
     return;

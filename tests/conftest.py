@@ -10,7 +10,8 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 REF = os.environ.get("KATAGO_REFERENCE", "/root/reference")
-REF_BIN_DIR = os.path.join(REPO, "oracle", "_ref")
+REF_BIN_DIR = os.path.join(REPO, "oracle", "_ref")  # test binaries bound to the CPU oracle, the reference's OpenCL backend, test nets
+PRODUCT_BIN_DIR = os.path.join(REPO, "integration", "_build")  # the product binding: katago_hip, katago_hip_refeval (integration/Makefile)
 
 
 def pytest_configure(config):
@@ -53,13 +54,15 @@ def small_model(model_dir):
 
 
 def ref_binary(name):
-    """oracle/_ref/<name>: prebuilt (GPU box) or built here from the mounted reference."""
-    path = os.path.join(REF_BIN_DIR, name)
+    """integration/_build/<name> (the product binding, katago_hip*) or oracle/_ref/<name> (everything bound to the oracle): prebuilt
+    (GPU box) or built here from the mounted reference."""
+    product = name.startswith("katago_hip")
+    path = os.path.join(PRODUCT_BIN_DIR if product else REF_BIN_DIR, name)
     if not os.path.exists(path):
         if not os.path.isdir(os.path.join(REF, "cpp")):
             pytest.skip("%s not built and the reference tree is not mounted" % name)
-        subprocess.run(["make", "-s", "-C", os.path.join(REPO, "oracle"), "-j%d" % (os.cpu_count() or 4), "ref", "REF=" + REF],
-                       check=True, stdout=subprocess.DEVNULL)
+        subprocess.run(["make", "-s", "-C", os.path.join(REPO, "integration" if product else "oracle"), "-j%d" % (os.cpu_count() or 4),
+                        "all" if product else "ref", "REF=" + REF], check=True, stdout=subprocess.DEVNULL)
     return path
 
 

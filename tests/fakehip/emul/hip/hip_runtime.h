@@ -3,6 +3,7 @@
 // a work-group is a set of OS threads, __syncthreads a barrier (emu::Barrier), __shfl_xor an exchange through a per-wave array,
 // dynamic LDS a static buffer, work-groups run one after the other. Only what those kernels use is provided.
 #pragma once
+#define KMX_EMULATED_HIP 1  // engine.cpp: no virtual-memory API here (its KMX_DEBUG_GUARD placement is a device-only triage mode)
 #include <condition_variable>
 #include <mutex>
 #include <cmath>

@@ -60,7 +60,7 @@ def test_driver_command_exits_zero_with_roofline_and_cpu_baseline():
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     # the callers' side of the same box, outside the timed region
     assert d["host_rows_through_batcher_per_s"] > 0.5 * d["value"]
-    if os.path.exists(os.path.join(REPO, "oracle", "_ref", "katago_hip")):
+    if os.path.exists(os.path.join(REPO, "integration", "_build", "katago_hip")):
         assert d["reference_benchmark_nn_evals_per_s"] > 0.5 * d["value"], d
         # ... and at BASELINE configs[1]'s own setting (-v 1600 -t 256 -fixed-batch-size 256): short searches, 256 descents - lower, reported beside it
         assert d["reference_benchmark_configs1_nn_evals_per_s"] > 0.3 * d["value"] and "-v 1600 -t 256 -fixed-batch-size 256" in d["reference_benchmark_configs1"], d

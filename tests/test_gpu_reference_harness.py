@@ -1,4 +1,4 @@
-"""-m gpu: the reference's OWN test commands running on the HIP backend (oracle/_ref/katago_hip = unmodified reference host
+"""-m gpu: the reference's OWN test commands running on the HIP backend (integration/_build/katago_hip = unmodified reference host
 code with this repo's NNEvaluator + featuriser in place of neuralnet/nneval.cpp, + integration/katamxbackend.cpp + libkatamx.so:
 the default binding build since round 4; katago_hip_refeval keeps the reference's own evaluator)."""
 import os

@@ -1,5 +1,5 @@
 """-m gpu: the reference's `selfplay` command — the one its games/hour metric is defined on (command/selfplay.cpp:388-389)
-— on the HIP backend (oracle/_ref/katago_hip), writing .npz shards through integration/zipfile_zlib.cpp. The CPU twin of
+— on the HIP backend (integration/_build/katago_hip), writing .npz shards through integration/zipfile_zlib.cpp. The CPU twin of
 this test (tests/test_npz_writer.py) runs the same command on the oracle; here the rows are evaluated on the MI355X on a
 9x9 buffer with 7x7 boards masked inside it, in greedy batches of up to 8 rows from 8 game threads."""
 import glob

@@ -192,9 +192,9 @@ def test_eight_devices_selfplay_in_one_process(fake_so, tmp_path, policy):
     import shard_checks
     from katago_amd import modelgen
 
-    binary = os.path.join(REPO, "oracle", "_ref", "katago_hip")
+    binary = os.path.join(REPO, "integration", "_build", "katago_hip")
     if not os.path.exists(binary):
-        pytest.skip("oracle/_ref/katago_hip not built (make -C oracle ref needs the reference checkout)")
+        pytest.skip("integration/_build/katago_hip not built (make -C integration needs the reference checkout)")
     d = str(tmp_path)
     os.makedirs(os.path.join(d, "models"))
     modelgen.write_model(os.path.join(d, "models", "b2c32nbt-s1-d1.bin.gz"), "b2c32nbt", seed=3)

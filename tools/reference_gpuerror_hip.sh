@@ -27,7 +27,7 @@ cd $OUT
 for SIZE in 9 19; do
   timeout 900 $REPO/oracle/_ref/katago_oracle testgpuerror -model $G170 -config bench.cfg -boardsize $SIZE -quick -reference-file $OUT/ref_$SIZE.txt > /dev/null 2>&1
   for PREC in bf16 fp16; do
-    timeout 600 $REPO/oracle/_ref/katago_hip testgpuerror -model $G170 -config bench.cfg -boardsize $SIZE -quick -reference-file $OUT/ref_$SIZE.txt -override-config katamxPrecision=$PREC > $OUT/hip_${PREC}_$SIZE.log 2>&1
+    timeout 600 $REPO/integration/_build/katago_hip testgpuerror -model $G170 -config bench.cfg -boardsize $SIZE -quick -reference-file $OUT/ref_$SIZE.txt -override-config katamxPrecision=$PREC > $OUT/hip_${PREC}_$SIZE.log 2>&1
     echo "== $PREC ${SIZE}x$SIZE rc=$?"
     grep -E "batched current error vs reference (winrateError|leadError|scoreMeanError|topPolicyDelta|policyKLDiv|ownershipError|closest)" $OUT/hip_${PREC}_$SIZE.log
   done

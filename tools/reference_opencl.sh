@@ -48,9 +48,9 @@ sys.path.insert(0, "$REPO")
 from katago_amd import modelgen
 modelgen.write_model("$OUT/b18rand.bin.gz", "b18c384nbt", seed=7)
 PY
-for BIN in katago_opencl katago_hip; do
-  timeout 1500 $REPO/oracle/_ref/$BIN benchmark -model $OUT/b18rand.bin.gz -config bench.cfg -v 1600 -t 64,256 -boardsize 19 -n 3 > $OUT/benchmark_b18_$BIN.log 2>&1
+for BIN in oracle/_ref/katago_opencl integration/_build/katago_hip; do
+  timeout 1500 $REPO/$BIN benchmark -model $OUT/b18rand.bin.gz -config bench.cfg -v 1600 -t 64,256 -boardsize 19 -n 3 > $OUT/benchmark_b18_$(basename $BIN).log 2>&1
   echo "$BIN benchmark rc=$?"
-  tr '\r' '\n' < $OUT/benchmark_b18_$BIN.log | grep "nnEvals/s" | tail -2
+  tr '\r' '\n' < $OUT/benchmark_b18_$(basename $BIN).log | grep "nnEvals/s" | tail -2
 done
 rm -f $OUT/b18rand.bin.gz

@@ -26,4 +26,4 @@ python3 "$REPO/tools/selfplay_cfg.py" "$CFG" numGameThreads=$((GAMES_PER_GPU * N
   nnMaxBatchSize=256 "${KV[@]}" "$@" > /dev/null
 export KATAMX_LEAVES_PER_THREAD=${KATAMX_LEAVES_PER_THREAD:-$LEAVES}
 echo "config: $CFG ($NGPU devices, $((GAMES_PER_GPU * NGPU)) games, $LEAVES leaves per game, $KATAMX_LEAVES_PER_THREAD per OS thread)" >&2
-exec ${KMX_LAUNCH_PREFIX:-} "$REPO/oracle/_ref/katago_hip" selfplay -config "$CFG" -models-dir "$MODELS" -output-dir "$OUTDIR" ${KMX_SELFPLAY_ARGS:-}
+exec ${KMX_LAUNCH_PREFIX:-} "$REPO/integration/_build/katago_hip" selfplay -config "$CFG" -models-dir "$MODELS" -output-dir "$OUTDIR" ${KMX_SELFPLAY_ARGS:-}

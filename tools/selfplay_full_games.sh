@@ -1,7 +1,7 @@
 #!/bin/bash
 # games/hour as the reference defines it (command/selfplay.cpp:388-389: "Total games" x 3600 / "Total selfplay runtime (seconds)"), with
 # FULL-LENGTH games played to the reference's end conditions at its production settings (tools/selfplay_cfg.py = selfplay8mainb18.cfg),
-# b18c384nbt (random weights) on 19x19, through the product path (oracle/_ref/katago_hip: own evaluator + featuriser + fibers).
+# b18c384nbt (random weights) on 19x19, through the product path (integration/_build/katago_hip: own evaluator + featuriser + fibers).
 #   tools/selfplay_full_games.sh <tag> <game threads> <search threads per game> <leaves per OS thread> <max games total> <timeout s> [key=value ...]
 # Writes gpurun_out/selfplay_full_<tag>.{log,txt}. A run that hits the timeout is interrupted with SIGINT (the reference then stops its games,
 # writes its totals and exits cleanly): the .txt says so and reports rows/s only.
@@ -24,7 +24,7 @@ args.update(kv)
 selfplay_cfg.write(d + "/main.cfg", **args)
 PY
 REPO=$PWD
-( cd $D && KATAMX_LEAVES_PER_THREAD=$LEAVES timeout -s INT $TMO $REPO/oracle/_ref/katago_hip selfplay -config main.cfg -models-dir models -output-dir out -max-games-total $MAXGAMES > $REPO/$OUT/selfplay_full_$TAG.log 2>&1 )
+( cd $D && KATAMX_LEAVES_PER_THREAD=$LEAVES timeout -s INT $TMO $REPO/integration/_build/katago_hip selfplay -config main.cfg -models-dir models -output-dir out -max-games-total $MAXGAMES > $REPO/$OUT/selfplay_full_$TAG.log 2>&1 )
 python3 - "$OUT/selfplay_full_$TAG.log" "$TAG" "$GAMES" "$SEARCH" "$LEAVES" "$MAXGAMES" <<'PY' | tee $OUT/selfplay_full_$TAG.txt
 import re, sys
 t = open(sys.argv[1]).read()
