@@ -154,7 +154,25 @@ __device__ __forceinline__ void waitLdsFrag(V8& frag) {
   (void)frag;
 #endif
 }
-// ... for a count that is a constant only after the k-half loop is unrolled
+// ... for a count that is a constant only after the k-half loop is unrolled (the last chunk's reads count down, see the kernel)
+template <class V8>
+__device__ __forceinline__ void waitLdsFragSel(V8& frag, int n) {
+  switch(n) {
+    case 0: waitLdsFrag<0>(frag); break;
+    case 1: waitLdsFrag<1>(frag); break;
+    case 2: waitLdsFrag<2>(frag); break;
+    case 3: waitLdsFrag<3>(frag); break;
+    case 4: waitLdsFrag<4>(frag); break;
+    case 5: waitLdsFrag<5>(frag); break;
+    case 6: waitLdsFrag<6>(frag); break;
+    case 7: waitLdsFrag<7>(frag); break;
+    case 8: waitLdsFrag<8>(frag); break;
+    case 9: waitLdsFrag<9>(frag); break;
+    case 10: waitLdsFrag<10>(frag); break;
+    case 11: waitLdsFrag<11>(frag); break;
+    default: waitLdsFrag<0>(frag); break;  // stricter than needed, never wrong
+  }
+}
 template <class V8>
 __device__ __forceinline__ void waitFragSel(V8& frag, int n) {
   switch(n) {
@@ -457,6 +475,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
     constexpr int NHS = RWG::NHS;
     constexpr int NSET = MTW < MT ? 6 : 3;  // image-fragment register sets; the reads run NSET - 1 k halves ahead of their MFMAs
     static_assert(NHS % NSET == 0, "the set of a k half must be a compile-time index");
+    static_assert(MTW * (NSET - 1) - 1 <= 11, "waitLdsFragSel knows counts up to 11");
     // the ring of weight fragments: R k halves of WN fragments each. One channel tile per wave: a whole chunk (18 x 4 registers); two: half
     // a chunk (9 x 8 registers, and a k half is twice as long)
     static_assert(NHS % R == 0 && (R - 2) * WN <= 17, "ring slots are compile-time indices; waitFragSel knows counts up to 17");
@@ -491,6 +510,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
     int chunk = 0;
     // one chunk: the barrier, then 18 k halves. LAST: the last chunk requests nothing beyond its own fragments (nothing stays in flight into
     // the epilogue, whose registers a late fragment would overwrite) and its waits count down with what is left in flight.
+    // ROUND 6: that rule now holds for the IMAGE fragments too. Until then the last chunk went on reading NSET - 1 k halves ahead - the
+    // fragments of a chunk that does not exist, never used and therefore never waited for. Their destination registers are dead to the
+    // compiler: it gave them to the epilogue (the cfg 125 build: v[40:43], the row pointer of the residual prefetch), and when the LDS
+    // data landed there AFTER the pointer had been computed the load went to an address made of image bits: the GPU exception
+    // (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION) that killed production self-play in round 5's driver run - only under contention,
+    // when LDS returns late enough: a pass alone on the chip never showed it, and the CPU emulation completes a read at once (DESIGN.md 0e;
+    // tools/check_async_loads.py now walks the shipped code objects for exactly this and is a test).
     auto chunkBody = [&](auto lastTag) {
       constexpr bool LAST = decltype(lastTag)::value != 0;
       const unsigned curA = (unsigned)(chunk % NSA) * ACT_BYTES;
@@ -510,10 +536,16 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
         const int younger = (!LAST || NHS - 1 - hs > R - 2) ? R - 2 : NHS - 1 - hs;
 #pragma unroll
         for(int wn = 0; wn < WN; wn++) waitFragSel(wf[slot][wn], younger * WN);
+        // LAST: no image fragment is read beyond the chunk's own
+        const bool readAhead = !LAST || hs + NSET - 1 < NHS;
 #pragma unroll
         for(int pt = 0; pt < MTW; pt++) {
-          // an image fragment is read NSET - 1 k halves before its use, MTW reads per k half: MTW (NSET - 1) - 1 younger reads at every use
-          waitLdsFrag<MTW * (NSET - 1) - 1>(af[hs % NSET][pt]);
+          // an image fragment is read NSET - 1 k halves before its use, MTW reads per k half, in the order (k half, cell tile): at the use of
+          // (hs, pt) the younger reads are those up to (hs + NSET - 1, pt - 1): MTW (NSET - 1) - 1 - in the last chunk at most what is left
+          // of the chunk, (NHS - 1 - hs) MTW + (MTW - 1 - pt): its last use waits for everything
+          constexpr int STEADY = MTW * (NSET - 1) - 1;
+          const int left = (NHS - 1 - hs) * MTW + (MTW - 1 - pt);
+          waitLdsFragSel(af[hs % NSET][pt], (!LAST || left > STEADY) ? STEADY : left);
 #pragma unroll
           for(int wn = 0; wn < WN; wn++) {
             acc[wn * MTW + pt] = TR::mfma(wf[slot][wn], af[hs % NSET][pt], acc[wn * MTW + pt]);
@@ -524,7 +556,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(PACK ?
                 if(f < NHS) loadW(f % R, wCur, f);
                 else if(!LAST) loadW(f % R, wNext, f - NHS);
               }
-              ldsReadFrag(af[setR][pt], fragAddr(hs + NSET - 1, curA, nextA, pt));
+              if(readAhead) ldsReadFrag(af[setR][pt], fragAddr(hs + NSET - 1, curA, nextA, pt));
               __builtin_amdgcn_sched_barrier(0);
             }
           }

@@ -1032,15 +1032,39 @@ void Engine::runSchedule(int n, const float* dSpatial, const unsigned char* dPac
       return;
     }
     // KMX_DEBUG_SYNC=1 (fault triage, with KMX_GRAPHS=0): every op is named on stderr before its launch and waited for after it - the
-    // last line before a device fault names the op that faulted (round 6)
+    // last line before a device fault names the op that faulted (round 6). KMX_DEBUG_SQUAT=<bytes> on top of it: before
+    // every op a squatter launch (kernels.h launchLdsSquatter: four one-wave work-groups per CU holding <bytes> of LDS each for 200 us)
+    // goes out on a second stream, so that the op's work-groups start at a nonzero LDS base wherever they fit beside it; LDS words of
+    // the squatters that the op overwrote are reported.
     static const bool debugSync = getenv("KMX_DEBUG_SYNC") != nullptr;
+    static const int debugSquat = getenv("KMX_DEBUG_SQUAT") ? atoi(getenv("KMX_DEBUG_SQUAT")) : 0;
+    static hipStream_t squatStream = nullptr;
+    static unsigned* squatCorrupt = nullptr;
+    if(debugSync && debugSquat > 0 && squatStream == nullptr) {
+      hipCheck(hipStreamCreateWithFlags(&squatStream, hipStreamNonBlocking), "hipStreamCreate");
+      hipCheck(hipMalloc((void**)&squatCorrupt, sizeof(unsigned)), "hipMalloc");
+      hipCheck(hipMemset(squatCorrupt, 0, sizeof(unsigned)), "hipMemset");
+    }
     for(size_t i = 0; i < ops_.size(); i++) {
       if(debugSync) {
         fprintf(stderr, "[kmx op] %zu %s rows %d\n", i, opClasses_[ops_[i].cls].c_str(), n);
         fflush(stderr);
+        if(debugSquat > 0) hipCheck(launchLdsSquatter(1024, debugSquat, 200, squatCorrupt, squatStream), "squatter launch");
       }
       ops_[i].fn(n, stream_);
-      if(debugSync) hipCheck(hipStreamSynchronize(stream_), "hipStreamSynchronize (KMX_DEBUG_SYNC)");
+      if(debugSync) {
+        hipCheck(hipStreamSynchronize(stream_), "hipStreamSynchronize (KMX_DEBUG_SYNC)");
+        if(debugSquat > 0) {
+          hipCheck(hipStreamSynchronize(squatStream), "hipStreamSynchronize (KMX_DEBUG_SQUAT)");
+          unsigned bad = 0;
+          hipCheck(hipMemcpy(&bad, squatCorrupt, sizeof(bad), hipMemcpyDeviceToHost), "hipMemcpy");
+          if(bad != 0) {
+            fprintf(stderr, "[kmx squat] op %zu %s rows %d overwrote %u LDS words outside its allocation\n", i, opClasses_[ops_[i].cls].c_str(), n, bad);
+            fflush(stderr);
+            hipCheck(hipMemset(squatCorrupt, 0, sizeof(unsigned)), "hipMemset");
+          }
+        }
+      }
       if((int)i + 1 == forkAt) hipCheck(hipEventRecord(forkEv_, stream_), "hipEventRecord");
     }
     return;

@@ -292,6 +292,11 @@ hipError_t launchBnAct(int dtype, const BnActArgs& a, hipStream_t stream);
 // fp32 <-> T conversion of dense activation tensors (test hooks / debugging)
 hipError_t launchFloatToT(int dtype, const float* in, int inC, void* out, int outStride, size_t cells, hipStream_t stream);
 hipError_t launchTToFloat(int dtype, const void* in, int inStride, int offset, float* out, int outC, size_t cells, hipStream_t stream);
+// Fault triage (KMX_DEBUG_SQUAT, engine.cpp; tests): `blocks` one-wave work-groups that hold `ldsBytes` of LDS each for `usec` microseconds,
+// fill them with a pattern and count, into *corrupt, the words that no longer hold it at the end. Launched beside a kernel under test it
+// makes that kernel's work-groups start at a NONZERO LDS base on the compute units they share - where a kernel runs whenever another
+// stream's kernels are on the chip - and notices writes that land outside the kernel's own allocation.
+hipError_t launchLdsSquatter(int blocks, int ldsBytes, int usec, unsigned* corrupt, hipStream_t stream);
 
 // host helpers
 uint16_t floatToHalfBits(float f);

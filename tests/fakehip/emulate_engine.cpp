@@ -30,6 +30,7 @@ double benchMfma(int, int, int, int, int, double*, double*) { return 0.0; }
 double benchLaunchFloor(int, int, int, int, int) { return 0.0; }
 double benchSeam(int, int, int) { return 0.0; }
 double benchConvChain(int, int, int, int, int) { return 0.0; }
+hipError_t launchLdsSquatter(int, int, int, unsigned*, hipStream_t) { return 801; }  // (device-only triage tool)
 
 #ifndef KMX_EMU_REAL_CONV  // the "real convolution" build compiles a transformed copy of conv_mfma.hip / conv_kernel.h instead
 namespace {

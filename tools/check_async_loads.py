@@ -9,11 +9,21 @@ lands. Both are silent at compile time.
 
 This script reads the device assembly of a translation unit (hipcc --cuda-device-only -S) and walks every kernel that contains such
 loads, instruction by instruction, with the hardware's in-order vmcnt queue: a register is IN FLIGHT from the load that names it as its
-destination until an s_waitcnt vmcnt(N) retires that load. Any instruction that reads or writes a register in flight is reported.
+destination until an s_waitcnt vmcnt(N) retires that load - and, since round 6, the same for LDS reads (ds_read_*) and lgkmcnt: the
+hand-written ds_read_b128 of the same kernels read fragments several k halves ahead, and the reads issued for a "next chunk" that does not
+exist were never waited for: their destination registers are dead to the compiler, which gave them to the epilogue's row addresses - and
+the LDS data that landed there later made production self-play die of HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION.
+Any instruction that reads or writes a register in flight is reported.
 Loops are walked twice (state carried over the back edge). Exit status 1 if anything is reported.
 
-    python tools/check_async_loads.py /tmp/conv_mfma.s [kernel-name-substring]
+    python tools/check_async_loads.py /tmp/conv_mfma.s [kernel-name-substring]      # hipcc --cuda-device-only -S output
+    python tools/check_async_loads.py katago_amd/libkatamx.so [kernel-name-substring] # the shipped library: its gfx950 code objects are
+                                                                                      # unbundled and disassembled (llvm-objdump), seconds
+Also reports, per kernel with such loads, scratch use (a spilled fragment register is a copy at the wrong time by construction).
 """
+import os
+import subprocess
+import tempfile
 import re
 import sys
 
@@ -35,7 +45,10 @@ VM_STORE = ("global_store", "buffer_store", "flat_store", "scratch_store", "glob
 def parse(body):
     prog = []
     for l in body:
-        s = l.split(";")[0].strip()
+        s = l.split(";")[0].split("//")[0].strip()
+        if re.match(r"^<L\d+>:$", s):  # llvm-objdump --symbolize-operands
+            prog.append(("label", s[:-1]))
+            continue
         if not s or s.startswith((".", "/")):
             if re.match(r"^\.LBB\d+_\d+:", s):
                 prog.append(("label", s[:-1]))
@@ -52,6 +65,7 @@ def check(name, body, verbose=False):
     prog = parse(body)
     labels = {p[1]: i for i, p in enumerate(prog) if p[0] == "label"}
     queue = []  # in-flight VMEM operations in issue order: (frozenset(dest regs), text)
+    lgkm = []   # in-flight LDS / scalar-memory operations in issue order (LDS operations of a wave return in order)
     problems = []
     taken = set()
     i = 0
@@ -65,7 +79,7 @@ def check(name, body, verbose=False):
         _, op, rest, text = p
         ops = [o.strip() for o in rest.split(",")] if rest else []
         inflight = set()
-        for d, _t in queue:
+        for d, _t in queue + lgkm:
             inflight |= d
         if op == "s_waitcnt":
             m = re.search(r"vmcnt\((\d+)\)", rest)
@@ -73,8 +87,33 @@ def check(name, body, verbose=False):
                 n = int(m.group(1))
                 while len(queue) > n:
                     queue.pop(0)
-            elif re.fullmatch(r"\s*\d+\s*|0x[0-9a-f]+", rest):  # raw immediate: treat as a full wait
+            m = re.search(r"lgkmcnt\((\d+)\)", rest)
+            if m:
+                n = int(m.group(1))
+                while len(lgkm) > n:
+                    lgkm.pop(0)
+            if not re.search(r"cnt\(", rest):  # raw immediate: treat as a full wait
                 queue.clear()
+                lgkm.clear()
+            i += 1
+            continue
+        if op in ("s_endpgm",):
+            # the hardware waits for everything outstanding before it ends the wave; what matters is what ran before
+            queue.clear()
+            lgkm.clear()
+            i += 1
+            continue
+        if op.startswith("ds_"):
+            touched_all = set(regs(rest))
+            hit = touched_all & inflight
+            if hit:
+                problems.append((text, sorted(hit)))
+            is_read = op.startswith(("ds_read", "ds_load", "ds_bpermute", "ds_permute", "ds_swizzle", "ds_consume", "ds_append")) or "_rtn" in op
+            lgkm.append((frozenset(regs(ops[0])) if is_read and ops else frozenset(), text))
+            i += 1
+            continue
+        if op.startswith(("s_load", "s_buffer_load", "s_sendmsg", "s_memtime", "s_memrealtime", "s_dcache")):
+            lgkm.append((frozenset(), text))
             i += 1
             continue
         if op.startswith("s_cbranch") or op == "s_branch":
@@ -83,9 +122,6 @@ def check(name, body, verbose=False):
                 taken.add(i)
                 i = labels[tgt]
                 continue
-            i += 1
-            continue
-        if op in ("s_endpgm",):
             i += 1
             continue
         touched = set(regs(rest))
@@ -112,22 +148,70 @@ def check(name, body, verbose=False):
     return problems
 
 
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+
+
+def disassemble_library(so_path):
+    """The gfx950 code objects of a shared library (its .hip_fatbin section: one offload bundle per translation unit), disassembled."""
+    text = []
+    with tempfile.TemporaryDirectory() as d:
+        fat = os.path.join(d, "fat.bin")
+        subprocess.run([os.path.join(LLVM_BIN, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, so_path], check=True)
+        blob = open(fat, "rb").read()
+        offs = [m.start() for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", blob)]
+        for k, o in enumerate(offs):
+            piece = os.path.join(d, "b%d.bin" % k)
+            with open(piece, "wb") as f:
+                f.write(blob[o:offs[k + 1] if k + 1 < len(offs) else len(blob)])
+            co = os.path.join(d, "co%d.o" % k)
+            subprocess.run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + piece,
+                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True, capture_output=True)
+            r = subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", "--mcpu=gfx950", "--symbolize-operands", "--no-show-raw-insn",
+                                "--no-leading-addr", co], check=True, capture_output=True, text=True)
+            text.append(r.stdout)
+            notes = subprocess.run([os.path.join(LLVM_BIN, "llvm-readelf"), "--notes", co], capture_output=True, text=True).stdout
+            text.append("\n".join("; NOTE " + l for l in notes.split("\n")))
+    return "\n".join(text)
+
+
+def scratch_of(notes_lines, name):
+    """private_segment_fixed_size / vgpr_spill_count of a kernel from the code object's metadata (the '; NOTE' lines)."""
+    t = "\n".join(notes_lines)
+    for block in re.split(r"\n; NOTE\s+- \.agpr_count", t)[1:]:
+        if re.search(r"\.name:\s+" + re.escape(name) + r"\b", block):
+            g = lambda k: int((re.findall(k + r":\s+(\d+)", block) or ["0"])[0])
+            return g(r"\.private_segment_fixed_size"), g(r"\.vgpr_spill_count")
+    return None
+
+
 def main():
     path = sys.argv[1]
     only = sys.argv[2] if len(sys.argv) > 2 else ""
-    lines = open(path).read().split("\n")
-    starts = [(i, m.group(1)) for i, l in enumerate(lines) for m in [re.match(r"^(_Z\w+):\s*(;.*)?$", l)] if m]
+    from_library = path.endswith(".so")
+    lines = (disassemble_library(path) if from_library else open(path).read()).split("\n")
+    notes = [l for l in lines if l.startswith("; NOTE")]
+    if from_library:
+        starts = [(i, m.group(1)) for i, l in enumerate(lines) for m in [re.match(r"^<(_Z\w+)>:\s*$", l)] if m]
+    else:
+        starts = [(i, m.group(1)) for i, l in enumerate(lines) for m in [re.match(r"^(_Z\w+):\s*(;.*)?$", l)] if m]
     bad = 0
-    for i, name in starts:
+    for k, (i, name) in enumerate(starts):
         if only and only not in name:
             continue
-        j = i
-        while j < len(lines) and not lines[j].startswith(".Lfunc_end"):
-            j += 1
+        j = i + 1
+        if from_library:
+            j = starts[k + 1][0] if k + 1 < len(starts) else len(lines)
+        else:
+            while j < len(lines) and not lines[j].startswith(".Lfunc_end"):
+                j += 1
         body = lines[i + 1:j]
-        if not any(("global_load_dwordx4" in l and re.search(r", s\[\d+:\d+\]", l)) for l in body):
+        if not any(("global_load_dwordx4" in l and re.search(r", s\[\d+:\d+\]", l)) for l in body) and not os.environ.get("KMX_CHECK_ALL_KERNELS"):
             continue
         problems = check(name, body)
+        sc = scratch_of(notes, name) if notes else None
+        if sc is not None and (sc[0] or sc[1]):
+            print("%s: %d bytes of scratch per lane, %d spilled registers" % (name, sc[0], sc[1]))
+            bad += 1
         print("%s: %d instruction(s) touch a register whose load is in flight" % (name, len(problems)))
         for t, h in problems[:12]:
             print("    %-70s  in flight: v%s" % (t, ",v".join(map(str, h[:8]))))

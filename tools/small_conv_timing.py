@@ -12,7 +12,7 @@ from katago_amd import capi  # noqa: E402
 
 lib = capi.load_library()
 capi.check(lib.kmx_global_init(), lib)
-for cfg, batch in ((127, 8), (128, 32), (126, 64)):
+for cfg, batch in ((127, 8),):  # (round 5 also stamped cfg 128 and 126: those instantiations spilled - conv_bench.hip - and are gone)
     for mode in (0, 1):
         for variant, what in ((0, "product"), (9999, "cycle stamps")):
             ms = ctypes.c_double()
