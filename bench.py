@@ -257,7 +257,10 @@ def selfplay_rates(binary, model_path, tmp, game_threads=8, search_threads=8, ti
         cfg = selfplay_cfg.write(os.path.join(d, "main.cfg"), numGameThreads=game_threads, numSearchThreads=search_threads, nnMaxBatchSize=64,
                                  logGamesEvery=1000, switchNetsMidGame="false", nnCacheSizePowerOfTwo=21, nnMutexPoolSizePowerOfTwo=16,
                                  **selfplay_cfg.ONLY_19)
-        env = dict(os.environ, KATAMX_LEAVES_PER_THREAD=str(search_threads))
+        # KMX_BATCH_TRACE: one line per launched device batch on stderr (csrc/batcher.cpp) - the batch-size distribution of the run and, if the
+        # child dies, the sizes that were on the device; HSA_DISABLE_COREDUMP_ON_EXCEPTION: a device exception is reported by the runtime's
+        # own message (kind of fault) instead of by its core-dump attempt, which in round 5's driver run left nothing but "execvp failed"
+        env = dict(os.environ, KATAMX_LEAVES_PER_THREAD=str(search_threads), KMX_BATCH_TRACE="1", HSA_DISABLE_COREDUMP_ON_EXCEPTION="1")
         p = subprocess.Popen([binary, "selfplay", "-config", cfg, "-models-dir", os.path.join(d, "models"), "-output-dir", os.path.join(d, "out"),
                               "-max-games-total", str(game_threads)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=d, env=env)
         try:
@@ -271,12 +274,29 @@ def selfplay_rates(binary, model_path, tmp, game_threads=8, search_threads=8, ti
             except subprocess.TimeoutExpired:
                 p.kill()
                 log, _ = p.communicate()
+        sizes = [int(v) for v in re.findall(r"^\[kmx batch\] slot \d+ rows (\d+)", log, re.M)]
+        trace_tail = re.findall(r"^\[kmx batch\] (.*)$", log, re.M)[-8:]
+        log = re.sub(r"^\[kmx batch\].*\n", "", log, flags=re.M)
         g = lambda k: float((re.findall(k + r": ([\d.]+)", log) or ["nan"])[-1])
         secs, total = g(r"Total selfplay runtime \(seconds\)"), g("Total games")
         rows, moves, fin, batches = g("Final NN rows"), g("Final moves played"), g("Final games finished"), g("Final NN batches")
+        hist = {}
+        for v in sizes:
+            hist[v] = hist.get(v, 0) + 1
         if not secs > 0 or not rows > 0:
-            return {"selfplay_error": log[-300:]}
+            # the child did not reach its totals: keep what a diagnosis needs - how it ended, the runtime's fault line, what was on the device
+            import signal
+
+            rc = p.returncode
+            sig = signal.Signals(-rc).name if rc is not None and rc < 0 else None
+            fault = [l.strip()[-300:] for l in log.splitlines() if re.search(r"HSA_STATUS|Memory access fault|GPU coredump|Aborted|terminate called|what\(\)", l)]
+            return {"selfplay_error": {"returncode": rc, "signal": sig, "fault": fault[:4], "last_device_batches": trace_tail,
+                                       "device_batch_rows_histogram": {str(k): hist[k] for k in sorted(hist)}, "log_tail": log[-600:]}}
         out = {"selfplay_nn_rows_per_s": round(rows / secs, 1)}
+        if sizes:
+            srt = sorted(sizes)
+            out["selfplay_device_batch_rows"] = {"batches": len(srt), "mean": round(sum(srt) / len(srt), 1), "p10": srt[len(srt) // 10],
+                                                 "p50": srt[len(srt) // 2], "p90": srt[(len(srt) * 9) // 10], "max": srt[-1]}
         what = ("katago selfplay (command/selfplay.cpp), b18c384nbt 19x19 random weights, %d game threads x %d search threads on fibers, the reference's "
                 "production settings (selfplay8mainb18.cfg: 2000 / 350 visits), product path (own evaluator + featuriser + leaf batcher)" % (game_threads, search_threads))
         if fin >= game_threads and "Exited cleanly after signal" not in log:

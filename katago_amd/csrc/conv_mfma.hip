@@ -71,16 +71,17 @@ constexpr int CFG_REGW_HALF = 125;   // cfg 128's cell tiles over TWO work-group
 //                        from host rows 1.38 -> 1.31 ms at batch 1, 1.59 -> 1.49 at 8, 2.11 -> 1.93 at 16, 2.12 -> 1.98 at 32, 3.24 -> 2.88 at 64,
 //                        3.78 -> 3.36 at 85; self-play at 8 games x 8 leaves 20.4 -> 21.7 k NN rows/s
 //   regw64_max_wgs  256  work-groups up to which cfg 126 is taken
-//   regw_half       0    cfg 125 (cell tiles over two work-groups) while batch x channel tiles x 2 <= loaders_max_wgs (0: cfg 128 there;
-//                        2: also where the three-way split would be taken - tests). One box, a pass from host rows: 1.95 -> 1.79 ms at
-//                        batch 15, 1.97 -> 1.80 at 16, 2.08 -> 1.96 at 21 (profiles/r05_steps/regw/half_small_batch_scan.txt).
-//                        OFF SINCE ROUND 6: with it on (round 5's last hour) production self-play dies of a GPU exception within
-//                        10-25 s - HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION raised by a multiplying wave of THIS shape at the top of
-//                        its epilogue, only while another stream's pass shares the chip (profiles/r06_steps/fault). The
-//                        shape stays instantiated for the triage tools (tools/concurrent_pass_stress.py) and is not chosen.
+//   regw_half       1    cfg 125 (cell tiles over two work-groups) while batch x channel tiles x 2 <= loaders_max_wgs (0: cfg 128 there;
+//                        2: also where the three-way split would be taken - tests). One box, a pass from host rows: 1.92 -> 1.78 ms at
+//                        batch 15, 1.95 -> 1.79-1.83 at 16, 2.03-2.07 -> 1.89-1.95 at 21; production self-play at 8 games x 8 leaves 21.0
+//                        -> 22.7-23.2 k NN rows/s (profiles/r06_steps/fault/fixed_*). Round 5 switched it on in its last hour and the
+//                        driver's self-play run died of a GPU exception: the register-weights shapes read image fragments past their
+//                        last chunk and never waited for them, and THIS instantiation's epilogue happened to re-use those registers for
+//                        a row pointer (conv_small_kernel.h chunkBody). Fixed in the kernel, guarded by
+//                        tools/check_async_loads.py (tests/test_async_loads.py) and tests/test_gpu_selfplay_production.py.
 struct ConvTune {
   int minWgs8 = 150, loaders = 1, loadersDepth = 1, loadersSplit = 1, loadersMaxWgs = 256, packedMaxWgs = 512, deep1x1 = 1, deep1x1MaxWgs = 256,
-      split1x1 = 1, regw = 3, regw64MaxWgs = 256, regwHalf = 0;
+      split1x1 = 1, regw = 3, regw64MaxWgs = 256, regwHalf = 1;
 };
 const ConvTune& convTune() {
   static const ConvTune t = [] {
