@@ -68,6 +68,11 @@ struct ComputeContext {
   int nnYLen;
   int precisionMode;
   kmx_context* ctx = NULL;
+  // useFP16 = false on a net the fp32 verification mode does not cover (transformer blocks, RMSNorm tips: csrc/engine.cpp) falls back
+  // to the backend's 16-bit default with a logged warning instead of failing at handle creation: a second context,
+  // created on first need (under batcherMutex), frees with this one.
+  kmx_context* fallbackCtx = NULL;
+  std::vector<int> gpuIdxs;
   // katamxBatcher = true: every server thread of this context that serves the same (model, device) feeds ONE persistent leaf
   // batcher (kmx_batcher_*) instead of owning a handle: its getOutput submits the rows NNEvaluator::serve popped and waits
   // for their tickets. Rows of several server threads then share device batches (up to katamxBatcherInFlight of them
@@ -80,6 +85,7 @@ struct ComputeContext {
     int maxBatchSize = 0;
   };
   std::mutex batcherMutex;
+  std::mutex fallbackMutex;
   std::map<std::pair<const LoadedModel*, int>, SharedBatcher> batchers;
 };
 
@@ -178,6 +184,7 @@ ComputeContext* NeuralNet::createComputeContext(
     else if(p != "auto" && p != "") throw StringError("KATAMX_PRECISION must be one of fp16, bf16, fp32, auto");
   }
   context->precisionMode = precisionMode;
+  context->gpuIdxs = gpuIdxs;
   if(cfg.contains("katamxBatcher")) context->useBatcher = cfg.getBool("katamxBatcher");
   else if(const char* e = getenv("KATAMX_BATCHER")) context->useBatcher = atoi(e) != 0;
   if(cfg.contains("katamxBatcherInFlight")) context->batcherInFlight = cfg.getInt("katamxBatcherInFlight", 1, 8);
@@ -187,10 +194,35 @@ ComputeContext* NeuralNet::createComputeContext(
     "creating compute context");
   return context.release();
 }
+
+// kmx_handle_create / kmx_batcher_create through `create(ctx)`; a context that asks for fp32 and a net that mode does not serve
+// (KMX_ERR_UNSUPPORTED) retry on the context's 16-bit twin.
+template <class F>
+static void createWithPrecisionFallback(ComputeContext* context, Logger* logger, const string& modelName, const char* what, F create) {
+  int rc = create(context->ctx);
+  if(rc == KMX_ERR_UNSUPPORTED && context->precisionMode == KMX_PREC_FP32) {
+    const string why = lastError();
+    {
+      std::lock_guard<std::mutex> lock(context->fallbackMutex);
+      if(context->fallbackCtx == NULL)
+        check(
+          kmx_context_create(context->gpuIdxs.data(), (int)context->gpuIdxs.size(), context->nnXLen, context->nnYLen, KMX_PREC_AUTO, &context->fallbackCtx),
+          "creating the 16-bit fallback context");
+    }
+    const string msg = "katamx backend: WARNING: useFP16 = false is not served for model " + modelName + " (" + why +
+                       "); falling back to the backend's 16-bit default for it";
+    if(logger != NULL) logger->write(msg);
+    else cerr << msg << endl;
+    rc = create(context->fallbackCtx);
+  }
+  check(rc, what);
+}
 void NeuralNet::freeComputeContext(ComputeContext* computeContext) {
   if(computeContext == NULL)
     return;
   kmx_context_free(computeContext->ctx);
+  if(computeContext->fallbackCtx != NULL)
+    kmx_context_free(computeContext->fallbackCtx);
   delete computeContext;
 }
 
@@ -217,19 +249,18 @@ ComputeHandle* NeuralNet::createComputeHandle(
     std::lock_guard<std::mutex> lock(context->batcherMutex);
     ComputeContext::SharedBatcher& sb = context->batchers[std::make_pair(loadedModel, gpuIdxForThisThread)];
     if(sb.batcher == NULL) {
-      check(
-        kmx_batcher_create(context->ctx, loadedModel->model, maxBatchSize, context->batcherInFlight, gpuIdxForThisThread, &sb.batcher),
-        "creating the leaf batcher");
+      createWithPrecisionFallback(context, logger, loadedModel->modelDesc.name, "creating the leaf batcher", [&](kmx_context* c) {
+        return kmx_batcher_create(c, loadedModel->model, maxBatchSize, context->batcherInFlight, gpuIdxForThisThread, &sb.batcher);
+      });
       sb.maxBatchSize = maxBatchSize;
     }
     sb.users++;
     handle->batcher = sb.batcher;
   }
   else
-    check(
-      kmx_handle_create(
-        context->ctx, loadedModel->model, maxBatchSize, requireExactNNLen ? 1 : 0, gpuIdxForThisThread, &handle->handle),
-      "creating compute handle");
+    createWithPrecisionFallback(context, logger, loadedModel->modelDesc.name, "creating compute handle", [&](kmx_context* c) {
+      return kmx_handle_create(c, loadedModel->model, maxBatchSize, requireExactNNLen ? 1 : 0, gpuIdxForThisThread, &handle->handle);
+    });
   if(logger != NULL) {
     int prec = handle->batcher != NULL ? kmx_batcher_precision(handle->batcher) : kmx_handle_precision(handle->handle);
     logger->write(
@@ -408,9 +439,9 @@ KatamxLeaf::Port* KatamxLeaf::openPort(
   port->context = context;
   port->loadedModel = loadedModel;
   port->numInputMetaChannels = loadedModel->modelDesc.numInputMetaChannels;
-  check(
-    kmx_batcher_create(context->ctx, loadedModel->model, maxBatchSize, batchesInFlight, gpuIdx, &port->batcher),
-    "creating the leaf batcher");
+  createWithPrecisionFallback(context, logger, loadedModel->modelDesc.name, "creating the leaf batcher", [&](kmx_context* c) {
+    return kmx_batcher_create(c, loadedModel->model, maxBatchSize, batchesInFlight, gpuIdx, &port->batcher);
+  });
   if(logger != NULL) {
     logger->write(
       "katamx (HIP/gfx950) leaf port: device " + Global::intToString(gpuIdx < 0 ? 0 : gpuIdx) + " [" + deviceLabel(gpuIdx) + "] precision " +

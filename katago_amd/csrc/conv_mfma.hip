@@ -54,7 +54,9 @@ constexpr int CFG_REGW_HALF = 125;   // cfg 128's cell tiles over TWO work-group
 // ---- ONE debug override for every switch of the shape choice: KMX_CONV_TUNE="key=value,key=value" (read once) ----
 // Defaults are the product; the keys exist for A/B scans (tools/small_batch_scan.py) and for tests that force a shape at a size the
 // chooser would not pick it for (tests/test_kernels_latest_completion.py, tests/test_engine_emulated.py). Unknown keys abort: a typo must
-// not silently measure the default. (Until round 4 these were nine separate environment variables.)
+// not silently measure the default - reported through the normal error path since round 6 (convTuneError(): engine construction fails with
+// KMX_ERR_INVALID_ARG, launchConv returns hipErrorInvalidValue) instead of abort() inside the embedder's process. (Until round 4 these were
+// nine separate environment variables: a leftover one is named on stderr once.)
 //   min_wgs8        150  work-groups from which the 8-wave x 192 / x 128 shapes are taken
 //   loaders         1    the small-batch 3x3 shape with fetching waves (0: the 4-wave shapes of conv_kernel.h)
 //   loaders_depth   1    its fetch depth: slabs six steps / images two chunks ahead (0: three / one); 16.94 -> 16.47 us per 3x3 launch at
@@ -82,10 +84,15 @@ constexpr int CFG_REGW_HALF = 125;   // cfg 128's cell tiles over TWO work-group
 struct ConvTune {
   int minWgs8 = 150, loaders = 1, loadersDepth = 1, loadersSplit = 1, loadersMaxWgs = 256, packedMaxWgs = 512, deep1x1 = 1, deep1x1MaxWgs = 256,
       split1x1 = 1, regw = 3, regw64MaxWgs = 256, regwHalf = 1;
+  std::string error;  // non-empty: KMX_CONV_TUNE could not be parsed (an unknown key)
 };
 const ConvTune& convTune() {
   static const ConvTune t = [] {
     ConvTune t;
+    for(const char* legacy : {"KMX_CONV_LOADERS", "KMX_CONV_LOADERS_DEPTH", "KMX_CONV_LOADERS_SPLIT", "KMX_CONV_LOADERS_MAX_WGS", "KMX_CONV_PACKED_MAX_WGS",
+                              "KMX_CONV_DEEP1X1", "KMX_CONV_DEEP1X1_MAX_WGS", "KMX_CONV_SPLIT1X1", "KMX_MIN_WGS8"})
+      if(getenv(legacy) != nullptr)
+        fprintf(stderr, "katamx: %s is no longer read (round 4): use KMX_CONV_TUNE=\"key=value,...\" (csrc/conv_mfma.hip)\n", legacy);
     const char* e = getenv("KMX_CONV_TUNE");
     if(e == nullptr) return t;
     const struct { const char* key; int* v; } keys[] = {
@@ -108,10 +115,7 @@ const ConvTune& convTune() {
             *k.v = atoi(item.c_str() + eq + 1);
             known = true;
           }
-      if(!known) {
-        fprintf(stderr, "katamx: KMX_CONV_TUNE: unknown item '%s'\n", item.c_str());
-        abort();
-      }
+      if(!known && t.error.empty()) t.error = "KMX_CONV_TUNE: unknown item '" + item + "' (keys: csrc/conv_mfma.hip)";
     }
     return t;
   }();
@@ -140,7 +144,13 @@ hipError_t launchT(int ks, int cfg, const ConvArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+const char* convTuneError() {
+  const ConvTune& t = convTune();
+  return t.error.empty() ? nullptr : t.error.c_str();
+}
+
 hipError_t launchConv(int dtype, int ks, int cfg, const ConvArgs& a, hipStream_t stream) {
+  if(convTuneError() != nullptr) return hipErrorInvalidValue;  // a typo in KMX_CONV_TUNE must not silently measure the default
   if(a.X < 2 || a.Y < 2 || a.X > MAXLEN || a.Y > MAXLEN || a.N <= 0) return hipErrorInvalidValue;
   if(a.inC % 8 != 0 || a.coutPad % 32 != 0 || (a.nChunks + 4) * 64 > ZERO_PAGE_BYTES) return hipErrorInvalidValue;
   if(dtype == DT_F32) return launchConvF32(ks, a, stream);

@@ -274,6 +274,7 @@ Engine::Engine(const ModelDesc& model, int nnXLen, int nnYLen, int maxBatch, int
 }
 
 void Engine::construct(const ModelDesc& model) {
+  if(const char* tuneError = convTuneError()) throw Error(KMX_ERR_INVALID_ARG, tuneError);  // (a debug override that could not be parsed)
   hipCheck(hipSetDevice(device_), "hipSetDevice");
   hipCheck(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
   if(const char* e = getenv("KMX_GRAPHS")) useGraphs_ = atoi(e) != 0;

@@ -72,6 +72,7 @@ hipError_t launchConv(int dtype, int ks, int cfg, const ConvArgs& a, hipStream_t
 hipError_t launchConvF32(int ks, const ConvArgs& a, hipStream_t stream);  // conv_f32.hip: the DT_F32 form of the contract above (cfg is ignored)
 int chooseConvCfg(int ks, int coutPad, int batch);
 bool convCfgInstantiated(int ks, int cfg);  // is there a kernel for this (kernel size, shape)?
+const char* convTuneError();  // null, or why the debug override KMX_CONV_TUNE could not be parsed (engine construction then fails)
 
 // A chain of 2..MAX_CHAIN 3x3 convolutions 192 -> 192 of one board as ONE launch (conv_chain_kernel.h): the inner residual blocks of a
 // nested-bottleneck block. Convolution i reads the activated image of convolution i - 1 (conv 0: `in`); every tensor has channel

@@ -516,6 +516,7 @@ int kmx_debug_conv_cfg(int ks, int cout_pad, int batch, int* cfg, int* instantia
   return guarded([&] {
     if(!cfg || !instantiated || cout_pad < 64 || cout_pad % 64 != 0 || batch < 1 || (ks != 1 && ks != 3 && ks != 5))
       throw Error(KMX_ERR_INVALID_ARG, "kmx_debug_conv_cfg: bad argument");
+    if(const char* tuneError = convTuneError()) throw Error(KMX_ERR_INVALID_ARG, tuneError);  // what engine construction reports, too
     *cfg = chooseConvCfg(ks, cout_pad, batch);
     // the special shapes of conv_mfma.hip: 113 / 114 (1x1, deep ring), 117 (3x3, split) and 118 / 119 (3x3, fetching waves) tile 32 channels, 124 tiles 64
     const int ntile = (*cfg == 124 || *cfg == 126) ? 64 : *cfg >= 111 ? 32 : 32 * (*cfg / 10) * (*cfg % 10);

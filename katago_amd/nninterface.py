@@ -333,6 +333,10 @@ class Batcher:
         capi.check(self._lib.kmx_batcher_stats(self._p, ctypes.byref(r), ctypes.byref(b)), self._lib)
         return r.value, b.value
 
+    def effectiveBatch(self):
+        """kmx_batcher_effective_batch: the largest batch this batcher ever launches (min(maxBatchSize, the device's granule))."""
+        return int(self._lib.kmx_batcher_effective_batch(self._p))
+
 
 # ---- layer test hooks (nninterface.h:134-180) ------------------------------------------------------
 

@@ -38,6 +38,7 @@ struct kmx_batcher {
   const kmx_context* ctx = nullptr;
   const kmx_model* model = nullptr;
   kmx_model_info info;
+  int maxBatch = 0;
   std::atomic<uint64_t> rows{0};
 };
 
@@ -130,6 +131,7 @@ int kmx_batcher_create(kmx_context* ctx, const kmx_model* model, int max_batch_s
   kmx_batcher* b = new kmx_batcher();
   b->ctx = ctx;
   b->model = model;
+  b->maxBatch = max_batch_size;
   const int rc = okmx_model_info_get(model->m, &b->info);
   if(rc != KMX_OK) {
     delete b;
@@ -140,6 +142,8 @@ int kmx_batcher_create(kmx_context* ctx, const kmx_model* model, int max_batch_s
 }
 void kmx_batcher_free(kmx_batcher* batcher) { delete batcher; }
 int kmx_batcher_precision(const kmx_batcher*) { return KMX_PREC_FP32; }
+// (no device, no granule: what was asked for is what a batch may hold; include/katamx.h, ABI 7)
+int kmx_batcher_effective_batch(const kmx_batcher* b) { return b ? b->maxBatch : 0; }
 
 int kmx_batcher_submit(kmx_batcher* b, const float* row_spatial, const float* row_global, const float* row_meta, int symmetry,
                        float policy_optimism, float* out_policy, float* out_value, float* out_score, float* out_ownership, uint64_t* ticket) {

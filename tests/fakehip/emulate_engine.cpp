@@ -17,6 +17,7 @@ namespace kmx {
 #ifndef KMX_EMU_REAL_CONV
 int chooseConvCfg(int, int, int) { return 11; }
 bool convCfgInstantiated(int, int) { return true; }
+const char* convTuneError() { return nullptr; }
 // no fused seam kernel in this build: the engine then schedules the two convolution launches
 bool pointwisePairSupported(int, int, int) { return false; }
 hipError_t launchPointwisePair(int, int, int, int, const PwPairArgs&, hipStream_t) { return 801; }

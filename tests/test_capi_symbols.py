@@ -55,3 +55,28 @@ def test_tuning_hooks_refuse_bad_arguments_without_gpu():
     for args in ((0, 8192, 0, 10, 1), (18, 4096, 0, 10, 1), (18, 8192, 3, 10, 1), (18, 8192, 0, 0, 1), (18, 200 * 1024, 0, 10, 1)):
         assert lib.kmx_bench_launch_floor(*args, ctypes.byref(us)) == capi.KMX_ERR_INVALID_ARG, args
     assert lib.kmx_bench_launch_floor(18, 8192, 0, 10, 1, None) == capi.KMX_ERR_INVALID_ARG
+
+
+def test_the_cpu_twin_of_the_abi_defines_what_the_binding_can_call(tmp_path):
+    """oracle/kmx_abi_on_oracle.cpp implements include/katamx.h on the CPU oracle so that the SAME binding object links against either
+    (test infrastructure: katago_oracle, katago_oraclex). An entry point added to the header and missed there is an unresolved symbol for
+    every embedder built against the header and linked with the twin (round 5: kmx_batcher_effective_batch, ABI 7). The layer / device
+    test hooks (kmx_test_*, kmx_eval_device ...) that only exist on a GPU are listed and must not grow silently."""
+    import subprocess
+
+    obj = str(tmp_path / "twin.o")
+    subprocess.run(["g++", "-std=c++17", "-c", "-I" + os.path.join(REPO, "include"), "-I" + os.path.join(REPO, "oracle"),
+                    os.path.join(REPO, "oracle", "kmx_abi_on_oracle.cpp"), "-o", obj], check=True)
+    out = subprocess.run(["nm", "-g", "--defined-only", obj], check=True, capture_output=True, text=True).stdout
+    defined = set(re.findall(r"\b(kmx_[a-z0-9_]+)$", out, re.M))
+    # what the binding and this repo's evaluator call (integration/*.cpp, *.h): all of it must exist in the twin
+    used = set()
+    for f in os.listdir(os.path.join(REPO, "integration")):
+        if f.endswith((".cpp", ".h")) and f != "leaf_pump.cpp":  # (leaf_pump is the synthetic consumer of the device library only)
+            text = re.sub(r"//[^\n]*|/\*.*?\*/", "", open(os.path.join(REPO, "integration", f)).read(), flags=re.S)
+            used |= set(re.findall(r"\b(kmx_[a-z0-9_]+)\s*\(", text))
+    used &= set(declared_symbols())
+    assert len(used) >= 20 and "kmx_batcher_submit_packed" in used, sorted(used)
+    assert sorted(used - defined) == [], "the CPU twin lacks entry points the binding calls"
+    # and the one the advisor found missing in round 5: declared, exported by the device library, callable on the twin
+    assert "kmx_batcher_effective_batch" in defined

@@ -56,3 +56,21 @@ def test_small_batch_3x3_ranges_of_b18():
     want = {1: 127, 14: 127, 15: 125, 21: 125, 22: 128, 42: 128, 43: 126, 85: 126, 86: 12, 149: 13, 150: 23, 256: 23}
     assert {b: choice(192, b) for b in want} == want
     assert [choice(64, b) for b in (1, 42, 43, 64, 65, 128, 129, 256)] == [127, 127, 125, 125, 128, 128, 126, 126]
+
+
+def test_a_typo_in_the_debug_override_is_an_error_not_an_abort():
+    """KMX_CONV_TUNE with an unknown key: reported through the normal error path (KMX_ERR_INVALID_ARG from engine construction and from
+    kmx_debug_conv_cfg, hipErrorInvalidValue from launchConv) - until round 5 the shared library called abort() in the embedder's process
+    (ADVICE round 5). A leftover environment variable of the nine that KMX_CONV_TUNE replaced is named on stderr."""
+    import os
+    import subprocess
+    import sys
+
+    code = ("import ctypes, sys; sys.path.insert(0, %r); from katago_amd import capi; lib = capi.load_library(); c, k = ctypes.c_int(), ctypes.c_int();"
+            "rc = lib.kmx_debug_conv_cfg(3, 192, 8, ctypes.byref(c), ctypes.byref(k)); print('RC', rc, lib.kmx_last_error().decode())"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=dict(os.environ, KMX_CONV_TUNE="regw_haf=1", KMX_MIN_WGS8="100"))
+    assert p.returncode == 0 and ("RC %d" % capi.KMX_ERR_INVALID_ARG) in p.stdout and "unknown item 'regw_haf=1'" in p.stdout, p.stdout + p.stderr
+    assert "KMX_MIN_WGS8 is no longer read" in p.stderr, p.stderr
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=dict(os.environ, KMX_CONV_TUNE="regw_half=0"))
+    assert p.returncode == 0 and "RC 0" in p.stdout, p.stdout + p.stderr

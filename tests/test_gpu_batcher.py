@@ -33,6 +33,10 @@ def test_batcher_rows_are_bit_identical_to_kmx_eval(tmp_path, dtype):
             for k in ("policy", "value", "score", "ownership")}
     h.close()
     b = nn.Batcher(ctx, model, 48, maxInFlight=3)
+    assert b.effectiveBatch() == 48
+    big = nn.Batcher(ctx, model, 1024, maxInFlight=1)  # sealed at one granule of the device (its CU count), include/katamx.h ABI 6 / 7
+    assert big.effectiveBatch() == min(1024, 256)
+    big.close()
     got = [None] * n
     errors = []
     packed = nn.packRows(sp, 19, 19)  # every fifth row is handed over as bit planes (kmx_batcher_submit_packed)

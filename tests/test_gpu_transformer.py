@@ -278,3 +278,21 @@ def test_reference_gpuerror_acceptance_transformer_on_hip(tmp_path, net):
     m = results["auto"]
     assert len(m) == 4 and m["current cfg"] < 0.5 and m["batched current cfg"] < 0.5, results
     assert results["bf16"]["current cfg"] > m["current cfg"]  # AUTO picked the more accurate format
+
+
+def test_fp32_request_on_a_transformer_net_falls_back_with_a_warning(tmp_path):
+    """useFP16 = false (what `testgpuerror` without a reference file asks of its second evaluator, and what a user config may say) on a net
+    with transformer blocks: the fp32 verification mode of the device covers convolutional nets only (csrc/engine.cpp), and until round 5
+    handle creation failed with KMX_ERR_UNSUPPORTED - a hard stop for the reference's own command. The binding now falls back to the
+    backend's 16-bit default for that net and says so in the log (integration/katamxbackend.cpp createWithPrecisionFallback)."""
+    net = TF_NETS[0]
+    if not os.path.exists(os.path.join(REF_MODELS, net)):
+        pytest.skip("reference test nets not packaged")
+    cfg = tmp_path / "bench.cfg"
+    cfg.write_text(BENCH_CFG + "homeDataDir = %s\n" % (tmp_path / "home"))
+    r = subprocess.run([ref_binary("katago_hip"), "testgpuerror", "-model", os.path.join(REF_MODELS, net), "-config", str(cfg), "-boardsize", "9", "-quick"],
+                       capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    out = r.stdout + r.stderr
+    assert "falling back to the backend's 16-bit default" in out and "useFP16 = false is not served" in out, out[-3000:]
+    assert "error vs reference" in out or "GPU -1 finished" in out or r.returncode == 0, out[-3000:]
+    assert "KMX_ERR" not in out and "terminate called" not in out, out[-3000:]
