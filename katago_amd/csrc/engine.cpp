@@ -422,7 +422,7 @@ ConvArgs Engine::makeConvArgs(const FusedConv* fc, const void* in, int inStride,
 void Engine::launchConvOp(const ConvArgs& a, int ks, int n, hipStream_t st) {
   ConvArgs b = a;
   b.N = n;
-  hipCheck(launchConv(dtype_, ks, chooseConvCfg(ks, a.coutPad, n * cfgScale_), b, st), "convolution launch");
+  hipCheck(launchConv(dtype_, ks, chooseConvCfg(ks, a.coutPad, shapeRows(n)), b, st), "convolution launch");
 }
 
 void Engine::addConv(const FusedConv* fc, const void* in, int inStride, const float* ncBias, int ncBiasStride,
@@ -563,7 +563,7 @@ int Engine::addOrdinaryChain(const std::vector<BlockDesc>& blocks, size_t i, con
   const double launches = (double)(nc / perLaunch), handovers = (double)(nc - nc / perLaunch);
   const double bytesChained = 2.0 * S_ * (2.0 * launches * C + (double)nBlocks * 2.0 * C + handovers * C);
   addOp("conv3x3", 2.0 * macs * S_, bytesChained, [this, ca, ch, nc, perLaunch](int n, hipStream_t st) {
-    if(chooseConvCfg(3, CHAIN_CHANNELS, n * cfgScale_) == 23) {
+    if(chooseConvCfg(3, CHAIN_CHANNELS, shapeRows(n)) == 23) {
       for(int k0 = 0; k0 < nc; k0 += perLaunch) {
         ConvChainArgs x = ch;
         x.N = n;
@@ -986,7 +986,7 @@ void Engine::runSchedule(int n, const float* dSpatial, const unsigned char* dPac
     if(useGraphs_ && forkAt <= 0) {
       GraphKey key;
       key.n = n;
-      key.scale = cfgScale_;
+      key.scale = shapeRows(n);  // (what the shapes were chosen for: the batch, its concurrent parts and the rows beside it)
       const void* ptrs[8] = {dSpatial, dPacked, dGlobal, dMeta, dPolicy, dValue, dScore, dOwnership};
       for(int i = 0; i < 8; i++) key.p[i] = ptrs[i];
       auto it = graphCache_.find(key);
@@ -1081,7 +1081,7 @@ void Engine::runSchedule(int n, const float* dSpatial, const unsigned char* dPac
       }
     }
     // (a chain op - smallBelow < 0 - takes its separate-launch form whenever the batch does not take the one-work-group-per-board shape)
-    const bool smallForm = op.smallBelow < 0 ? chooseConvCfg(3, CHAIN_CHANNELS, n * cfgScale_) != 23 : n < op.smallBelow;
+    const bool smallForm = op.smallBelow < 0 ? chooseConvCfg(3, CHAIN_CHANNELS, shapeRows(n)) != 23 : n < op.smallBelow;
     p.cls = smallForm ? op.clsSmall : op.cls;
     p.launches = smallForm ? op.launchesSmall : op.launches;
     p.flops = op.flopsPerRow * n;
