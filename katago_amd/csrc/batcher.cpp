@@ -82,9 +82,6 @@ class Batcher {
       // fault triage: one line per launched batch on stderr (slot, rows, what else is on the device) - the last lines before a device
       // fault name the batch sizes that were in flight (bench.py keeps them when the self-play leg dies)
       if(const char* e = getenv("KMX_BATCH_TRACE")) trace_ = atoi(e) != 0;
-      // shapes for the boards that SHARE the chip (round 6): a small batch launched beside another one picks its work-group shapes for the
-      // sum of both (Engine::setRowsBeside). KMX_BATCH_SHAPE_BESIDE=0 restores shapes by the batch's own rows.
-      if(const char* e = getenv("KMX_BATCH_SHAPE_BESIDE")) shapeBeside_ = atoi(e) != 0;
     }
     maxBatch = sealAt_;  // no batch ever holds more rows: engines and staging are sized for what can be used
     maxBatch_ = sealAt_;
@@ -317,7 +314,6 @@ class Batcher {
       const int n = s.count;
       const bool anyOwner = s.anyOwner;
       if(trace_) fprintf(stderr, "[kmx batch] slot %d rows %d beside %d rows in %d batches\n", si, n, rowsOnDevice_ - n, running_ - 1);
-      s.eng->setRowsBeside(shapeBeside_ ? rowsOnDevice_ - n : 0);
       l.unlock();
       while(s.copied.load(std::memory_order_acquire) < n) std::this_thread::yield();  // a row copy takes a few microseconds
       int err = KMX_OK;
@@ -422,7 +418,6 @@ class Batcher {
   static constexpr int SMALL_ROWS = 96;     // partial batches may run side by side while the device holds at most this many rows
   bool closing_ = false;
   bool trace_ = false;
-  bool shapeBeside_ = false;
   uint64_t nextTicket_ = 1;
   // node-based map: references to its elements stay valid while other tickets come and go (a waiter sleeps holding one)
   std::map<uint64_t, Pending> pending_;

@@ -57,7 +57,12 @@ constexpr int CFG_REGW_HALF = 125;   // cfg 128's cell tiles over TWO work-group
 // not silently measure the default - reported through the normal error path since round 6 (convTuneError(): engine construction fails with
 // KMX_ERR_INVALID_ARG, launchConv returns hipErrorInvalidValue) instead of abort() inside the embedder's process. (Until round 4 these were
 // nine separate environment variables: a leftover one is named on stderr once.)
-//   min_wgs8        150  work-groups from which the 8-wave x 192 / x 128 shapes are taken
+//   min_wgs8        129  work-groups from which the 8-wave x 192 / x 128 shapes are taken. Round 6 (150 until then): from 129 boards on the
+//                        4-wave x 96 shape is more than one work-group per CU (a pass over 144 rows: 5.11 -> 4.32 ms; 130: 4.19 -> 4.12; at 96-112
+//                        the 4-wave shapes stay 3-4 % ahead), and where two batches of ~110-135 rows share the chip - `benchmark -v 1600 -t
+//                        256` 25.2 -> 26.7 k nnEvals/s, self-play at 32 games x 8 leaves 25.9 -> 27.2 k NN rows/s, two runs each
+//                        (profiles/r06_steps/midbatch). Choosing shapes for the rows that SHARE the chip (the batcher telling an engine
+//                        what runs beside its batch) was measured in the same call and adds nothing: removed.
 //   loaders         1    the small-batch 3x3 shape with fetching waves (0: the 4-wave shapes of conv_kernel.h)
 //   loaders_depth   1    its fetch depth: slabs six steps / images two chunks ahead (0: three / one); 16.94 -> 16.47 us per 3x3 launch at
 //                        batch 1, a pass 1.93 -> 1.88 ms (profiles/r04_steps/small_batch/depth_scan.txt)
@@ -82,7 +87,7 @@ constexpr int CFG_REGW_HALF = 125;   // cfg 128's cell tiles over TWO work-group
 //                        a row pointer (conv_small_kernel.h chunkBody). Fixed in the kernel, guarded by
 //                        tools/check_async_loads.py (tests/test_async_loads.py) and tests/test_gpu_selfplay_production.py.
 struct ConvTune {
-  int minWgs8 = 150, loaders = 1, loadersDepth = 1, loadersSplit = 1, loadersMaxWgs = 256, packedMaxWgs = 512, deep1x1 = 1, deep1x1MaxWgs = 256,
+  int minWgs8 = 129, loaders = 1, loadersDepth = 1, loadersSplit = 1, loadersMaxWgs = 256, packedMaxWgs = 512, deep1x1 = 1, deep1x1MaxWgs = 256,
       split1x1 = 1, regw = 3, regw64MaxWgs = 256, regwHalf = 1;
   std::string error;  // non-empty: KMX_CONV_TUNE could not be parsed (an unknown key)
 };

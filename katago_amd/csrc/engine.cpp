@@ -986,7 +986,7 @@ void Engine::runSchedule(int n, const float* dSpatial, const unsigned char* dPac
     if(useGraphs_ && forkAt <= 0) {
       GraphKey key;
       key.n = n;
-      key.scale = shapeRows(n);  // (what the shapes were chosen for: the batch, its concurrent parts and the rows beside it)
+      key.scale = cfgScale_;
       const void* ptrs[8] = {dSpatial, dPacked, dGlobal, dMeta, dPolicy, dValue, dScore, dOwnership};
       for(int i = 0; i < 8; i++) key.p[i] = ptrs[i];
       auto it = graphCache_.find(key);

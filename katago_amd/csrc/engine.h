@@ -121,11 +121,7 @@ class Engine {
   // The convolution work-group shape is chosen for `rows * scale` boards: a handle that runs two engines side by side
   // on two streams sets 2, so that each half still uses the 8-wave shape (the other half fills the rest of the chip).
   void setConcurrency(int scale) { cfgScale_ = scale < 1 ? 1 : scale; }
-  // rows of OTHER batches that are on the device while this engine's next pass runs (the leaf batcher's small batches side by side): the
-  // work-group shapes are chosen for the boards that share the chip, not for this pass's alone (conv_mfma.hip chooseConvCfg takes
-  // "boards x concurrent streams"). Every shape gives the same bits, so this moves time only.
-  void setRowsBeside(int rows) { rowsBeside_ = rows < 0 ? 0 : rows; }
-  int shapeRows(int n) const { return n * cfgScale_ + rowsBeside_; }
+  int shapeRows(int n) const { return n * cfgScale_; }  // what the work-group shapes are chosen for: the boards of all concurrent parts
   // Other engines' passes run on the same device at the same time (the batcher's batches in flight): kernels that exist in a
   // "chip to itself" and a "side by side" form (the seam, kernels.h PwPairArgs::alone) take the latter.
   void setSharesDevice(bool shares) { sharesDevice_ = shares; }
@@ -219,7 +215,6 @@ class Engine {
   int stagingSlot_ = 0;
   bool hostAnyOwner_ = false;
   int cfgScale_ = 1;
-  int rowsBeside_ = 0;
   bool sharesDevice_ = false;
   bool fuseSeams_ = true;   // KMX_FUSE_SEAMS=0: always the two convolution launches
   bool packInputs_ = false;  // KMX_PACK_INPUTS=1: kmx_eval bit-packs 0/1 planes while staging. Off: measured on MI355X (b18c384nbt, batch 256,
