@@ -79,6 +79,7 @@ class Batcher {
       }
       else sealAt_ = maxBatch;
       if(const char* e = getenv("KMX_BATCH_LINGER_US")) lingerUs_ = atoi(e) < 0 ? 0 : atoi(e);
+      if(const char* e = getenv("KMX_BATCH_LINGER_BIG_US")) lingerBigUs_ = atoi(e) < 0 ? 0 : atoi(e);
       // fault triage: one line per launched batch on stderr (slot, rows, what else is on the device) - the last lines before a device
       // fault name the batch sizes that were in flight (bench.py keeps them when the self-play leg dies)
       if(const char* e = getenv("KMX_BATCH_TRACE")) trace_ = atoi(e) != 0;
@@ -278,11 +279,20 @@ class Batcher {
       // 11.9 k with eight). While fewer rows wait than the last delivered batch held, the dispatcher waits up to lingerUs_ more
       // (KMX_BATCH_LINGER_US, default 150; 0 = the reference's pure greedy rule, threadsafequeue.h:173-189) - at most once per batch,
       // 5 % of a pass.
-      if(!closing_ && sealed_.empty() && filling_ >= 0 && lingerUs_ > 0 && slots_[filling_].count < lastBatchRows_ &&
+      // Round 6: the linger is longer where batches are large. With ~256 leaves in flight (BASELINE configs[1] as written: `benchmark -t 256`;
+      // self-play at 32 games x 8 leaves) two batches of ~115-135 rows alternate and each pass costs 4 ms: waiting up to lingerBigUs_ (default
+      // 800 us; KMX_BATCH_LINGER_BIG_US) for a batch as large as the last one, once that held at least LINGER_BIG_ROWS rows, lets the batches
+      // grow to 140-190 rows. Measured, two runs each, one box (profiles/r06_steps/midbatch/linger2.txt): `benchmark -v 1600 -t 256` 27.7 k
+      // nnEvals/s without, 30.5 k at 600 us, 29.9 k at 1000 and 1500; self-play at 32 x 8 28.0 k NN rows/s without, 29.1 k at 600, 29.6 k at
+      // 1000, 29.5 k at 1500; nothing changes at 8 x 8 (batches of ~27 rows never qualify: 22.0-22.6 k either way) nor on long searches with
+      // 1024 leaves (batches seal full). With 100 games x 1 leaf (batches of ~42 rows, a few above 64) a threshold of 64 rows cost 6 %
+      // (25.5 -> 24.0 k): the threshold is 96.
+      const int lingerNow = lastBatchRows_ >= LINGER_BIG_ROWS ? std::max(lingerUs_, lingerBigUs_) : lingerUs_;
+      if(!closing_ && sealed_.empty() && filling_ >= 0 && lingerNow > 0 && slots_[filling_].count < lastBatchRows_ &&
          slots_[filling_].count < sealAt_)
       {
         const int f = filling_;
-        cvWork_.wait_for(l, std::chrono::microseconds(lingerUs_), [&] {
+        cvWork_.wait_for(l, std::chrono::microseconds(lingerNow), [&] {
           return closing_ || !sealed_.empty() || filling_ != f || slots_[f].count >= lastBatchRows_ || slots_[f].count >= sealAt_;
         });
         if(!closing_ && sealed_.empty() && filling_ < 0) continue;  // (cannot happen: only this thread seals a partial batch)
@@ -415,6 +425,8 @@ class Batcher {
   int rowsOnDevice_ = 0;                    // rows of the batches between launch and completion
   int lastBatchRows_ = 0;                   // rows of the batch delivered last: what a partial batch is expected to grow to
   int lingerUs_ = 150;
+  int lingerBigUs_ = 800;                   // ... once the last delivered batch held at least LINGER_BIG_ROWS rows
+  static constexpr int LINGER_BIG_ROWS = 96;
   static constexpr int SMALL_ROWS = 96;     // partial batches may run side by side while the device holds at most this many rows
   bool closing_ = false;
   bool trace_ = false;
