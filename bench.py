@@ -509,6 +509,16 @@ def main():
         ms_, tf_, mhz_ = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         if lib.kmx_bench_mfma(8, 256, 3, 540, 10, ctypes.byref(ms_), ctypes.byref(tf_), ctypes.byref(mhz_)) == 0:
             box = {"mfma_lds_barrier_loop_tflops": round(tf_.value, 1), "shader_mhz_during_it": round(mhz_.value)}
+        # Round 6: what the matrix cores SUSTAIN on operands that look like the convolution's (uniform noise) - the chip clocks down under
+        # them whatever else a kernel does (tools/mfma_power_probe.py): the bare chain of MFMAs and the convolution's step shape,
+        # in the pass's own precision, ~1.2 s each (the power controller needs tens of ms to settle; the 4 ms loop above runs at the clock
+        # the passes left the chip at).
+        if box is not None and world == 1:
+            prec = capi.PREC_FP16 if dtype == "fp16" else capi.PREC_BF16
+            for key, shape in (("mfma_chain", 0), ("mfma_lds_barrier_loop", 1)):
+                if lib.kmx_bench_mfma_sustained(256, shape, 2, prec, 1.2, ctypes.byref(tf_), ctypes.byref(mhz_)) == 0:
+                    box[key + "_sustained_on_noise_operands_tflops"] = round(tf_.value, 1)
+                    box[key + "_sustained_on_noise_operands_mhz"] = round(mhz_.value)
 
     roofline = None
     if prof_entries:
@@ -524,6 +534,12 @@ def main():
                     "flops_per_launch": flops / launches, "algorithmic_bytes_per_launch": nbytes / launches,
                     "kernel_time_share": {k: round(v[1] / total_ms, 4) for k, v in prof_entries.items()},
                     "kernel_avg_launch_us": {k: round(v[1] / max(v[0], 1) * 1e3, 2) for k, v in prof_entries.items()}}
+        sustained = (box or {}).get("mfma_chain_sustained_on_noise_operands_tflops")
+        if sustained:
+            # `peak` stays the nominal dense figure (256 CUs x 2.4 GHz); this is the same `achieved` against what a kernel of nothing but
+            # MFMAs sustains on this box, on noise-like operands, in this precision
+            roofline["sustained_mfma_only_on_noise_operands_tflops"] = sustained
+            roofline["frac_of_sustained"] = round(achieved / sustained, 4)
 
     roofline_seam = None
     if prof_entries and prof_entries.get("conv1x1_pair", (0, 0, 0, 0))[0] > 0:

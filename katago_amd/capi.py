@@ -144,6 +144,7 @@ TUNING_SIGNATURES = {
     "kmx_debug_conv_cfg": (ctypes.c_int, [ctypes.c_int] * 3 + [_IP, _IP]),
     "kmx_bench_mfma": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_double)] * 3),
     "kmx_bench_launch_floor": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_double)]),
+    "kmx_bench_mfma_sustained": (ctypes.c_int, [ctypes.c_int] * 4 + [ctypes.c_double] + [ctypes.POINTER(ctypes.c_double)] * 2),
 }
 
 _lib = None

@@ -581,6 +581,125 @@ double benchMfma(int wavesPerWg, int wgs, int mode, int steps, int iters, double
 }
 
 
+// ---- what the matrix cores SUSTAIN, by operand data (kmx_bench_mfma_sustained; tools/mfma_power_probe.py; round 6) ----
+// mfmaPeakKernel above multiplies a smooth ramp of small positive numbers and holds 2.38 GHz on the whole chip; the convolution's operands
+// look like noise, and the chip clocks down under them whatever else the kernel does. This one runs the same two loops - the bare chain of
+// 18 MFMAs on a 3 x 3 tile of accumulators, and the convolution's step shape (+ 12 ds_read_b128 + one s_barrier per step) - for SECONDS (the
+// power controller needs tens of milliseconds to settle) on operands of a chosen kind: 0 zeros, 1 the smooth ramp, 2 uniform noise in
+// [-1, 1). 8 waves per work-group, two per SIMD.
+namespace {
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float operandValue(int kind, unsigned i) {
+  if(kind == 0) return 0.0f;
+  if(kind == 1) return 0.001f * (float)(i & 255);
+  return (float)(int)(hash32(i) >> 8) * (1.0f / 8388608.0f) - 1.0f;
+}
+template <class TR, bool LDS>
+__global__ __launch_bounds__(512) void mfmaSustainedKernel(int steps, int kind, unsigned long long* clocks, float* sink) {
+  extern __shared__ __attribute__((aligned(256))) char smemSus[];
+  typedef typename TR::V8 V8;
+  typedef typename TR::T T;
+  const int lane = threadIdx.x & 63;
+  f32x16 acc[9];
+#pragma unroll
+  for(int i = 0; i < 9; i++)
+#pragma unroll
+    for(int r = 0; r < 16; r++) acc[i][r] = 0.0f;
+  V8 wf[2][3], af[2][3];
+#pragma unroll
+  for(int kk = 0; kk < 2; kk++)
+#pragma unroll
+    for(int j = 0; j < 3; j++)
+#pragma unroll
+      for(int i = 0; i < 8; i++) {
+        wf[kk][j][i] = TR::fromFloat(operandValue(kind, (unsigned)(threadIdx.x * 64 + kk * 24 + j * 8 + i)));
+        af[kk][j][i] = TR::fromFloat(operandValue(kind, (unsigned)(threadIdx.x * 64 + 4096 * 64 + kk * 24 + j * 8 + i)));
+      }
+  if(LDS) {
+    for(int i = threadIdx.x; i < 32768; i += blockDim.x) ((T*)smemSus)[i] = TR::fromFloat(operandValue(kind, (unsigned)i * 2654435761u + blockIdx.x));
+    __syncthreads();
+  }
+  const unsigned long long c0 = clock64(), w0 = wall_clock64();
+  for(int s = 0; s < steps; s++) {
+    if(LDS) {
+      const char* base = smemSus + ((s & 3) * 8192) + (lane & 31) * 64 + ((((lane >> 5)) ^ ((lane >> 2) & 3)) << 4);
+#pragma unroll
+      for(int kk = 0; kk < 2; kk++)
+#pragma unroll
+        for(int j = 0; j < 3; j++) {
+          wf[kk][j] = *(const V8*)(base + j * 2048 + kk * 32);
+          af[kk][j] = *(const V8*)(base + 6144 + j * 2048 + (kk * 32) % 2048);
+        }
+    }
+#pragma unroll
+    for(int kk = 0; kk < 2; kk++)
+#pragma unroll
+      for(int ct = 0; ct < 3; ct++)
+#pragma unroll
+        for(int pt = 0; pt < 3; pt++) acc[ct * 3 + pt] = TR::mfma(wf[kk][ct], af[kk][pt], acc[ct * 3 + pt]);
+    if(LDS) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  }
+  const unsigned long long c1 = clock64(), w1 = wall_clock64();
+  float t = 0.0f;
+#pragma unroll
+  for(int i = 0; i < 9; i++)
+#pragma unroll
+    for(int r = 0; r < 16; r++) t += acc[i][r];
+  if(t == 12345.678f) sink[lane] = t;
+  if(blockIdx.x == 0 && threadIdx.x == 0) {
+    clocks[0] = c1 - c0;
+    clocks[1] = w1 - w0;
+  }
+}
+}  // namespace
+// returns the seconds it ran; *tflops over the whole run, *coreMhz inside the last launch
+double benchMfmaSustained(int wgs, int shape, int kind, int dtype, double seconds, double* tflops, double* coreMhz) {
+  DevBuf clk(16), sink(1024);
+  const int steps = 540;
+  void (*kern)(int, int, unsigned long long*, float*) =
+    dtype == DT_F16 ? (shape ? mfmaSustainedKernel<TraitsF16, true> : mfmaSustainedKernel<TraitsF16, false>)
+                    : (shape ? mfmaSustainedKernel<TraitsBF16, true> : mfmaSustainedKernel<TraitsBF16, false>);
+  hipCheck(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "lds attribute");
+  hipStream_t st;
+  hipCheck(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "stream");
+  auto launch = [&](int n) {
+    for(int i = 0; i < n; i++) hipLaunchKernelGGL(kern, dim3(wgs), dim3(512), 65536, st, steps, kind, clk.as<unsigned long long>(), sink.as<float>());
+    hipCheck(hipGetLastError(), "sustained mfma launch");
+  };
+  hipEvent_t e0, e1;
+  hipCheck(hipEventCreate(&e0), "event");
+  hipCheck(hipEventCreate(&e1), "event");
+  launch(10);
+  hipCheck(hipEventRecord(e0, st), "record");
+  launch(40);
+  hipCheck(hipEventRecord(e1, st), "record");
+  hipCheck(hipStreamSynchronize(st), "sync");
+  float ms = 0;
+  hipCheck(hipEventElapsedTime(&ms, e0, e1), "elapsed");
+  int iters = (int)(seconds * 1e3 / ((double)ms / 40.0));
+  if(iters < 1) iters = 1;
+  if(iters > 200000) iters = 200000;
+  hipCheck(hipEventRecord(e0, st), "record");
+  launch(iters);
+  hipCheck(hipEventRecord(e1, st), "record");
+  hipCheck(hipStreamSynchronize(st), "sync");
+  hipCheck(hipEventElapsedTime(&ms, e0, e1), "elapsed");
+  unsigned long long h[2] = {0, 0};
+  hipCheck(hipMemcpy(h, clk.get(), 16, hipMemcpyDeviceToHost), "copy clocks");
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipStreamDestroy(st);
+  if(tflops) *tflops = 18.0 * 32768.0 * steps * 8.0 * (double)wgs * iters / ((double)ms * 1e-3) / 1e12;
+  if(coreMhz) *coreMhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
+  return (double)ms * 1e-3;
+}
+
 // ---- what a dependent launch costs before it does anything (kmx_bench_launch_floor; tools/launch_floor.py) ----
 // A small pass is ~122 dependent launches of 11-17 us; the loops in them are a third of that. This measures the floor under a launch of
 // the small-batch shapes' geometry: `launches` dependent launches of a kernel of 512 threads and `ldsBytes` of LDS on `wgs` work-groups,

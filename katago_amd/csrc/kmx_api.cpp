@@ -22,6 +22,7 @@ double benchConvStreams(int ks, int cfg, int cin, int cout, int batch, int nStre
 double benchSeam(int batch, int iters, int timing);  // conv_bench.hip
 double benchConvChain(int batch, int nConv, int chained, int iters, int timing);  // conv_bench.hip
 double benchMfma(int wavesPerWg, int wgs, int mode, int steps, int iters, double* tflops, double* coreMhz);       // conv_bench.hip
+double benchMfmaSustained(int wgs, int shape, int kind, int dtype, double seconds, double* tflops, double* coreMhz);                  // conv_bench.hip
 double benchLaunchFloor(int wgs, int ldsBytes, int mode, int launches, int iters);                                 // conv_bench.hip
 }
 
@@ -530,6 +531,16 @@ int kmx_bench_mfma(int waves_per_wg, int wgs, int mode, int steps, int iters, do
       throw Error(KMX_ERR_INVALID_ARG, "kmx_bench_mfma: bad argument");
     (void)deviceCountOrThrow();
     *avg_ms = benchMfma(waves_per_wg, wgs, mode, steps, iters, tflops, core_mhz);
+  });
+}
+
+int kmx_bench_mfma_sustained(int wgs, int shape, int data_kind, int precision_mode, double seconds, double* tflops, double* core_mhz) {
+  return guarded([&] {
+    if(!tflops || wgs < 1 || wgs > 65536 || shape < 0 || shape > 1 || data_kind < 0 || data_kind > 2 || !(seconds > 0.0) || seconds > 30.0 ||
+       (precision_mode != KMX_PREC_FP16 && precision_mode != KMX_PREC_BF16))
+      throw Error(KMX_ERR_INVALID_ARG, "kmx_bench_mfma_sustained: bad argument");
+    (void)deviceCountOrThrow();
+    (void)benchMfmaSustained(wgs, shape, data_kind, dtypeForPrecision(precision_mode), seconds, tflops, core_mhz);
   });
 }
 

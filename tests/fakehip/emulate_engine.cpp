@@ -29,6 +29,7 @@ double benchConv(int, int, int, int, int, int, int, int, int, int) { return 0.0;
 double benchConvStreams(int, int, int, int, int, int, double, int, int) { return 0.0; }
 double benchMfma(int, int, int, int, int, double*, double*) { return 0.0; }
 double benchLaunchFloor(int, int, int, int, int) { return 0.0; }
+double benchMfmaSustained(int, int, int, int, double, double*, double*) { return 0.0; }
 double benchSeam(int, int, int) { return 0.0; }
 double benchConvChain(int, int, int, int, int) { return 0.0; }
 hipError_t launchLdsSquatter(int, int, int, unsigned*, hipStream_t) { return 801; }  // (device-only triage tool)
