@@ -50,6 +50,13 @@ def _check_line(d, steps, warmup):
     q = d["roofline_seam"]
     assert q["bound"] == "hbm" and q["unit"] == "GB/s" and q["peak"] == 8000.0 and 0.05 < q["frac"] < 1.0
     assert abs(q["achieved"] - q["algorithmic_bytes_per_launch"] / (q["avg_launch_ms"] * 1e-3) / 1e9) / q["achieved"] < 0.01
+    # round 6: what an MFMA-only kernel sustains on noise-like operands on this box, measured by the run; the convolution sits below it,
+    # and it sits below the nominal peak
+    box = d["box"]
+    sus = box["mfma_chain_sustained_on_noise_operands_tflops"]
+    assert 500 < box["mfma_lds_barrier_loop_sustained_on_noise_operands_tflops"] <= sus * 1.02 and sus < r["peak"]
+    assert r["sustained_mfma_only_on_noise_operands_tflops"] == sus and abs(r["frac_of_sustained"] - r["achieved"] / sus) < 1e-3
+    assert r["frac"] < r["frac_of_sustained"] < 1.0
 
 
 def test_driver_command_exits_zero_with_roofline_and_cpu_baseline():
@@ -89,6 +96,25 @@ def test_driver_command_repeated_fresh_processes(rep):
 def test_default_command_runs():
     d = _run_bench(["--no-cpu-baseline"])
     _check_line(d, d["steps"], d["warmup"])
+
+
+def test_sustained_mfma_rate_depends_on_the_operands():
+    """kmx_bench_mfma_sustained (round 6): the same chain of MFMAs sustains less on uniform noise than on a smooth ramp - the chip clocks
+    down by what the multipliers toggle - and the convolution's step shape (LDS reads + barrier) less than the bare chain."""
+    lib = capi.load_library()
+    tf, mhz = ctypes.c_double(), ctypes.c_double()
+
+    def rate(shape, kind, prec=capi.PREC_FP16, wgs=256):
+        capi.check(lib.kmx_bench_mfma_sustained(wgs, shape, kind, prec, 1.0, ctypes.byref(tf), ctypes.byref(mhz)), lib)
+        return tf.value, mhz.value
+
+    ramp, ramp_mhz = rate(0, 1)
+    noise, noise_mhz = rate(0, 2)
+    step, _ = rate(1, 2)
+    half, half_mhz = rate(0, 2, wgs=128)
+    assert 1000 < noise < 0.9 * ramp < 2500 and noise_mhz < ramp_mhz, (ramp, ramp_mhz, noise, noise_mhz)
+    assert step < noise * 1.02, (step, noise)
+    assert half_mhz > noise_mhz and half > 0.55 * noise, (half, half_mhz, noise, noise_mhz)  # half the chip is not throttled
 
 
 @pytest.fixture(scope="module")
