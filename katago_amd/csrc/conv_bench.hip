@@ -597,7 +597,10 @@ __device__ __forceinline__ float operandValue(int kind, unsigned i) {
   if(kind == 1) return 0.001f * (float)(i & 255);
   return (float)(int)(hash32(i) >> 8) * (1.0f / 8388608.0f) - 1.0f;
 }
-template <class TR, bool LDS>
+// ORDER: in which order a k half's nine MFMAs go out - 0: weight fragment outer, image fragment inner (the convolution's order: the weight
+// operand stays for three MFMAs, at every fourth both operands change); 1: the same as a snake (exactly one operand changes between any two
+// consecutive MFMAs of a k half); 2: image fragment outer. Same accumulators, same K order per accumulator: the sums do not depend on it.
+template <class TR, bool LDS, int ORDER>
 __global__ __launch_bounds__(512) void mfmaSustainedKernel(int steps, int kind, unsigned long long* clocks, float* sink) {
   extern __shared__ __attribute__((aligned(256))) char smemSus[];
   typedef typename TR::V8 V8;
@@ -637,9 +640,14 @@ __global__ __launch_bounds__(512) void mfmaSustainedKernel(int steps, int kind, 
 #pragma unroll
     for(int kk = 0; kk < 2; kk++)
 #pragma unroll
-      for(int ct = 0; ct < 3; ct++)
+      for(int i = 0; i < 3; i++)
 #pragma unroll
-        for(int pt = 0; pt < 3; pt++) acc[ct * 3 + pt] = TR::mfma(wf[kk][ct], af[kk][pt], acc[ct * 3 + pt]);
+        for(int j = 0; j < 3; j++) {
+          const int ct = ORDER == 2 ? j : i;
+          const int pt = ORDER == 2 ? i : (ORDER == 1 && (i & 1)) ? 2 - j : j;
+          acc[ct * 3 + pt] = TR::mfma(wf[kk][ct], af[kk][pt], acc[ct * 3 + pt]);
+          __builtin_amdgcn_sched_barrier(0);  // the order written is the order issued
+        }
     if(LDS) {
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -658,13 +666,16 @@ __global__ __launch_bounds__(512) void mfmaSustainedKernel(int steps, int kind, 
   }
 }
 }  // namespace
-// returns the seconds it ran; *tflops over the whole run, *coreMhz inside the last launch
+// shape: bit 0 the step shape (LDS reads + barrier) instead of the bare chain, bits 1-2 the ORDER above. Returns the seconds it ran; *tflops over the whole run, *coreMhz inside the last launch
 double benchMfmaSustained(int wgs, int shape, int kind, int dtype, double seconds, double* tflops, double* coreMhz) {
   DevBuf clk(16), sink(1024);
   const int steps = 540;
-  void (*kern)(int, int, unsigned long long*, float*) =
-    dtype == DT_F16 ? (shape ? mfmaSustainedKernel<TraitsF16, true> : mfmaSustainedKernel<TraitsF16, false>)
-                    : (shape ? mfmaSustainedKernel<TraitsBF16, true> : mfmaSustainedKernel<TraitsBF16, false>);
+  void (*kern)(int, int, unsigned long long*, float*) = nullptr;
+#define KMX_SUS(TR_, L_, O_) if(dtype == TR_::DT && (shape & 1) == (L_ ? 1 : 0) && (shape >> 1) == O_) kern = mfmaSustainedKernel<TR_, L_, O_>;
+  KMX_SUS(TraitsF16, false, 0) KMX_SUS(TraitsF16, true, 0) KMX_SUS(TraitsBF16, false, 0) KMX_SUS(TraitsBF16, true, 0)
+  KMX_SUS(TraitsF16, false, 1) KMX_SUS(TraitsF16, true, 1) KMX_SUS(TraitsF16, false, 2) KMX_SUS(TraitsF16, true, 2)
+#undef KMX_SUS
+  if(kern == nullptr) throw Error(KMX_ERR_INVALID_ARG, "kmx_bench_mfma_sustained: no such loop (the issue orders 1 and 2 exist for fp16 only)");
   hipCheck(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), "lds attribute");
   hipStream_t st;
   hipCheck(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "stream");

@@ -572,7 +572,9 @@ print("RESULT " + json.dumps({"ok": ok, "bad": bad}))
     p = subprocess.run([sys.executable, "-c", code, emu_lib], capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "RESULT " in p.stdout, (p.stdout + p.stderr)[-3000:]
     res = json.loads(p.stdout.split("RESULT ")[1])
-    assert sorted(res["ok"]["ms_per_pass"]) == ["1", "8"] and all(v > 0 for v in res["ok"]["rows_per_s"].values()), res  # 32 > 12 rows: skipped
+    # 32 > 12 rows: skipped. (rows_per_s is an integer: an emulated pass on a loaded machine takes seconds and rounds to 0 - the times say it ran)
+    assert sorted(res["ok"]["ms_per_pass"]) == ["1", "8"] and all(v > 0 for v in res["ok"]["ms_per_pass"].values()), res
+    assert sorted(res["ok"]["rows_per_s"]) == ["1", "8"] and all(v >= 0 for v in res["ok"]["rows_per_s"].values()), res
     assert "small_batches_error" in res["bad"], res
 
 
