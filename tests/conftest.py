@@ -39,6 +39,35 @@ def _built():
     subprocess.run(["make", "-s", "-C", os.path.join(REPO, "oracle"), "oracle"], check=True)
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _model_files_written_once(tmp_path_factory):
+    """A random-weight model file is a pure function of (architecture, seed, options, file format): the second test that asks for the
+    same one gets a copy of the first's file instead of 7 s (b18c384nbt) or 20 s (b28c512nbt) of gzip - a minute and a half of the GPU
+    suite, which the driver stops at 20 minutes."""
+    import json
+    import shutil
+
+    from katago_amd import modelgen
+
+    real, kept = modelgen.write_model, {}
+    store = str(tmp_path_factory.mktemp("kmx_model_files"))
+
+    def write_model(path, arch, *args, **kw):
+        if args:
+            return real(path, arch, *args, **kw)
+        suffix = next(s for s in (".bin.gz", ".txt.gz", ".bin", ".txt", "") if path.endswith(s))
+        key = json.dumps([arch, suffix, sorted(kw.items())], sort_keys=True, default=str)
+        if key not in kept:
+            made = os.path.join(store, "%d%s" % (len(kept), suffix))
+            kept[key] = (made, real(made, arch, **kw))
+        shutil.copyfile(kept[key][0], path)
+        return dict(kept[key][1]) if isinstance(kept[key][1], dict) else kept[key][1]
+
+    modelgen.write_model = write_model
+    yield
+    modelgen.write_model = real
+
+
 @pytest.fixture(scope="session")
 def model_dir(tmp_path_factory):
     return str(tmp_path_factory.mktemp("kmx_models"))

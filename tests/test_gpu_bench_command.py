@@ -87,9 +87,10 @@ def test_traffic_is_measured_by_the_run_that_prints_it():
         assert t and "this run" in t["source"] and 0.9 < t["hbm_bytes_per_launch"] / r["algorithmic_bytes_per_launch"] < 2.0, t
 
 
-@pytest.mark.parametrize("rep", range(3))
+@pytest.mark.parametrize("rep", range(2))
 def test_driver_command_repeated_fresh_processes(rep):
-    """The round-1 fault was not deterministic: a few more fresh processes, without the CPU leg."""
+    """The round-1 fault was not deterministic: more fresh processes, without the CPU leg (with the full command above and the default
+    command below: four fresh bench processes per suite run)."""
     _check_line(_run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"]), 20, 5)
 
 

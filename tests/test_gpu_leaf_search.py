@@ -41,7 +41,8 @@ def test_search_driven_rate_reaches_the_device_rate(tmp_path):
     cfg = tmp_path / "bench.cfg"
     cfg.write_text(h.BENCH_CFG + "nnMaxBatchSize = 256\nnumNNServerThreadsPerModel = 2\n")
     # the device-resident rate of this box, same process layout as the driver's bench run
-    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--no-cpu-baseline", "--steps", "40", "--warmup", "5"],
+    # (only `value` is wanted: without --no-callers bench.py would play its whole self-play leg here, minutes of the suite's 20)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--no-cpu-baseline", "--no-callers", "--no-profile", "--steps", "40", "--warmup", "5"],
                        capture_output=True, text=True, timeout=600, cwd=REPO)
     assert r.returncode == 0, r.stderr[-2000:]
     device = json.loads(r.stdout.strip().splitlines()[-1])["value"]

@@ -45,7 +45,8 @@ NEAR_TIE = 2.0
     # measured on MI355X (profiles/r02/search_fixed_seed_*.txt): fp16 0.978 | 0.028, 0.0024 | 0.0045 | 1.8, 0.076 - the spread of the
     # reference's own fp16 golden; bf16 0.976 | 0.89 (one search flips), 0.015 | 0.020 | 9.3, 0.52
     ("auto", dict(searches=130, near_tie=NEAR_TIE, same_best=0.97, best_share_max=0.08, best_share_mean=0.01, tv_mean=0.015, root_util_max=4.0, root_util_mean=0.3)),
-    ("fp16", dict(searches=130, near_tie=NEAR_TIE, same_best=0.97, best_share_max=0.08, best_share_mean=0.01, tv_mean=0.015, root_util_max=4.0, root_util_mean=0.3)),
+    # ("auto" IS fp16 with the 1/8 range transform on this net, DESIGN.md 1: the explicit "fp16" case ran the same searches a second time -
+    # 21 s of a suite the driver stops at 20 minutes - and is not repeated; KATAMX_PRECISION=fp16 is covered by tests/test_gpu_reference_harness.py)
     ("bf16", dict(searches=115, same_best=0.95, best_share_max=1.0, best_share_mean=0.04, tv_mean=0.06, root_util_max=15.0, root_util_mean=1.5)),
     # fp32 on the device (round 5, KMX_PREC_FP32): no 16-bit rounding anywhere - held to the fp16 limits at most, figures in the record
     ("fp32", dict(searches=130, near_tie=NEAR_TIE, same_best=0.97, best_share_max=0.08, best_share_mean=0.01, tv_mean=0.015, root_util_max=4.0, root_util_mean=0.3)),
