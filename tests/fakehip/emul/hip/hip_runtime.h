@@ -4,8 +4,11 @@
 // dynamic LDS a static buffer, work-groups run one after the other. Only what those kernels use is provided.
 #pragma once
 #define KMX_EMULATED_HIP 1  // engine.cpp: no virtual-memory API here (its KMX_DEBUG_GUARD placement is a device-only triage mode)
-#include <condition_variable>
-#include <mutex>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+#include <atomic>
+#include <climits>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
@@ -79,37 +82,55 @@ inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms =
 
 namespace emu {
 struct Idx { unsigned x, y, z; };
-// A barrier whose participants may leave (a thread that returns from the kernel). Mutex + condition variable on purpose:
-// std::barrier of libstdc++ waits through a shared pool of atomics, which both costs a lot with hundreds of threads and
-// makes ThreadSanitizer see synchronisation between unrelated barriers.
+// A barrier whose participants may leave (a thread that returns from the kernel). One 64-bit word holds (expected, arrived), so
+// exactly one arrival or departure completes a phase; waiters sleep on the phase word through the futex system call directly - a mutex +
+// condition variable makes every one of hundreds of woken lanes queue for the mutex again (two thirds of the CPU suite's time was system
+// time), and std::barrier of libstdc++ waits through a shared pool of atomics, which costs a lot with hundreds of threads and makes
+// ThreadSanitizer see synchronisation between unrelated barriers. ThreadSanitizer sees this one through its acquire / release atomics.
 class Barrier {
  public:
-  explicit Barrier(unsigned n) : expected_(n) {}
+  explicit Barrier(unsigned n) : state_((uint64_t)n << 32) {}
+  void reset(unsigned n) { state_.store((uint64_t)n << 32, std::memory_order_release); }  // (only while nobody uses it)
   void arrive_and_wait() {
-    std::unique_lock<std::mutex> l(m_);
-    const unsigned ph = phase_;
-    if(++arrived_ == expected_) release();
-    else cv_.wait(l, [&] { return phase_ != ph; });
+    const uint32_t ph = phase_.load(std::memory_order_acquire);
+    uint64_t s = state_.load(std::memory_order_relaxed);
+    for(;;) {
+      const uint32_t expected = (uint32_t)(s >> 32), arrived = (uint32_t)s + 1;
+      const bool last = arrived == expected;
+      if(state_.compare_exchange_weak(s, last ? (uint64_t)expected << 32 : s + 1, std::memory_order_acq_rel, std::memory_order_relaxed)) {
+        if(last) release();
+        else
+          while(phase_.load(std::memory_order_acquire) == ph) syscall(SYS_futex, (uint32_t*)&phase_, FUTEX_WAIT_PRIVATE, ph, nullptr, nullptr, 0);
+        return;
+      }
+    }
   }
   void arrive_and_drop() {
-    std::lock_guard<std::mutex> l(m_);
-    --expected_;
-    if(expected_ > 0 && arrived_ == expected_) release();
+    uint64_t s = state_.load(std::memory_order_relaxed);
+    for(;;) {
+      const uint32_t expected = (uint32_t)(s >> 32) - 1, arrived = (uint32_t)s;
+      const bool last = expected > 0 && arrived == expected;
+      if(state_.compare_exchange_weak(s, (uint64_t)expected << 32 | (last ? 0u : arrived), std::memory_order_acq_rel, std::memory_order_relaxed)) {
+        if(last) release();
+        return;
+      }
+    }
   }
 
  private:
-  void release() {
-    arrived_ = 0;
-    ++phase_;
-    cv_.notify_all();
+  void release() {  // (nobody can arrive for the next phase before the phase word moves: everyone else is asleep on it or gone)
+    phase_.fetch_add(1, std::memory_order_release);
+    syscall(SYS_futex, (uint32_t*)&phase_, FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
   }
-  std::mutex m_;
-  std::condition_variable cv_;
-  unsigned expected_, arrived_ = 0, phase_ = 0;
+  std::atomic<uint64_t> state_;  // expected << 32 | arrived
+  std::atomic<uint32_t> phase_{0};
 };
+// The exchange arrays of a wave's collectives (MFMA operands, shuffles) exist twice and a lane counts its collectives (waveOp): collective
+// k writes set k % 2, meets the wave's barrier ONCE and reads. A lane can only write set k % 2 again (collective k + 2) after the barrier of
+// collective k + 1, at which every lane has arrived with its reads of collective k behind it - so no second barrier per collective.
 struct Wave {
-  float buf[64];
-  float opA[64][8], opB[64][8];
+  float buf[2][64];
+  float opA[2][64][8], opB[2][64][8];
   std::unique_ptr<Barrier> bar;
 };
 struct Block {
@@ -119,6 +140,7 @@ struct Block {
 extern thread_local Idx tIdx, bIdx, bDim, gDim;
 extern thread_local Block* cur;
 extern thread_local bool dropped;
+extern thread_local unsigned waveOp;  // collectives this lane has taken part in (all lanes of a wave execute the same sequence)
 void* dynLds();
 void launchImpl(dim3 grid, dim3 block, const std::function<void()>& body);
 }  // namespace emu
@@ -153,20 +175,21 @@ namespace emu {
 template <class V8, class F16>
 inline F16 mfma16(V8 a, V8 b, F16 c) {
   Wave& w = cur->waves[tIdx.x >> 6];
-  const unsigned lane = tIdx.x & 63;
+  const unsigned lane = tIdx.x & 63, set = waveOp++ & 1;
+  float(*const opA)[8] = w.opA[set];
+  float(*const opB)[8] = w.opB[set];
   for(int i = 0; i < 8; i++) {
-    w.opA[lane][i] = (float)a[i];
-    w.opB[lane][i] = (float)b[i];
+    opA[lane][i] = (float)a[i];
+    opB[lane][i] = (float)b[i];
   }
   w.bar->arrive_and_wait();
   const unsigned col = lane & 31, half = lane >> 5;
   for(int v = 0; v < 16; v++) {
     const unsigned row = (v / 4) * 8 + half * 4 + (v % 4);
     float sum = 0.0f;
-    for(int k = 0; k < 16; k++) sum += w.opA[row + 32 * (k / 8)][k % 8] * w.opB[col + 32 * (k / 8)][k % 8];
+    for(int k = 0; k < 16; k++) sum += opA[row + 32 * (k / 8)][k % 8] * opB[col + 32 * (k / 8)][k % 8];
     c[v] += sum;
   }
-  w.bar->arrive_and_wait();
   return c;
 }
 }  // namespace emu
@@ -275,33 +298,30 @@ struct Pair32 {
 };
 inline Pair32 permlane32Swap(unsigned a, unsigned b) {
   Wave& w = cur->waves[tIdx.x >> 6];
-  const unsigned lane = tIdx.x & 63;
+  const unsigned lane = tIdx.x & 63, set = waveOp++ & 1;
   unsigned ua, ub;
-  memcpy(&w.opA[lane][0], &a, 4);
-  memcpy(&w.opB[lane][0], &b, 4);
+  memcpy(&w.opA[set][lane][0], &a, 4);
+  memcpy(&w.opB[set][lane][0], &b, 4);
   w.bar->arrive_and_wait();
   Pair32 r;
   if(lane < 32) {
     r.v[0] = a;
-    memcpy(&ua, &w.opA[lane + 32][0], 4);
+    memcpy(&ua, &w.opA[set][lane + 32][0], 4);
     r.v[1] = ua;  // new second, lower half = old first, upper half
   }
   else {
-    memcpy(&ub, &w.opB[lane - 32][0], 4);
+    memcpy(&ub, &w.opB[set][lane - 32][0], 4);
     r.v[0] = ub;  // new first, upper half = old second, lower half
     r.v[1] = b;
   }
-  w.bar->arrive_and_wait();
   return r;
 }
 }  // namespace emu
 #define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) emu::permlane32Swap(a, b)
 inline float __shfl_xor(float v, int laneMask) {
   emu::Wave& w = emu::cur->waves[emu::tIdx.x >> 6];
-  const unsigned lane = emu::tIdx.x & 63;
-  w.buf[lane] = v;
+  const unsigned lane = emu::tIdx.x & 63, set = emu::waveOp++ & 1;
+  w.buf[set][lane] = v;
   w.bar->arrive_and_wait();
-  const float r = w.buf[lane ^ (unsigned)laneMask];
-  w.bar->arrive_and_wait();
-  return r;
+  return w.buf[set][lane ^ (unsigned)laneMask];
 }
