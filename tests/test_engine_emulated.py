@@ -157,23 +157,31 @@ def _tree_digest(paths, extra):
     return h.hexdigest()[:20]
 
 
-def build_emu_full(d, conv_mutations=(), pw2_mutations=(), chain_mutations=(), small_mutations=(), extra_flags=(), so_name="libkatamx_emufull.so", pw3_mutations=()):
+def build_emu_full(d, conv_mutations=(), pw2_mutations=(), chain_mutations=(), small_mutations=(), extra_flags=(), so_name="libkatamx_emufull.so", pw3_mutations=(),
+                   plain_pointers=False):
     """conv_mutations: further (pattern, replacement, count) rewrites of conv_kernel.h - deliberate defects for the tests of the
-    emulator's own teeth. extra_flags: compile AND link flags (tools/emulated_asan.sh: -fsanitize=address ...).
+    emulator's own teeth. extra_flags: compile AND link flags (tools/emulated_asan.sh: -fsanitize=address ...). plain_pointers: the
+    kernels' address_space(3) / (1) qualifiers dropped (tools/emulated_tsan.sh: sanitizers skip accesses through non-default address spaces).
     The build takes a minute and a half (conv_mfma.hip's instantiations) and several test files want the same one: a library is kept under
     $TMPDIR/kmx_emu_builds/<digest of every source, rewrite rule and flag> and built by whoever asks first; the others wait on its lock."""
     import fcntl
     import shutil
 
     key = _tree_digest([CSRC, FAKE], [CONV_REWRITES, PW_REWRITES, PW2_REWRITES, PW3_REWRITES, CHAIN_REWRITES, SMALL_REWRITES, list(conv_mutations),
-                                      list(pw2_mutations), list(chain_mutations), list(small_mutations), list(pw3_mutations), list(extra_flags), so_name])
+                                      list(pw2_mutations), list(chain_mutations), list(small_mutations), list(pw3_mutations), list(extra_flags), so_name, plain_pointers])
     keep = os.path.join(os.environ.get("TMPDIR", "/tmp"), "kmx_emu_builds", key)
     os.makedirs(keep, exist_ok=True)
     kept = os.path.join(keep, so_name)
     with open(os.path.join(keep, "lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not os.path.exists(kept):
-            built = _build_emu_full(d, conv_mutations, pw2_mutations, chain_mutations, small_mutations, extra_flags, so_name, pw3_mutations)
+            import time
+
+            for other in os.listdir(os.path.dirname(keep)):  # builds of sources that no longer exist: gone after three days
+                o = os.path.join(os.path.dirname(keep), other)
+                if other != key and os.path.isdir(o) and time.time() - os.path.getmtime(o) > 3 * 86400:
+                    shutil.rmtree(o, ignore_errors=True)
+            built = _build_emu_full(d, conv_mutations, pw2_mutations, chain_mutations, small_mutations, extra_flags, so_name, pw3_mutations, plain_pointers)
             shutil.copyfile(built, kept + ".part")
             os.replace(kept + ".part", kept)
     mine = os.path.join(d, so_name)  # (callers such as tools/emulated_asan.sh expect the library in the directory they named)
@@ -185,42 +193,47 @@ def build_emu_full(d, conv_mutations=(), pw2_mutations=(), chain_mutations=(), s
     return mine
 
 
-def _build_emu_full(d, conv_mutations, pw2_mutations, chain_mutations, small_mutations, extra_flags, so_name, pw3_mutations):
+def _build_emu_full(d, conv_mutations, pw2_mutations, chain_mutations, small_mutations, extra_flags, so_name, pw3_mutations, plain_pointers):
     import re
     import shutil
+
+    def put(name, text):
+        if plain_pointers:
+            text = text.replace("__attribute__((address_space(3)))", "").replace("__attribute__((address_space(1)))", "")
+        open(os.path.join(d, name), "w").write(text)
 
     src = open(os.path.join(CSRC, "conv_kernel.h")).read()
     for pat, rep, count in list(CONV_REWRITES) + list(conv_mutations):
         src, k = re.subn(pat, rep, src)
         assert k == count, "conv_kernel.h changed: %r matched %d times, expected %d" % (pat, k, count)
-    open(os.path.join(d, "conv_kernel.h"), "w").write(src)
+    put("conv_kernel.h", src)
     shutil.copy(os.path.join(CSRC, "conv_mfma.hip"), os.path.join(d, "conv_mfma.hip"))
     src = open(os.path.join(CSRC, "conv_chain_kernel.h")).read()
     for pat, rep, count in list(CHAIN_REWRITES) + list(chain_mutations):
         src, k = re.subn(pat, rep, src)
         assert k == count, "conv_chain_kernel.h changed: %r matched %d times, expected %d" % (pat, k, count)
-    open(os.path.join(d, "conv_chain_kernel.h"), "w").write(src)
+    put("conv_chain_kernel.h", src)
     shutil.copy(os.path.join(CSRC, "conv_chain.hip"), os.path.join(d, "conv_chain.hip"))
     src = open(os.path.join(CSRC, "conv_small_kernel.h")).read()
     for pat, rep, count in list(SMALL_REWRITES) + list(small_mutations):
         src, k = re.subn(pat, rep, src)
         assert k == count, "conv_small_kernel.h changed: %r matched %d times, expected %d" % (pat, k, count)
-    open(os.path.join(d, "conv_small_kernel.h"), "w").write(src)
+    put("conv_small_kernel.h", src)
     src = open(os.path.join(CSRC, "pointwise_kernel.h")).read()
     for pat, rep, count in PW_REWRITES:
         src, k = re.subn(pat, rep, src)
         assert k == count, "pointwise_kernel.h changed: %r matched %d times, expected %d" % (pat, k, count)
-    open(os.path.join(d, "pointwise_kernel.h"), "w").write(src)
+    put("pointwise_kernel.h", src)
     src = open(os.path.join(CSRC, "pointwise2_kernel.h")).read()
     for pat, rep, count in list(PW2_REWRITES) + list(pw2_mutations):
         src, k = re.subn(pat, rep, src)
         assert k == count, "pointwise2_kernel.h changed: %r matched %d times, expected %d" % (pat, k, count)
-    open(os.path.join(d, "pointwise2_kernel.h"), "w").write(src)
+    put("pointwise2_kernel.h", src)
     src = open(os.path.join(CSRC, "pointwise3_kernel.h")).read()
     for pat, rep, count in list(PW3_REWRITES) + list(pw3_mutations):
         src, k = re.subn(pat, rep, src)
         assert k == count, "pointwise3_kernel.h changed: %r matched %d times, expected %d" % (pat, k, count)
-    open(os.path.join(d, "pointwise3_kernel.h"), "w").write(src)
+    put("pointwise3_kernel.h", src)
     shutil.copy(os.path.join(CSRC, "pointwise.hip"), os.path.join(d, "pointwise.hip"))
     cxx = ["/opt/rocm/lib/llvm/bin/clang++", "-x", "c++", "-std=c++20", "-O2", "-fPIC", "-pthread", "-I" + os.path.join(FAKE, "emul"), "-I" + FAKE,
            "-I" + CSRC, "-DKMX_EMU_REAL_CONV"] + list(extra_flags)
