@@ -519,6 +519,11 @@ def main():
                 if lib.kmx_bench_mfma_sustained(256, shape, 2, prec, 1.2, ctypes.byref(tf_), ctypes.byref(mhz_)) == 0:
                     box[key + "_sustained_on_noise_operands_tflops"] = round(tf_.value, 1)
                     box[key + "_sustained_on_noise_operands_mhz"] = round(mhz_.value)
+            # ... and the bare chain on operands DISTRIBUTED like this bench's own (normal weights of a random-init 192-channel 3x3 layer x mish
+            # of a unit normal at 1/8, data kind 3): a little BELOW uniform noise on the boxes measured (1 555 against 1 679 TFLOP/s in fp16)
+            if lib.kmx_bench_mfma_sustained(256, 0, 3, prec, 1.2, ctypes.byref(tf_), ctypes.byref(mhz_)) == 0:
+                box["mfma_chain_sustained_on_net_like_operands_tflops"] = round(tf_.value, 1)
+                box["mfma_chain_sustained_on_net_like_operands_mhz"] = round(mhz_.value)
 
     roofline = None
     if prof_entries:
@@ -540,6 +545,9 @@ def main():
             # MFMAs sustains on this box, on noise-like operands, in this precision
             roofline["sustained_mfma_only_on_noise_operands_tflops"] = sustained
             roofline["frac_of_sustained"] = round(achieved / sustained, 4)
+        net_like = (box or {}).get("mfma_chain_sustained_on_net_like_operands_tflops")
+        if net_like:
+            roofline["frac_of_sustained_on_net_like_operands"] = round(achieved / net_like, 4)
 
     roofline_seam = None
     if prof_entries and prof_entries.get("conv1x1_pair", (0, 0, 0, 0))[0] > 0:

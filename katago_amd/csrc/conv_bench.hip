@@ -586,16 +586,22 @@ double benchMfma(int wavesPerWg, int wgs, int mode, int steps, int iters, double
 // look like noise, and the chip clocks down under them whatever else the kernel does. This one runs the same two loops - the bare chain of
 // 18 MFMAs on a 3 x 3 tile of accumulators, and the convolution's step shape (+ 12 ds_read_b128 + one s_barrier per step) - for SECONDS (the
 // power controller needs tens of milliseconds to settle) on operands of a chosen kind: 0 zeros, 1 the smooth ramp, 2 uniform noise in
-// [-1, 1). 8 waves per work-group, two per SIMD.
+// [-1, 1), 3 the distributions of the bench's own operands (normal weights of a random-init 192-channel 3x3 layer x mish of a unit normal at 1/8). 8 waves per work-group, two per SIMD.
 namespace {
 __device__ __forceinline__ unsigned hash32(unsigned x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return x;
 }
-__device__ __forceinline__ float operandValue(int kind, unsigned i) {
+__device__ __forceinline__ float operandValue(int kind, unsigned i, bool weight) {
   if(kind == 0) return 0.0f;
   if(kind == 1) return 0.001f * (float)(i & 255);
-  return (float)(int)(hash32(i) >> 8) * (1.0f / 8388608.0f) - 1.0f;
+  const float u = (float)(int)(hash32(i) >> 8) * (1.0f / 8388608.0f);  // [0, 2)
+  if(kind == 2) return u - 1.0f;
+  // kind 3: what the bench's convolutions multiply - weights N(0, 2 / (9 x 192)) (modelgen.py's random init of a 192 -> 192 3x3 layer), the
+  // image mish of a unit normal at 1/8 (the fp16 range transform): the values' DISTRIBUTION, not only their being non-constant
+  const float g = sqrtf(-2.0f * __logf(0.5f * u + 1e-7f)) * __cosf(6.2831853f * ((float)(hash32(i ^ 0x9e3779b9u) >> 8) * (1.0f / 16777216.0f)));
+  if(weight) return 0.034f * g;
+  return 0.125f * g * tanhf(log1pf(__expf(g)));
 }
 // ORDER: in which order a k half's nine MFMAs go out - 0: weight fragment outer, image fragment inner (the convolution's order: the weight
 // operand stays for three MFMAs, at every fourth both operands change); 1: the same as a snake (exactly one operand changes between any two
@@ -618,11 +624,12 @@ __global__ __launch_bounds__(512) void mfmaSustainedKernel(int steps, int kind, 
     for(int j = 0; j < 3; j++)
 #pragma unroll
       for(int i = 0; i < 8; i++) {
-        wf[kk][j][i] = TR::fromFloat(operandValue(kind, (unsigned)(threadIdx.x * 64 + kk * 24 + j * 8 + i)));
-        af[kk][j][i] = TR::fromFloat(operandValue(kind, (unsigned)(threadIdx.x * 64 + 4096 * 64 + kk * 24 + j * 8 + i)));
+        wf[kk][j][i] = TR::fromFloat(operandValue(kind, (unsigned)(threadIdx.x * 64 + kk * 24 + j * 8 + i), true));
+        af[kk][j][i] = TR::fromFloat(operandValue(kind, (unsigned)(threadIdx.x * 64 + 4096 * 64 + kk * 24 + j * 8 + i), false));
       }
   if(LDS) {
-    for(int i = threadIdx.x; i < 32768; i += blockDim.x) ((T*)smemSus)[i] = TR::fromFloat(operandValue(kind, (unsigned)i * 2654435761u + blockIdx.x));
+    for(int i = threadIdx.x; i < 32768; i += blockDim.x)  // (a step reads weight fragments from the first 6 KB of its 8 KB quarter, image fragments behind them)
+      ((T*)smemSus)[i] = TR::fromFloat(operandValue(kind, (unsigned)i * 2654435761u + blockIdx.x, (2 * i) % 8192 < 6144));
     __syncthreads();
   }
   const unsigned long long c0 = clock64(), w0 = wall_clock64();

@@ -41,7 +41,8 @@ int kmx_bench_mfma(int waves_per_wg, int wgs, int mode, int steps, int iters, do
 /* What the matrix cores SUSTAIN, by operand data (round 6): the loop above - shape bit 0 clear: the bare chain of 18 MFMAs per step on a 3 x 3
  * tile of accumulators, set: the convolution's step (+ 12 ds_read_b128 + one s_barrier); shape bits 1-2 (fp16 only): the order in which a k
  * half's nine MFMAs go out - 0 weight fragment outer (the convolution's), 1 the same as a snake, 2 image fragment outer - on `wgs` work-groups of 8 waves for `seconds` seconds,
- * operands of data_kind 0 zeros, 1 a smooth ramp of small positive numbers (what kmx_bench_mfma multiplies), 2 uniform noise in [-1, 1);
+ * operands of data_kind 0 zeros, 1 a smooth ramp of small positive numbers (what kmx_bench_mfma multiplies), 2 uniform noise in [-1, 1),
+ * 3 the distributions of the bench's own operands (normal weights of a random-init 192-channel 3x3 layer x mish of a unit normal at 1/8);
  * precision_mode KMX_PREC_FP16 | KMX_PREC_BF16. TFLOP/s over the whole run and the shader clock inside the last launch: on noise the chip
  * clocks down whatever else the kernel does, and that - not 2.4 GHz x 256 CUs - is the rate a convolution on real activations can be held
  * against. tools/mfma_power_probe.py, bench.py's `box`. */

@@ -536,7 +536,7 @@ int kmx_bench_mfma(int waves_per_wg, int wgs, int mode, int steps, int iters, do
 
 int kmx_bench_mfma_sustained(int wgs, int shape, int data_kind, int precision_mode, double seconds, double* tflops, double* core_mhz) {
   return guarded([&] {
-    if(!tflops || wgs < 1 || wgs > 65536 || shape < 0 || shape > 5 || data_kind < 0 || data_kind > 2 || !(seconds > 0.0) || seconds > 30.0 ||
+    if(!tflops || wgs < 1 || wgs > 65536 || shape < 0 || shape > 5 || data_kind < 0 || data_kind > 3 || !(seconds > 0.0) || seconds > 30.0 ||
        (precision_mode != KMX_PREC_FP16 && precision_mode != KMX_PREC_BF16))
       throw Error(KMX_ERR_INVALID_ARG, "kmx_bench_mfma_sustained: bad argument");
     (void)deviceCountOrThrow();

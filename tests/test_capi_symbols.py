@@ -55,9 +55,9 @@ def test_tuning_hooks_refuse_bad_arguments_without_gpu():
     for args in ((0, 8192, 0, 10, 1), (18, 4096, 0, 10, 1), (18, 8192, 3, 10, 1), (18, 8192, 0, 0, 1), (18, 200 * 1024, 0, 10, 1)):
         assert lib.kmx_bench_launch_floor(*args, ctypes.byref(us)) == capi.KMX_ERR_INVALID_ARG, args
     assert lib.kmx_bench_launch_floor(18, 8192, 0, 10, 1, None) == capi.KMX_ERR_INVALID_ARG
-    # kmx_bench_mfma_sustained (round 6): work-groups, loop shape 0 | 1, operand kind 0..2, a 16-bit precision, 0 < seconds <= 30
+    # kmx_bench_mfma_sustained (round 6): work-groups, loop shape 0 | 1, operand kind 0..3, a 16-bit precision, 0 < seconds <= 30
     tf, mhz = ctypes.c_double(), ctypes.c_double()
-    for args in ((0, 1, 2, capi.PREC_FP16, 1.0), (256, 6, 2, capi.PREC_FP16, 1.0), (256, 1, 3, capi.PREC_FP16, 1.0),
+    for args in ((0, 1, 2, capi.PREC_FP16, 1.0), (256, 6, 2, capi.PREC_FP16, 1.0), (256, 1, 4, capi.PREC_FP16, 1.0),
                  (256, 1, 2, capi.PREC_FP32, 1.0), (256, 1, 2, capi.PREC_BF16, 0.0), (256, 1, 2, capi.PREC_BF16, 31.0)):
         assert lib.kmx_bench_mfma_sustained(*args, ctypes.byref(tf), ctypes.byref(mhz)) == capi.KMX_ERR_INVALID_ARG, args
     assert lib.kmx_bench_mfma_sustained(256, 1, 2, capi.PREC_FP16, 1.0, None, None) == capi.KMX_ERR_INVALID_ARG

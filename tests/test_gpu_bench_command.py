@@ -57,6 +57,9 @@ def _check_line(d, steps, warmup):
     assert 500 < box["mfma_lds_barrier_loop_sustained_on_noise_operands_tflops"] <= sus * 1.02 and sus < r["peak"]
     assert r["sustained_mfma_only_on_noise_operands_tflops"] == sus and abs(r["frac_of_sustained"] - r["achieved"] / sus) < 1e-3
     assert r["frac"] < r["frac_of_sustained"] < 1.0
+    # ... and on operands distributed like the bench's own (kind 3): within a fifth of the noise figure, below the nominal peak
+    net = box["mfma_chain_sustained_on_net_like_operands_tflops"]
+    assert 0.8 * sus < net < 1.2 * sus and abs(r["frac_of_sustained_on_net_like_operands"] - r["achieved"] / net) < 1e-3, (sus, net)
 
 
 def test_driver_command_exits_zero_with_roofline_and_cpu_baseline():
