@@ -31,6 +31,19 @@ def pytest_configure(config):
             opt.tx = ["popen"] * n
 
 
+# The CPU suite's long files, longest first: with the workers above a file is handed to whichever worker is free, in collection order - and the
+# longest one (the mutated build of the emulated kernels + its runs, four minutes) came last in the alphabet, alone on the tail of the run.
+LONGEST_FIRST = ["test_kernels_wrong_count.py", "test_engine_emulated.py", "test_nneval_own.py", "test_kernels_latest_completion.py",
+                 "test_kernels_emulated_chain.py", "test_kernels_emulated_seam.py", "test_kernels_emulated_conv.py"]
+
+
+def pytest_collection_modifyitems(config, items):
+    if "not gpu" not in (config.option.markexpr or ""):
+        return
+    rank = {name: i for i, name in enumerate(LONGEST_FIRST)}
+    items.sort(key=lambda it: rank.get(os.path.basename(str(it.fspath)), len(rank)))  # (stable: everything else keeps its order)
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _built():
     """The HIP library and the oracle must exist; build them if a fresh checkout lacks them."""
